@@ -1,0 +1,172 @@
+"""Thin ctypes binding of libhrgym_hip.so (include/hrgym.h) + `HipBatch`, a tensor-level handle.
+
+There is NO CPU fallback: if the HIP library is missing or the GPU is unavailable this module raises.
+PyTorch-ROCm is used only to own device buffers / streams (plumbing); all compute is in the HIP library.
+"""
+import ctypes
+import os
+import subprocess
+
+from ._cstruct import CONST, EnvState, ModelDesc, ClipTable
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhrgym_hip.so")
+SRC = os.path.join(_HERE, "csrc", "hrgym_hip.hip")
+
+EXPORTS = [
+    "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
+    "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
+    "hrg_batch_kernel_time",
+]
+
+
+def build_library(force=False, verbose=False):
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    deps = [SRC] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
+        os.path.join(os.path.dirname(_HERE), "include", f) for f in ("hrgym.h", "hrgym_state.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
+        return LIB_PATH
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH, SRC]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library and declare signatures. Raises if it is missing (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+                           "There is no CPU fallback for the stepper.")
+    lib = ctypes.CDLL(LIB_PATH)
+    vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
+    lib.hrg_last_error.restype = ctypes.c_char_p
+    lib.hrg_version.restype = ctypes.c_char_p
+    lib.hrg_state_bytes.restype = ctypes.c_size_t
+    lib.hrg_batch_create.argtypes = [ctypes.POINTER(ModelDesc), ctypes.POINTER(ClipTable), i32, i64, i32, ctypes.POINTER(vp)]
+    lib.hrg_batch_destroy.argtypes = [vp]
+    lib.hrg_batch_destroy.restype = None
+    lib.hrg_batch_reset.argtypes = [vp, vp, vp, vp]
+    lib.hrg_batch_step.argtypes = [vp] * 8
+    lib.hrg_batch_contacts.argtypes = [vp, vp, vp]
+    lib.hrg_batch_capsules.argtypes = [vp, vp, vp, vp]
+    lib.hrg_batch_get_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_batch_set_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_batch_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
+    if lib.hrg_state_bytes() != ctypes.sizeof(EnvState):
+        raise RuntimeError("hrg_env_state layout mismatch between header mirror and library: rebuild")
+    _lib = lib
+    return lib
+
+
+class HrgError(RuntimeError):
+    pass
+
+
+def _check(lib, rc):
+    if rc != 0:
+        raise HrgError(f"hrgym error {rc}: {lib.hrg_last_error().decode()}")
+
+
+class HipBatch:
+    """n_envs ReachHuman environments resident on one MI355X.
+
+    All I/O buffers are torch tensors on the batch's device; `step` is asynchronous (ordered on torch's
+    current stream of that device)."""
+
+    def __init__(self, desc, clips, n_envs, env_id0=0, device=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("HipBatch needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
+        self.torch = torch
+        self.lib = load_library()
+        self.n = int(n_envs)
+        self.device = torch.device("cuda", device)
+        self._clips = clips  # keep host frame table alive during create
+        table = clips.table()
+        if desc.n_clips != clips.n_clips:
+            desc.n_clips = clips.n_clips
+        self.h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hrg_batch_create(ctypes.byref(desc), ctypes.byref(table), self.n, int(env_id0), device, ctypes.byref(self.h)))
+            C = CONST
+            self.obs = torch.zeros((self.n, C["HRG_OBS_DIM"]), dtype=torch.float32, device=self.device)
+            self.term_obs = torch.zeros((self.n, C["HRG_OBS_DIM"]), dtype=torch.float32, device=self.device)
+            self.reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+            self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+            self.info = torch.zeros((self.n, C["HRG_INFO_DIM"]), dtype=torch.int32, device=self.device)
+
+    def _stream(self):
+        return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def reset(self, mask=None):
+        """Reset all envs (mask None) or those with mask != 0 (uint8 tensor on device). Returns obs tensor."""
+        mp = None
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=self.torch.uint8).contiguous()
+            mp = ctypes.c_void_p(mask.data_ptr())
+        with self.torch.cuda.device(self.device):
+            _check(self.lib, self.lib.hrg_batch_reset(self.h, mp, ctypes.c_void_p(self.obs.data_ptr()), self._stream()))
+        return self.obs
+
+    def step(self, actions):
+        """actions: float64 tensor [n, 7] on device. Returns (obs, reward, done, info) device tensors (views)."""
+        t = self.torch
+        if actions.dtype != t.float64 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=t.float64).contiguous()
+        if tuple(actions.shape) != (self.n, CONST["HRG_ACT_DIM"]):
+            raise ValueError(f"actions must be [{self.n}, {CONST['HRG_ACT_DIM']}]")
+        vp = ctypes.c_void_p
+        with t.cuda.device(self.device):
+            _check(self.lib, self.lib.hrg_batch_step(self.h, vp(actions.data_ptr()), vp(self.obs.data_ptr()), vp(self.term_obs.data_ptr()),
+                                                   vp(self.reward.data_ptr()), vp(self.done.data_ptr()), vp(self.info.data_ptr()), self._stream()))
+        self._keep = actions
+        return self.obs, self.reward, self.done, self.info
+
+    def get_state(self, e):
+        s = EnvState()
+        _check(self.lib, self.lib.hrg_batch_get_state(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
+        return s
+
+    def set_state(self, e, s):
+        _check(self.lib, self.lib.hrg_batch_set_state(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
+
+    def contacts(self):
+        import numpy as np
+        pairs = np.zeros((self.n, CONST["HRG_NCON_MAX"], 2), np.int32)
+        ncon = np.zeros(self.n, np.int32)
+        _check(self.lib, self.lib.hrg_batch_contacts(self.h, pairs.ctypes.data_as(ctypes.c_void_p), ncon.ctypes.data_as(ctypes.c_void_p)))
+        return pairs, ncon
+
+    def capsules(self):
+        import numpy as np
+        r = np.zeros((self.n, CONST["HRG_NSHIELD_RCAP"], 7))
+        h = np.zeros((self.n, CONST["HRG_NHCAP_MAX"], 7))
+        nh = np.zeros(self.n, np.int32)
+        vp = ctypes.c_void_p
+        _check(self.lib, self.lib.hrg_batch_capsules(self.h, r.ctypes.data_as(vp), h.ctypes.data_as(vp), nh.ctypes.data_as(vp)))
+        return r, h, nh
+
+    def kernel_time(self):
+        """(avg kernel ms, launches) of the step kernels since the previous call (HIP events on the launch stream).
+        The first call arms the timer."""
+        ms, n = ctypes.c_double(), ctypes.c_int64()
+        _check(self.lib, self.lib.hrg_batch_kernel_time(self.h, ctypes.byref(ms), ctypes.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.lib.hrg_batch_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

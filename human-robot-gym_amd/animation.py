@@ -1,0 +1,126 @@
+"""Human animation clips: packed frame table shared by all envs of a batch.
+
+Reference format (utils/animation_utils.py:11-59, utils/convert_bvh.py:76-126): per clip a dict of per-frame
+arrays `Pelvis_pos_{x,y,z}`, `Pelvis_quat` (x,y,z,w), `<Joint>_{x,y,z}` for the 23 joints (radians, clipped to
++-1.56) plus an info dict {position_offset, orientation_quat (x,y,z,w), scale}.  The mocap submodule that holds
+the real CMU clips is empty in the reference checkout, so benches and tests use SYNTHETIC clips of the same
+schema (`synthetic_clips`), as SURVEY.md §8(d) prescribes.
+"""
+import ctypes
+import json
+
+import numpy as np
+
+from ._cstruct import CONST, ClipTable
+from .model import load_assets
+
+FRAME_DIM = CONST["HRG_FRAME_DIM"]
+
+DEFAULT_CLIP_NAMES = [  # config/environment/default/reach_human.yaml:18-31
+    "CMU/62_01", "CMU/62_03", "CMU/62_04", "CMU/62_07", "CMU/62_09", "CMU/62_10", "CMU/62_12",
+    "CMU/62_13", "CMU/62_14", "CMU/62_15", "CMU/62_16", "CMU/62_18", "CMU/62_19",
+]
+
+
+def _qpos_joint_order():
+    """Names of the 69 human hinge joints in qpos order (human.xml body DFS order, per body z,y,x)."""
+    A = load_assets()
+    out = []
+    for b in A["human"]["bodies"][1:]:
+        out += b["joint_names"]
+    return out
+
+
+class ClipSet:
+    """A list of (animation dict, info dict) pairs packed into one float64 frame table."""
+
+    def __init__(self, clips):
+        if not 1 <= len(clips) <= CONST["HRG_MAX_CLIPS"]:
+            raise ValueError(f"need 1..{CONST['HRG_MAX_CLIPS']} clips")
+        order = _qpos_joint_order()
+        frames, self.lengths, self.infos = [], [], []
+        for anim, info in clips:
+            n = len(anim["Pelvis_pos_x"])
+            F = np.zeros((n, FRAME_DIM))
+            F[:, 0], F[:, 1], F[:, 2] = anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"]
+            F[:, 3:7] = np.asarray(anim["Pelvis_quat"])
+            for k, name in enumerate(order):
+                F[:, 7 + k] = anim[name]
+            frames.append(F)
+            self.lengths.append(n)
+            self.infos.append(info or {"position_offset": [0.0, 0.0, 0.0], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0})
+        self.frames = np.ascontiguousarray(np.concatenate(frames, 0))
+        self.n_clips = len(clips)
+
+    def table(self):
+        """ctypes `hrg_clip_table` pointing at self.frames (keep `self` alive while it is in use)."""
+        t = ClipTable()
+        t.n_clips = self.n_clips
+        off = 0
+        for i, n in enumerate(self.lengths):
+            t.clip_len[i] = n
+            t.clip_offset[i] = off
+            t.clip_pos_offset[i][:] = [float(x) for x in self.infos[i]["position_offset"]]
+            t.clip_quat[i][:] = [float(x) for x in self.infos[i]["orientation_quat"]]
+            off += n
+        t.frames = self.frames.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        t.total_frames = off
+        return t
+
+
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0):
+    """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
+    random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
+    rng = np.random.RandomState(seed)
+    order = _qpos_joint_order()
+    clips = []
+    for _ in range(n_clips):
+        n = int(rng.randint(min_frames, max_frames + 1))
+        t = np.arange(n) / fps
+
+        def band(sigma, cutoff, k=6):
+            f = rng.uniform(0.05, cutoff, size=k)
+            ph = rng.uniform(0, 2 * np.pi, size=k)
+            a = rng.randn(k)
+            a *= sigma / np.sqrt(0.5 * np.sum(a * a) + 1e-12)
+            return (a[:, None] * np.sin(2 * np.pi * f[:, None] * t[None, :] + ph[:, None])).sum(0)
+
+        anim = {}
+        anim["Pelvis_pos_x"] = np.clip(band(0.15, 0.3), -0.3, 0.3)
+        anim["Pelvis_pos_y"] = 1.0 + np.clip(band(0.01, 1.0), -0.03, 0.03)
+        anim["Pelvis_pos_z"] = np.clip(band(0.15, 0.3), -0.3, 0.3)
+        yaw = band(0.4, 0.2)
+        anim["Pelvis_quat"] = np.stack([np.zeros(n), np.sin(yaw / 2), np.zeros(n), np.cos(yaw / 2)], 1)  # about Y (up)
+        for name in order:
+            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else 0.3  # convert_bvh.py:55-72 None joints
+            anim[name] = np.clip(band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.zeros(n)
+        info = {"position_offset": [0.0, 0.0, 0.0], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
+        clips.append((anim, info))
+    return ClipSet(clips)
+
+
+def static_clip(n_frames=600, pelvis=(0.0, 1.0, 0.0)):
+    """A T-pose human standing still (the `Static/tpose` clip of the shield demos)."""
+    order = _qpos_joint_order()
+    anim = {k: np.zeros(n_frames) for k in order}
+    anim["Pelvis_pos_x"] = np.full(n_frames, pelvis[0])
+    anim["Pelvis_pos_y"] = np.full(n_frames, pelvis[1])
+    anim["Pelvis_pos_z"] = np.full(n_frames, pelvis[2])
+    anim["Pelvis_quat"] = np.tile(np.array([0.0, 0.0, 0.0, 1.0]), (n_frames, 1))
+    return ClipSet([(anim, None)])
+
+
+def load_clips_npz(paths):
+    """Load user-supplied clips stored as .npz (same keys as the reference pkl dicts) + optional _info.json."""
+    clips = []
+    for p in paths:
+        with np.load(p, allow_pickle=False) as z:
+            anim = {k: z[k] for k in z.files}
+        info = None
+        try:
+            with open(p[: -len(".npz")] + "_info.json") as f:
+                info = json.load(f)
+        except FileNotFoundError:
+            pass
+        clips.append((anim, info))
+    return ClipSet(clips)

@@ -1,0 +1,362 @@
+// hrgym_device.h — device-side building blocks of the batched ReachHuman stepper (gfx950 / CDNA4).
+//
+// Execution model: ONE WAVEFRONT (64 lanes) PER ENVIRONMENT, one 64-thread workgroup per wavefront.
+// The env's resident state block is staged HBM -> LDS once per policy step, all 25 shield cycles run out
+// of LDS/registers, and the block is written back once.  Inside a cycle, lanes take different roles:
+//   lanes = human bodies (24)        : tree kinematics, parent frames fetched with wave shuffles
+//   lanes = human reach capsules (<=64) x loop over 7 robot capsules : swept-capsule verification, __ballot
+//   lanes = capsule pairs            : contact broadphase/narrowphase (segment-segment), ballot compaction
+//   lanes = joints (6)               : long-term-trajectory planning (bisection), trajectory evaluation
+//   lanes = constraint rows (<=64)   : Newton solver rows live in registers, wave reductions for the line search
+//   lanes = (i,j) of the 8x8 mass matrix, lanes = kinematic configurations (3 chain FKs at once)
+// Small serial pieces (RNEA recursion, 8x8 Cholesky, path profiles) run wave-uniform: every lane computes the
+// same value and stores the same value, so no intra-wave hand-off is needed for them.
+// No MFMA: the work is tree-structured 3x3/6x6/8x8 FP64, not a dense contraction.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hrgym.h"
+#include "../../include/hrgym_state.h"
+
+#define NV HRG_NV
+#define NARM HRG_NARM
+#define DI __device__ __forceinline__
+#define HRG_PI 3.14159265358979323846
+
+#define GEOM_HUMAN0 HRG_NRCAP
+#define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
+#define GEOM_FLOOR (GEOM_TABLE + 1)
+
+// ------------------------------------------------------------------------------------------------ model
+struct DevModel {
+  hrg_model_desc m;
+  double Rbase[9];
+  double Rq[NV][9];          // body_quat as matrices
+  int32_t anc_mask[NV];      // bit i set: body i is an ancestor-or-self of body j
+  int32_t hb_maxdepth;
+  // human reach capsule table (one entry per lane): kind 0 ACC, 1 VEL, 2 POS ball, 3 POS part
+  int32_t hc_n;
+  int32_t hc_kind[HRG_NHCAP_MAX], hc_j1[HRG_NHCAP_MAX], hc_j2[HRG_NHCAP_MAX];
+  double hc_th[HRG_NHCAP_MAX], hc_v[HRG_NHCAP_MAX], hc_a[HRG_NHCAP_MAX], hc_len[HRG_NHCAP_MAX];
+  // robot self-collision candidate pairs in enumeration order
+  int32_t n_self;
+  int32_t self_i[64], self_j[64];
+  // animation clips (frames in device memory)
+  hrg_clip_table clips;
+};
+
+struct Contact {
+  int32_t g1, g2, b1, b2;
+  double dist, n[3], pos[3];
+};
+
+// per-workgroup (= per-env) LDS image
+struct Lds {
+  hrg_env_state st;
+  // robot tree at the simulation state
+  double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], com[NV][3], Iw[NV][6], vw[NV][3], vv[NV][3];
+  double cI[NV][10], F[NV][6];
+  double aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
+  double M[NV * NV], LM[NV * NV], H[NV * NV];
+  double bias[NV], a0[NV], Ma0[NV], ctrl[NV], qacc[NV], g[NV], d[NV], Md[NV];
+  // shield
+  double cq[NARM], cv[NARM], ca[NARM], qe[NARM];
+  double scap[2][HRG_NSHIELD_RCAP][6];
+  double rc[HRG_NSHIELD_RCAP][7];
+  union U {
+    hrg_ltt cand;                       // live inside shield_step only
+    struct { double J[64][NV], gg[64], hh[64]; } efc;  // live inside the constraint solve only
+  } u;
+  // contacts
+  double hcap[HRG_NHB][6];
+  double rcapw[HRG_NRCAP][6];
+  double rcen[HRG_NRCAP][3];
+  Contact con[HRG_NCON_MAX];
+};
+
+// ------------------------------------------------------------------------------------------------ math
+DI void v3set(double* r, double a, double b, double c) { r[0] = a; r[1] = b; r[2] = c; }
+DI void v3cpy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+DI void v3add(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+DI void v3sub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+DI void v3scl(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
+DI void v3madd(double* r, const double* a, const double* b, double s) { r[0] = a[0] + b[0] * s; r[1] = a[1] + b[1] * s; r[2] = a[2] + b[2] * s; }
+DI double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+DI double v3norm(const double* a) { return sqrt(v3dot(a, a)); }
+DI void v3cross(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+DI void m3mulv(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+DI void m3mul(double* R, const double* A, const double* B) {
+  double T[9];
+#pragma unroll
+  for (int i = 0; i < 3; i++)
+#pragma unroll
+    for (int j = 0; j < 3; j++) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
+  for (int i = 0; i < 9; i++) R[i] = T[i];
+}
+DI void quat2mat(double* M, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = 1 - 2 * (y * y + z * z); M[1] = 2 * (x * y - w * z); M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z); M[4] = 1 - 2 * (x * x + z * z); M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y); M[7] = 2 * (y * z + w * x); M[8] = 1 - 2 * (x * x + y * y);
+}
+DI void quatmul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+DI void axisangle2mat(double* M, const double* ax, double ang) {
+  double s, c;
+  sincos(ang, &s, &c);
+  double t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+  M[0] = t * x * x + c; M[1] = t * x * y - s * z; M[2] = t * x * z + s * y;
+  M[3] = t * x * y + s * z; M[4] = t * y * y + c; M[5] = t * y * z - s * x;
+  M[6] = t * x * z - s * y; M[7] = t * y * z + s * x; M[8] = t * z * z + c;
+}
+DI double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+// wave-wide helpers (wave = 64 lanes on gfx950)
+DI double wave_sum(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+DI double wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+  return v;
+}
+DI void wave_sync() { __syncthreads(); }  // workgroup == one wave: orders LDS traffic between lane roles
+
+// ------------------------------------------------------------------------------------------------ RNG
+DI uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+DI double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream, uint64_t idx) {
+  uint64_t h = mix64(seed);
+  h = mix64(h ^ (env * 0xD1B54A32D192ED03ULL));
+  h = mix64(h ^ (episode * 0x8CB92BA72F3D8DD7ULL));
+  h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3 };
+DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
+  double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
+  return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);
+}
+
+// ------------------------------------------------------------------------------------------------ segments
+// closest points of two segments; returns squared distance (Ericson 5.1.9)
+DI double seg_seg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) {
+  double d1[3], d2[3], r[3];
+  v3sub(d1, q1, p1);
+  v3sub(d2, q2, p2);
+  v3sub(r, p1, p2);
+  double a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), s, t;
+  const double EPS = 1e-12;
+  if (a <= EPS && e <= EPS) { s = t = 0; }
+  else if (a <= EPS) { s = 0; t = clampd(f / e, 0, 1); }
+  else {
+    double c = v3dot(d1, r);
+    if (e <= EPS) { t = 0; s = clampd(-c / a, 0, 1); }
+    else {
+      double b = v3dot(d1, d2), den = a * e - b * b;
+      s = den > EPS * a * e ? clampd((b * f - c * e) / den, 0, 1) : 0;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = clampd(-c / a, 0, 1); }
+      else if (t > 1) { t = 1; s = clampd((b - c) / a, 0, 1); }
+    }
+  }
+  v3madd(c1, p1, d1, s);
+  v3madd(c2, p2, d2, t);
+  double d[3];
+  v3sub(d, c1, c2);
+  return v3dot(d, d);
+}
+
+// ------------------------------------------------------------------------------------------------ profiles
+DI double scurve_time(double dv, double amax, double jmax) {
+  double ad = fabs(dv);
+  return ad >= amax * amax / jmax ? ad / amax + amax / jmax : 2 * sqrt(ad / jmax);
+}
+DI double dist_nocruise(double va, double vc, double amax, double jmax) {
+  return 0.5 * (va + vc) * scurve_time(vc - va, amax, jmax) + 0.5 * vc * scurve_time(vc, amax, jmax);
+}
+DI void scurve(double va, double vb, double amax, double jmax, double* dur, double* jerk) {
+  double d = vb - va, ad = fabs(d), sg = d >= 0 ? 1.0 : -1.0;
+  if (ad >= amax * amax / jmax) {
+    double tj = amax / jmax;
+    dur[0] = tj; dur[1] = ad / amax - tj; dur[2] = tj;
+  } else {
+    double tj = sqrt(ad / jmax);
+    dur[0] = tj; dur[1] = 0; dur[2] = tj;
+  }
+  jerk[0] = sg * jmax; jerk[1] = 0; jerk[2] = -sg * jmax;
+}
+
+// one joint of a long-term trajectory (executed by lane j < 6)
+DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax) {
+  double* dur = L->dur[j];
+  double* jerk = L->jerk[j];
+  for (int i = 0; i < HRG_LTT_NSEG; i++) { dur[i] = 0; jerk[i] = 0; }
+  L->q0[j] = q0; L->v0[j] = v0; L->a0[j] = a0; L->qT[j] = goal;
+  int n = 0;
+  double q = q0, v = v0;
+  if (a0 != 0) {
+    double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
+    dur[n] = t; jerk[n] = jj; n++;
+    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
+    v += a0 * t + 0.5 * jj * t * t;
+  } else n++;
+  double D = goal - q;
+  double dstop = 0.5 * v * scurve_time(v, amax, jmax);
+  double sg = (D - dstop) >= 0 ? 1.0 : -1.0;
+  if (sg * v < 0) {
+    scurve(v, 0, amax, jmax, dur + n, jerk + n);
+    D -= dstop;
+    v = 0;
+  }
+  n += 3;
+  double w_lo = fabs(v), w_hi = vmax > w_lo ? vmax : w_lo, w, tc = 0;
+  double Dm = sg * D, vm = sg * v;
+  if (Dm >= dist_nocruise(vm, w_hi, amax, jmax)) {
+    w = w_hi;
+    tc = w > 0 ? (Dm - dist_nocruise(vm, w, amax, jmax)) / w : 0;
+  } else {
+    double lo = w_lo, hi = w_hi;
+    for (int it = 0; it < 64; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (dist_nocruise(vm, mid, amax, jmax) <= Dm) lo = mid; else hi = mid;
+    }
+    w = lo;
+  }
+  scurve(v, sg * w, amax, jmax, dur + n, jerk + n);
+  n += 3;
+  dur[n] = tc; jerk[n] = 0; n++;
+  scurve(sg * w, 0, amax, jmax, dur + n, jerk + n);
+}
+
+DI void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double* a) {
+  double qq = L->q0[j], vv = L->v0[j], aa = L->a0[j], t = s;
+  if (t < 0) t = 0;
+  for (int i = 0; i < HRG_LTT_NSEG; i++) {
+    double d = L->dur[j][i], jj = L->jerk[j][i];
+    if (t < d) {
+      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *v = vv + aa * t + 0.5 * jj * t * t;
+      *a = aa + jj * t;
+      return;
+    }
+    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    vv += aa * d + 0.5 * jj * d * d;
+    aa += jj * d;
+    t -= d;
+  }
+  *q = L->qT[j]; *v = 0; *a = 0;
+}
+
+DI void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, double amax, double jmax) {
+  P->s0 = s0; P->v0 = v0; P->a0 = a0; P->k = 0;
+  for (int i = 0; i < 3; i++) { P->dur[i] = 0; P->jerk[i] = 0; }
+  if (fabs(v0 - ve) < 1e-12 && fabs(a0) < 1e-12) { P->v0 = ve; P->a0 = 0; return; }
+  double v_at = v0 + a0 * fabs(a0) / (2 * jmax);
+  double dir = ve >= v_at ? 1.0 : -1.0;
+  double A = dir * a0, dv = dir * (ve - v0);
+  double apk = amax > A ? amax : A;
+  double t1 = (apk - A) / jmax, t3 = apk / jmax;
+  double dv2 = dv - 0.5 * (A + apk) * t1 - 0.5 * apk * t3, t2;
+  if (dv2 >= 0) t2 = dv2 / apk;
+  else {
+    double r = 0.5 * A * A + jmax * dv;
+    apk = sqrt(r > 0 ? r : 0);
+    if (apk < A) apk = A;
+    t1 = (apk - A) / jmax; t2 = 0; t3 = apk / jmax;
+  }
+  P->dur[0] = t1; P->dur[1] = t2; P->dur[2] = t3;
+  P->jerk[0] = dir * jmax; P->jerk[1] = 0; P->jerk[2] = -dir * jmax;
+}
+DI double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
+DI void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
+  double ss = P->s0, vv = P->v0, aa = P->a0;
+  for (int i = 0; i < 3; i++) {
+    double d = P->dur[i], jj = P->jerk[i];
+    if (t < d) {
+      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *v = vv + aa * t + 0.5 * jj * t * t;
+      *a = aa + jj * t;
+      return;
+    }
+    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    vv += aa * d + 0.5 * jj * d * d;
+    aa += jj * d;
+    t -= d;
+  }
+  *s = ss + ve * t; *v = ve; *a = 0;
+}
+
+// ------------------------------------------------------------------------------------------------ spatial inertia
+DI void sinertia_body(double* s /*10*/, double m, const double* c, const double* Ic) {
+  s[0] = m;
+  s[1] = c[0] * m; s[2] = c[1] * m; s[3] = c[2] * m;
+  double cc = v3dot(c, c);
+  s[4] = Ic[0] + m * (cc - c[0] * c[0]);
+  s[5] = Ic[1] + m * (cc - c[1] * c[1]);
+  s[6] = Ic[2] + m * (cc - c[2] * c[2]);
+  s[7] = Ic[3] - m * c[0] * c[1];
+  s[8] = Ic[4] - m * c[0] * c[2];
+  s[9] = Ic[5] - m * c[1] * c[2];
+}
+DI void sinertia_mul(double* n, double* f, const double* s, const double* w, const double* v) {
+  double hv[3], hw[3];
+  v3cross(hv, s + 1, v);
+  v3cross(hw, s + 1, w);
+  n[0] = s[4] * w[0] + s[7] * w[1] + s[8] * w[2] + hv[0];
+  n[1] = s[7] * w[0] + s[5] * w[1] + s[9] * w[2] + hv[1];
+  n[2] = s[8] * w[0] + s[9] * w[1] + s[6] * w[2] + hv[2];
+  f[0] = s[0] * v[0] - hw[0];
+  f[1] = s[0] * v[1] - hw[1];
+  f[2] = s[0] * v[2] - hw[2];
+}
+
+// wave-uniform 8x8 Cholesky / solve on LDS arrays
+DI int chol8(double* A) {
+  for (int j = 0; j < NV; j++) {
+    double d = A[j * NV + j];
+    for (int k = 0; k < j; k++) d -= A[j * NV + k] * A[j * NV + k];
+    if (!(d > 0)) return 0;
+    d = sqrt(d);
+    A[j * NV + j] = d;
+    for (int i = j + 1; i < NV; i++) {
+      double s = A[i * NV + j];
+      for (int k = 0; k < j; k++) s -= A[i * NV + k] * A[j * NV + k];
+      A[i * NV + j] = s / d;
+    }
+  }
+  return 1;
+}
+DI void chol8_solve(const double* L, double* x) {
+  for (int i = 0; i < NV; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i * NV + k] * x[k];
+    x[i] = s / L[i * NV + i];
+  }
+  for (int i = NV - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < NV; k++) s -= L[k * NV + i] * x[k];
+    x[i] = s / L[i * NV + i];
+  }
+}

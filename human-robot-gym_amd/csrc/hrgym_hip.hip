@@ -1,0 +1,689 @@
+// hrgym_hip.hip — step/reset kernels and the extern "C" ABI of libhrgym_hip.so (include/hrgym.h).
+// One 64-lane wavefront per environment; see hrgym_device.h for the lane-role map.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "hrgym_kernels.h"
+
+// ================================================================================================ solver
+// mj_step for the robot tree (environments/manipulation/human_env.py:523): smooth acceleration, soft
+// constraints (friction loss, joint limits, pyramidal contacts) by primal Newton + exact line search,
+// semi-implicit Euler with implicit joint damping.  Lanes = constraint rows in fixed slots:
+//   0..7 friction loss of dof r | 8..23 joint limit (dof, lo/hi) | 24..63 contact c, pyramid edge d.
+DI void impedance(const hrg_model_desc& m, double x0, double* imp, double* K, double* Bd) {
+  const double d0 = m.solimp[0], dmax = m.solimp[1], width = m.solimp[2], mid = m.solimp[3], power = m.solimp[4];
+  const double x = fabs(x0) / width;
+  double y;
+  if (x >= 1) y = 1;
+  else if (x <= 0) y = 0;
+  else if (x <= mid) y = pow(x / mid, power) * mid;
+  else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+  *imp = d0 + y * (dmax - d0);
+  double tc = m.solref[0];
+  const double dr = m.solref[1];
+  if (tc < 2 * m.timestep) tc = 2 * m.timestep;
+  *K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+  *Bd = 2.0 / (dmax * tc);
+}
+
+DI void row_cost(int type, double D, double floss, double x, double* c, double* g, double* h) {
+  if (type == 1) {
+    if (x < 0) { *c = 0.5 * D * x * x; *g = D * x; *h = D; } else { *c = 0; *g = 0; *h = 0; }
+  } else {
+    const double lim = floss / D;
+    if (x <= -lim) { *c = floss * (-x - 0.5 * lim); *g = -floss; *h = 0; }
+    else if (x >= lim) { *c = floss * (x - 0.5 * lim); *g = floss; *h = 0; }
+    else { *c = 0.5 * D * x * x; *g = D * x; *h = D; }
+  }
+}
+
+// returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
+DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  const double h = m.timestep;
+  L.LM[lane] = L.M[lane];
+  if (lane < NV) {
+    const int i = lane;
+    double act = L.ctrl[i];
+    if (i >= NARM) act = clampd(m.finger_kp * (L.ctrl[i] - s.qpos[i]), m.finger_forcerange[0], m.finger_forcerange[1]);
+    L.a0[i] = act - m.jnt_damping[i] * s.qvel[i] - L.bias[i];
+    L.qacc[i] = s.qacc_warmstart[i];
+  }
+  wave_sync();
+  if (!chol8(L.LM)) return 1;
+  chol8_solve(L.LM, L.a0);
+  // ---- build this lane's row ----
+  double J[NV];
+#pragma unroll
+  for (int i = 0; i < NV; i++) J[i] = 0;
+  int type = 1;
+  bool cand = false;
+  double pos = 0, margin = 0, floss = 0;
+  const int r = lane;
+  if (r < NV) {
+    if (m.jnt_frictionloss[r] > 0) {
+      cand = true; type = 0; floss = m.jnt_frictionloss[r];
+#pragma unroll
+      for (int i = 0; i < NV; i++) J[i] = (i == r) ? 1.0 : 0.0;
+    }
+  } else if (r < 24) {
+    const int k = r - 8, dof = k >> 1, side = k & 1;
+    const double dist = side ? m.jnt_range[dof][1] - s.qpos[dof] : s.qpos[dof] - m.jnt_range[dof][0];
+    if (dist < 0) {
+      cand = true; pos = dist;
+#pragma unroll
+      for (int i = 0; i < NV; i++) J[i] = (i == dof) ? (side ? -1.0 : 1.0) : 0.0;
+    }
+  } else {
+    const int c = (r - 24) >> 2, d = (r - 24) & 3;
+    if (c < ncon && c < HRG_NCON_DYN) {
+      cand = true;
+      const Contact& cc = L.con[c];
+      const double n[3] = {cc.n[0], cc.n[1], cc.n[2]};
+      double t1[3], t2[3];
+      const double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+      v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+      v3scl(t1, t1, 1.0 / v3norm(t1));
+      v3cross(t2, n, t1);
+      const double* tt = d < 2 ? t1 : t2;
+      const double sg = (d & 1) ? -1.0 : 1.0;
+      double dir[3];
+      for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * tt[a];
+      pos = cc.dist;
+      margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+      const int am1 = cc.b1 >= 0 ? dm->anc_mask[cc.b1] : 0, am2 = cc.b2 >= 0 ? dm->anc_mask[cc.b2] : 0;
+#pragma unroll
+      for (int i = 0; i < NV; i++) {
+        double t[3], v[3];
+        v3cross(t, L.Sw[i], cc.pos);
+        v3add(v, L.Sv[i], t);
+        const double jv = v3dot(dir, v);
+        double acc = 0;
+        if ((am1 >> i) & 1) acc += -1.0 * jv;
+        if ((am2 >> i) & 1) acc += jv;
+        J[i] = acc;
+      }
+    }
+  }
+  double aref = 0, D = 0;
+  bool active = false;
+  {
+    double x[NV], A = 0, vel = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) { x[i] = J[i]; vel += J[i] * s.qvel[i]; }
+    // per-lane triangular solves against the shared factor
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+      double t = x[i];
+#pragma unroll
+      for (int k = 0; k < i; k++) t -= L.LM[i * NV + k] * x[k];
+      x[i] = t / L.LM[i * NV + i];
+    }
+#pragma unroll
+    for (int i = NV - 1; i >= 0; i--) {
+      double t = x[i];
+#pragma unroll
+      for (int k = i + 1; k < NV; k++) t -= L.LM[k * NV + i] * x[k];
+      x[i] = t / L.LM[i * NV + i];
+    }
+#pragma unroll
+    for (int i = 0; i < NV; i++) A += J[i] * x[i];
+    active = cand && A > 1e-14;
+    if (active) {
+      double imp, K, Bd;
+      impedance(m, pos - margin, &imp, &K, &Bd);
+      aref = -Bd * vel - K * imp * (pos - margin);
+      D = 1.0 / ((1 - imp) / imp * A);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < NV; i++) L.u.efc.J[r][i] = active ? J[i] : 0.0;
+  const uint64_t mask = __ballot(active);
+  if (lane < NV) {
+    double t = 0;
+    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.a0[j];
+    L.Ma0[lane] = t;
+  }
+  wave_sync();
+  if (mask == 0) {
+    if (lane < NV) L.qacc[lane] = L.a0[lane];
+    wave_sync();
+  } else {
+    // warm start vs unconstrained acceleration: keep the cheaper point
+    double cost[2];
+    for (int pass = 0; pass < 2; pass++) {
+      const double* x = pass ? L.a0 : L.qacc;
+      double c = 0;
+      for (int i = 0; i < NV; i++) {
+        double t = 0;
+        for (int j = 0; j < NV; j++) t += L.M[i * NV + j] * (x[j] - L.a0[j]);
+        c += 0.5 * (x[i] - L.a0[i]) * t;
+      }
+      double y = -aref, cc = 0, gg, hh;
+#pragma unroll
+      for (int i = 0; i < NV; i++) y += J[i] * x[i];
+      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
+      cost[pass] = c + wave_sum(cc);
+    }
+    wave_sync();
+    if (!(cost[0] < cost[1])) { if (lane < NV) L.qacc[lane] = L.a0[lane]; }
+    wave_sync();
+    for (int it = 0; it < m.solver_iters; it++) {
+      double y = -aref, cc = 0, gg = 0, hh = 0;
+#pragma unroll
+      for (int i = 0; i < NV; i++) y += J[i] * L.qacc[i];
+      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
+      L.u.efc.gg[r] = gg;
+      L.u.efc.hh[r] = hh;
+      wave_sync();
+      if (lane < NV) {
+        double t = -L.Ma0[lane];
+        for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
+        for (uint64_t mm = mask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.u.efc.J[q][lane] * L.u.efc.gg[q]; }
+        L.g[lane] = t;
+      }
+      {
+        const int i = lane >> 3, j = lane & 7;
+        double t = L.M[lane];
+        for (uint64_t mm = mask; mm;) {
+          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+          const double hq = L.u.efc.hh[q];
+          if (hq != 0) t += hq * L.u.efc.J[q][i] * L.u.efc.J[q][j];
+        }
+        L.H[lane] = t;
+      }
+      wave_sync();
+      double gn = 0, sc = 0;
+      for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
+      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      for (int i = 0; i < NV; i++) L.d[i] = -L.g[i];
+      if (!chol8(L.H)) break;
+      chol8_solve(L.H, L.d);
+      if (lane < NV) {
+        double t = 0;
+        for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.d[j];
+        L.Md[lane] = t;
+      }
+      double p = 0;
+#pragma unroll
+      for (int i = 0; i < NV; i++) p += J[i] * L.d[i];
+      wave_sync();
+      double dMd = 0, gd0 = 0;
+      for (int i = 0; i < NV; i++) {
+        dMd += L.d[i] * L.Md[i];
+        double t = -L.Ma0[i];
+        for (int j = 0; j < NV; j++) t += L.M[i * NV + j] * L.qacc[j];
+        gd0 += L.d[i] * t;
+      }
+      double al = 1.0, lo = 0, hi = -1, d1_0 = 0;
+      for (int ls = 0; ls < 40; ls++) {
+        double c2, g2 = 0, h2 = 0;
+        if (active) row_cost(type, D, floss, y + al * p, &c2, &g2, &h2);
+        const double d1 = gd0 + al * dMd + wave_sum(g2 * p);
+        const double d2 = dMd + wave_sum(h2 * p * p);
+        if (ls == 0) d1_0 = gd0 + wave_sum(gg * p);
+        if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+        if (d1 < 0) lo = al; else hi = al;
+        double nx = al - d1 / d2;
+        if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
+        else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+        al = nx;
+      }
+      wave_sync();
+      if (lane < NV) L.qacc[lane] += al * L.d[lane];
+      wave_sync();
+    }
+  }
+  // mj_checkAcc
+  const bool badacc = lane < NV && !(fabs(L.qacc[lane]) < 1e10);
+  if (__any(badacc)) return 1;
+  // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
+  {
+    const int i = lane >> 3, j = lane & 7;
+    L.H[lane] = L.M[lane] + (i == j ? h * m.jnt_damping[i] : 0.0);
+  }
+  if (lane < NV) {
+    s.qacc_warmstart[lane] = L.qacc[lane];
+    double t = 0;
+    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
+    L.d[lane] = t;
+  }
+  wave_sync();
+  if (!chol8(L.H)) return 1;
+  chol8_solve(L.H, L.d);
+  if (lane < NV) {
+    const double v = s.qvel[lane] + h * L.d[lane];
+    s.qvel[lane] = v;
+    s.qpos[lane] = s.qpos[lane] + h * v;
+  }
+  wave_sync();
+  return 0;
+}
+
+// ================================================================================================ env
+DI void goal_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int idx, double* g) {
+  const hrg_model_desc& m = dm->m;
+  for (int j = 0; j < NARM; j++) {
+    const double u = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_GOAL, (uint64_t)(idx * NARM + j));
+    g[j] = m.qpos_limits[0][j] + (m.qpos_limits[1][j] - m.qpos_limits[0][j]) * u;
+  }
+}
+
+// observation: object-state (vec/dist eef -> L hand, R hand, head; human_env.py:1536-1590) + goal_difference
+// (environments/manipulation/reach_human_env.py:649-651); lanes = observation entries
+DI void write_obs(const DevModel* __restrict__ dm, const Lds& L, int lane, const double* goal, float* out) {
+  const hrg_model_desc& m = dm->m;
+  const hrg_env_state& s = L.st;
+  if (lane < HRG_OBS_DIM) {
+    double v;
+    if (lane < 12) {
+      const int k = lane >> 2, a = lane & 3;
+      const int site = k == 0 ? m.site_lhand : (k == 1 ? m.site_rhand : m.site_head);
+      double d[3];
+      v3sub(d, s.human_site[site], s.eef_pos);
+      v = a < 3 ? d[a] : v3norm(d);
+    } else v = goal[lane - 12] - s.qpos[lane - 12];
+    out[lane] = (float)v;
+  }
+}
+
+DI void eef_update(const DevModel* __restrict__ dm, Lds& L) {
+  double t[3], e[3];
+  m3mulv(t, L.kR[NARM - 1], dm->m.eef_pos);
+  v3add(e, L.kp[NARM - 1], t);
+  v3cpy(L.st.eef_pos, e);
+}
+
+// HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
+// + FailsafeController.reset (failsafe_controller.py:204-250)
+DI void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  const int episode = s.episode + 1;
+  wave_sync();
+  for (int k = lane; k < (int)(sizeof(hrg_env_state) / sizeof(double)); k += 64) ((double*)&s)[k] = 0.0;
+  wave_sync();
+  s.episode = episode;
+  if (lane < NARM) s.qpos[lane] = m.init_qpos[lane] + m.init_noise * rng_gauss(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)lane);
+  else if (lane < NV) s.qpos[lane] = m.finger_init_qpos[lane - NARM];
+  const double ux = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 0), uy = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 1),
+               uz = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 2);
+  s.human_pos_offset[0] = m.base_human_pos_offset[0] + (2 * ux - 1) * m.human_rand[0];
+  s.human_pos_offset[1] = m.base_human_pos_offset[1] + (2 * uy - 1) * m.human_rand[1];
+  s.human_pos_offset[2] = m.base_human_pos_offset[2];
+  const double yaw = (2 * uz - 1) * m.human_rand[2];
+  s.human_rot_offset[0] = cos(0.5 * yaw); s.human_rot_offset[1] = 0; s.human_rot_offset[2] = 0; s.human_rot_offset[3] = sin(0.5 * yaw);
+  s.animation_time = -1;
+  wave_sync();
+  const double p0[3] = {0, 0, 0}, q0[4] = {1, 0, 0, 0};
+  human_fk_lanes(dm, L, lane, p0, q0, nullptr);
+  robot_chain_fk(dm, L, lane, false);
+  eef_update(dm, L);
+  shield_reset(dm, L, lane);
+  wave_sync();
+  if (obs_out) {
+    double g[NARM];
+    goal_of(dm, gid, episode, 0, g);
+    write_obs(dm, L, lane, g, obs_out);
+  }
+  wave_sync();
+}
+
+// HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
+// (wrappers/time_limit.py:31-44) + VecEnv auto-reset
+DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64_t gid, const double* __restrict__ action, float* obs, float* term_obs,
+                 float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  s.timestep = s.timestep + 1;
+  int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
+  double act = lane < HRG_ACT_DIM ? action[lane] : 0.0;
+  const double grip_a = __shfl(act, NARM, 64);
+  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) {
+    if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
+      if (lane < NARM) {
+        const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
+        const double otr = 0.5 * (m.act_out_max + m.act_out_min), itr = 0.5 * (m.act_in_max + m.act_in_min);
+        const double a = clampd(act, m.act_in_min, m.act_in_max);
+        const double g = clampd(s.qpos[lane] + ((a - itr) * scale + otr), m.qpos_limits[0][lane], m.qpos_limits[1][lane]);
+        s.goal_qpos[lane] = g;
+        s.new_goal_q[lane] = g;
+      }
+      s.new_goal = 1;
+      wave_sync();
+    }
+    // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
+    shield_step(dm, L, lane, e, dbg_r, dbg_h, dbg_nh);
+    robot_dynamics_terms(dm, L, lane);
+    if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
+      if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
+      wave_sync();
+    }
+    if (lane < NARM) { // run_controller, failsafe_controller.py:356-369
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += s.mass_matrix[lane * NARM + j] * (m.kp * (s.des_q[j] - s.qpos[j]) + m.kd * (s.des_v[j] - s.qvel[j]) + s.des_a[j]);
+      const double tq = clampd(t + L.bias[lane], m.arm_ctrlrange[lane][0], m.arm_ctrlrange[lane][1]);
+      s.torque[lane] = tq;
+      L.ctrl[lane] = tq;
+    }
+    { // gripper: RethinkGripper.format_action + ctrl-range mapping
+      const double sg = grip_a > 0 ? 1.0 : (grip_a < 0 ? -1.0 : 0.0);
+      const double ga = clampd(s.grip_action + m.gripper_speed * sg, -1.0, 1.0);
+      wave_sync();
+      s.grip_action = ga;
+      if (lane < HRG_NFINGER) {
+        const double lo = m.finger_ctrlrange[lane][0], hi = m.finger_ctrlrange[lane][1];
+        L.ctrl[NARM + lane] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (lane == 0 ? ga : -ga);
+      }
+    }
+    if (!failsafe_intervention && !s.is_safe) { failsafe_intervention = 1; s.failsafe_interventions = s.failsafe_interventions + 1; }
+    wave_sync();
+    human_control(dm, L, lane, gid); // _control_human + kinematics of sim.forward() #2
+    int ncon;
+    collide(dm, L, lane, &ncon);
+    classify(dm, L, ncon, &has_collision, &collision_type);
+    s.ncon = ncon;
+    if (lane < HRG_NCON_MAX) {
+      s.con_pairs[lane][0] = lane < ncon ? L.con[lane].g1 : -1;
+      s.con_pairs[lane][1] = lane < ncon ? L.con[lane].g2 : -1;
+    }
+    wave_sync();
+    crash = dynamics_step(dm, L, lane, ncon);
+    if (crash) break;
+    s.time = s.time + m.timestep;
+    eef_update(dm, L);
+    s.low_level_time = s.low_level_time + 1;
+    wave_sync();
+  }
+  // ---- observation / success / info / reward / done ----
+  double goal[NARM];
+  goal_of(dm, gid, s.episode, s.goal_index, goal);
+  write_obs(dm, L, lane, goal, term_obs);
+  double dist2 = 0;
+  for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
+  const double dist = sqrt(dist2);
+  const int goal_reached = !crash && dist <= m.goal_dist;
+  if (goal_reached) s.n_goal_reached = s.n_goal_reached + 1;
+  const int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0;
+  double r = goal_reached ? m.task_reward : -1.0;
+  if (m.reward_shaping) r += 1.0 + (-0.1 * dist);
+  if (illegal) r += m.collision_reward;
+  r *= m.reward_scale;
+  int d = 0;
+  if (crash) { r += m.sim_crash_reward; d = 1; }
+  else {
+    if (m.done_at_collision && illegal) d = 1;
+    if (m.done_at_success && goal_reached) d = 1;
+  }
+  const int ncoll = s.n_collisions_static + s.n_collisions_robot + s.n_collisions_human + s.n_collisions_critical;
+  int truncated = 0;
+  if (goal_reached) s.goal_index = (s.goal_index + 1) % m.n_goals;
+  if (s.timestep >= m.horizon) { truncated = !d; d = 1; }
+  if (lane < HRG_INFO_DIM) {
+    int v = 0;
+    switch (lane) {
+      case HRG_INFO_COLLISION: v = has_collision; break;
+      case HRG_INFO_COLLISION_TYPE: v = collision_type; break;
+      case HRG_INFO_N_COLLISIONS: v = ncoll; break;
+      case HRG_INFO_N_COLLISIONS_STATIC: v = s.n_collisions_static; break;
+      case HRG_INFO_N_COLLISIONS_ROBOT: v = s.n_collisions_robot; break;
+      case HRG_INFO_N_COLLISIONS_HUMAN: v = s.n_collisions_human; break;
+      case HRG_INFO_N_COLLISIONS_CRITICAL: v = s.n_collisions_critical; break;
+      case HRG_INFO_TIMEOUT: v = s.timestep >= m.horizon; break;
+      case HRG_INFO_FAILSAFE_INTERVENTIONS: v = s.failsafe_interventions; break;
+      case HRG_INFO_N_GOAL_REACHED: v = s.n_goal_reached; break;
+      case HRG_INFO_TRUNCATED: v = truncated; break;
+      case HRG_INFO_SIM_CRASH: v = crash; break;
+    }
+    info[lane] = v;
+  }
+  if (lane == 0) { *reward = (float)r; *done = (uint8_t)d; }
+  wave_sync();
+  if (d) env_reset(dm, L, lane, gid, obs);
+  else write_obs(dm, L, lane, goal, obs);
+}
+
+// ================================================================================================ kernels
+__global__ __launch_bounds__(64) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const double* __restrict__ actions,
+                                                     float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
+                                                     int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs) {
+  __shared__ Lds L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const double* src = (const double*)(states + e);
+  double* dst = (double*)&L.st;
+  constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
+  for (int k = lane; k < NW; k += 64) dst[k] = src[k];
+  wave_sync();
+  float* tobs = term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : scratch_obs + (size_t)e * HRG_OBS_DIM;
+  env_step(dm, L, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
+           info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh);
+  wave_sync();
+  double* out = (double*)(states + e);
+  for (int k = lane; k < NW; k += 64) out[k] = dst[k];
+}
+
+__global__ __launch_bounds__(64) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ obs, int64_t env_id0) {
+  __shared__ Lds L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  if (mask && !mask[e]) return;
+  const double* src = (const double*)(states + e);
+  double* dst = (double*)&L.st;
+  constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
+  for (int k = lane; k < NW; k += 64) dst[k] = src[k];
+  wave_sync();
+  env_reset(dm, L, lane, env_id0 + e, obs ? obs + (size_t)e * HRG_OBS_DIM : nullptr);
+  wave_sync();
+  double* out = (double*)(states + e);
+  for (int k = lane; k < NW; k += 64) out[k] = dst[k];
+}
+
+// ================================================================================================ host side
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIPCHK(x)                                                                                         \
+  do {                                                                                                    \
+    hipError_t _e = (x);                                                                                  \
+    if (_e != hipSuccess) return fail(HRG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e));        \
+  } while (0)
+
+struct hrg_batch {
+  int device = 0;
+  int32_t n_envs = 0;
+  int64_t env_id0 = 0;
+  DevModel* d_model = nullptr;
+  double* d_frames = nullptr;
+  hrg_env_state* d_states = nullptr;
+  double* d_rcaps = nullptr;
+  double* d_hcaps = nullptr;
+  int32_t* d_nh = nullptr;
+  float* d_scratch_obs = nullptr;
+  bool timing = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+};
+
+static void mat_from_quat(double* M, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = 1 - 2 * (y * y + z * z); M[1] = 2 * (x * y - w * z); M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z); M[4] = 1 - 2 * (x * x + z * z); M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y); M[7] = 2 * (y * z + w * x); M[8] = 1 - 2 * (x * x + y * y);
+}
+
+extern "C" {
+
+const char* hrg_last_error(void) { return g_err.c_str(); }
+const char* hrg_version(void) { return "hrgym-hip 0.1.0 (gfx950)"; }
+size_t hrg_state_bytes(void) { return sizeof(hrg_env_state); }
+
+int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
+  if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
+  if (desc->shield_type == HRG_SHIELD_PFL) return fail(HRG_ERR_UNSUPPORTED, "shield_type PFL is not implemented yet");
+  if (clips->n_clips < 1 || clips->n_clips > HRG_MAX_CLIPS || clips->n_clips != desc->n_clips) return fail(HRG_ERR_INVALID, "clip table / desc.n_clips mismatch");
+  for (int i = 0; i < NV; i++) {
+    if ((i < NARM) != (desc->jnt_type[i] == 0)) return fail(HRG_ERR_INVALID, "expected 6 hinges followed by 2 slides");
+    if (i < NARM && desc->body_parent[i] != i - 1) return fail(HRG_ERR_INVALID, "arm must be a serial chain");
+    if (i >= NARM && desc->body_parent[i] != NARM - 1) return fail(HRG_ERR_INVALID, "fingers must hang off the last link");
+  }
+  for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
+    if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
+  if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
+  HIPCHK(hipSetDevice(device));
+  hrg_batch* b = new hrg_batch();
+  b->device = device; b->n_envs = n_envs; b->env_id0 = env_id0;
+  // ---- device model ----
+  DevModel* hm = new DevModel();
+  memset(hm, 0, sizeof *hm);
+  hm->m = *desc;
+  mat_from_quat(hm->Rbase, desc->base_quat);
+  for (int i = 0; i < NV; i++) {
+    mat_from_quat(hm->Rq[i], desc->body_quat[i]);
+    int mask = 0;
+    for (int k = i; k >= 0; k = desc->body_parent[k]) mask |= 1 << k;
+    hm->anc_mask[i] = mask;
+  }
+  int maxd = 0;
+  for (int i = 0; i < HRG_NHB; i++) maxd = desc->hb_depth[i] > maxd ? desc->hb_depth[i] : maxd;
+  hm->hb_maxdepth = maxd;
+  int n = 0;
+  for (int k = 0; k < desc->n_bodypart; k++, n++) { hm->hc_kind[n] = 0; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_a[n] = desc->bp_amax[k]; hm->hc_v[n] = desc->bp_vmax[k]; }
+  for (int k = 0; k < desc->n_bodypart; k++, n++) { hm->hc_kind[n] = 1; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_v[n] = desc->bp_vmax[k]; }
+  for (int k = 0; k < desc->n_extremity; k++, n++) { hm->hc_kind[n] = 2; hm->hc_j1[n] = desc->ext_joint[k]; hm->hc_j2[n] = desc->ext_joint[k]; hm->hc_th[n] = desc->ext_thickness[k]; hm->hc_v[n] = desc->ext_vmax[k]; hm->hc_len[n] = desc->ext_length[k]; }
+  for (int k = 0; k < desc->n_bodypart; k++) {
+    if (!desc->bp_in_pos[k]) continue;
+    if (n >= HRG_NHCAP_MAX) { delete hm; delete b; return fail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
+    hm->hc_kind[n] = 3; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_v[n] = desc->bp_vmax[k];
+    n++;
+  }
+  if (n > HRG_NHCAP_MAX) { delete hm; delete b; return fail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
+  hm->hc_n = n;
+  int ns = 0;
+  for (int i = 0; i < HRG_NRCAP; i++)
+    for (int j = i + 1; j < HRG_NRCAP; j++)
+      if ((desc->rcap_selfmask[i] >> j) & 1u) { hm->self_i[ns] = i; hm->self_j[ns] = j; ns++; }
+  hm->n_self = ns;
+  // clips
+  const size_t fbytes = sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames;
+  int64_t tot = 0;
+  for (int c = 0; c < clips->n_clips; c++) {
+    if (clips->clip_len[c] < 1 || clips->clip_offset[c] != tot) { delete hm; delete b; return fail(HRG_ERR_INVALID, "clip table must be densely packed"); }
+    tot += clips->clip_len[c];
+  }
+  if (tot != clips->total_frames) { delete hm; delete b; return fail(HRG_ERR_INVALID, "clip table total_frames mismatch"); }
+  HIPCHK(hipMalloc(&b->d_frames, fbytes));
+  HIPCHK(hipMemcpy(b->d_frames, clips->frames, fbytes, hipMemcpyHostToDevice));
+  hm->clips = *clips;
+  hm->clips.frames = b->d_frames;
+  HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
+  HIPCHK(hipMemcpy(b->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice));
+  delete hm;
+  // ---- state ----
+  HIPCHK(hipMalloc(&b->d_states, sizeof(hrg_env_state) * (size_t)n_envs));
+  std::vector<hrg_env_state> init((size_t)n_envs);
+  memset(init.data(), 0, sizeof(hrg_env_state) * (size_t)n_envs);
+  for (auto& s : init) s.episode = -1;
+  HIPCHK(hipMemcpy(b->d_states, init.data(), sizeof(hrg_env_state) * (size_t)n_envs, hipMemcpyHostToDevice));
+  HIPCHK(hipMalloc(&b->d_rcaps, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
+  HIPCHK(hipMalloc(&b->d_hcaps, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
+  HIPCHK(hipMalloc(&b->d_nh, sizeof(int32_t) * (size_t)n_envs));
+  HIPCHK(hipMalloc(&b->d_scratch_obs, sizeof(float) * HRG_OBS_DIM * (size_t)n_envs));
+  HIPCHK(hipMemset(b->d_rcaps, 0, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
+  HIPCHK(hipMemset(b->d_hcaps, 0, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
+  HIPCHK(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
+  *out = b;
+  return HRG_OK;
+}
+
+void hrg_batch_destroy(hrg_batch* b) {
+  if (!b) return;
+  hipSetDevice(b->device);
+  hipDeviceSynchronize();
+  for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs);
+  delete b;
+}
+
+int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
+  if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0);
+  HIPCHK(hipGetLastError());
+  return HRG_OK;
+}
+
+int hrg_batch_step(hrg_batch* b, const double* actions_dev, float* obs_dev, float* term_obs_dev, float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream) {
+  if (!b || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return fail(HRG_ERR_INVALID, "null argument");
+  hipStream_t st = (hipStream_t)stream;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  if (b->timing) {
+    if (!b->pool.empty()) { ev = b->pool.back(); b->pool.pop_back(); }
+    else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
+    HIPCHK(hipEventRecord(ev.first, st));
+  }
+  hipLaunchKernelGGL(hrg_step_kernel, dim3(b->n_envs), dim3(64), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                     b->d_rcaps, b->d_hcaps, b->d_nh, b->env_id0, b->d_scratch_obs);
+  HIPCHK(hipGetLastError());
+  if (b->timing) { HIPCHK(hipEventRecord(ev.second, st)); b->events.push_back(ev); }
+  return HRG_OK;
+}
+
+int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host) {
+  if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipDeviceSynchronize());
+  std::vector<hrg_env_state> st((size_t)b->n_envs);
+  HIPCHK(hipMemcpy(st.data(), b->d_states, sizeof(hrg_env_state) * (size_t)b->n_envs, hipMemcpyDeviceToHost));
+  for (int e = 0; e < b->n_envs; e++) {
+    ncon_host[e] = st[e].ncon;
+    memcpy(pairs_host + (size_t)e * HRG_NCON_MAX * 2, st[e].con_pairs, sizeof(int32_t) * HRG_NCON_MAX * 2);
+  }
+  return HRG_OK;
+}
+
+int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int32_t* n_human_host) {
+  if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(robot_host, b->d_rcaps, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)b->n_envs, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(human_host, b->d_hcaps, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)b->n_envs, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_human_host, b->d_nh, sizeof(int32_t) * (size_t)b->n_envs, hipMemcpyDeviceToHost));
+  return HRG_OK;
+}
+
+int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_env_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(buf_host, b->d_states + env, bytes, hipMemcpyDeviceToHost));
+  return HRG_OK;
+}
+
+int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_env_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_states + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
+int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
+  if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  double tot = 0;
+  int64_t n = 0;
+  for (auto& p : b->events) {
+    HIPCHK(hipEventSynchronize(p.second));
+    float ms = 0;
+    HIPCHK(hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms; n++;
+    b->pool.push_back(p);
+  }
+  b->events.clear();
+  b->timing = true; // first call arms the timer
+  if (avg_ms) *avg_ms = n ? tot / (double)n : 0.0;
+  if (n_launches) *n_launches = n;
+  return HRG_OK;
+}
+
+} // extern "C"

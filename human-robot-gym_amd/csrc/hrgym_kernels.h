@@ -1,0 +1,514 @@
+// hrgym_kernels.h — the per-environment step: phases of one shield cycle and the env epilogue.
+// Reference call sites are cited per phase (paths relative to the reference root, human_robot_gym/...).
+#pragma once
+#include "hrgym_device.h"
+
+// ================================================================================================ robot tree
+// Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
+// 1 = configuration at the end of the fail-safe brake (both feed RobotReach), 2 = simulation state
+// (mj_kinematics of sim.forward(), environments/manipulation/human_env.py:504).
+DI void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
+  if (lane < 3 && (lane == 2 || shield_on)) {
+    const hrg_model_desc& m = dm->m;
+    const int cfg = lane;
+    double R[9], p[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = dm->Rbase[k];
+    v3cpy(p, m.base_pos);
+    for (int i = 0; i < NARM; i++) {
+      double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
+      double Rl[9], Rj[9], t[3];
+      m3mul(Rl, R, dm->Rq[i]);
+      m3mulv(t, R, m.body_pos[i]);
+      v3add(p, p, t);
+      axisangle2mat(Rj, m.jnt_axis[i], q);
+      m3mul(R, Rl, Rj);
+      if (cfg == 2) {
+#pragma unroll
+        for (int k = 0; k < 9; k++) L.kR[i][k] = R[k];
+        v3cpy(L.kp[i], p);
+      } else {
+        m3mulv(t, R, m.scap_p1[i]); v3add(&L.scap[cfg][i][0], p, t);
+        m3mulv(t, R, m.scap_p2[i]); v3add(&L.scap[cfg][i][3], p, t);
+        if (i == NARM - 1) {
+          m3mulv(t, R, m.scap_p1[NARM]); v3add(&L.scap[cfg][NARM][0], p, t);
+          m3mulv(t, R, m.scap_p2[NARM]); v3add(&L.scap[cfg][NARM][3], p, t);
+        }
+      }
+    }
+    if (cfg == 2) {
+      for (int f = 0; f < HRG_NFINGER; f++) {
+        const int i = NARM + f;
+        double Rl[9], t[3], pf[3], axw[3];
+        m3mul(Rl, R, dm->Rq[i]);
+        m3mulv(t, R, m.body_pos[i]);
+        v3add(pf, p, t);
+        m3mulv(axw, Rl, m.jnt_axis[i]);
+        v3madd(pf, pf, axw, L.st.qpos[i]);
+#pragma unroll
+        for (int k = 0; k < 9; k++) L.kR[i][k] = Rl[k];
+        v3cpy(L.kp[i], pf);
+      }
+    }
+  }
+  wave_sync();
+}
+
+// mj_comPos / mj_crb / mj_rne(flg_acc=0) for the robot tree: joint subspaces, world inertias, composite
+// inertia -> dense 8x8 M (lanes = matrix entries), bias forces (serial recursion wave-uniform, per-body
+// force terms on lanes = bodies).  SURVEY.md Appendix B.1 position+velocity stages.
+DI void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
+  const hrg_model_desc& m = dm->m;
+  if (lane < NV) {
+    const int i = lane;
+    const double* R = L.kR[i];
+    double axw[3], t[3];
+    m3mulv(axw, R, m.jnt_axis[i]);
+    if (i < NARM) { v3cpy(L.Sw[i], axw); v3cross(L.Sv[i], L.kp[i], axw); }
+    else { v3set(L.Sw[i], 0, 0, 0); v3cpy(L.Sv[i], axw); }
+    m3mulv(t, R, m.body_com[i]);
+    double c[3];
+    v3add(c, L.kp[i], t);
+    v3cpy(L.com[i], c);
+    const double* I = m.body_inertia[i];
+    double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Rt[9], W[9];
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b = 0; b < 3; b++) Rt[3 * a + b] = R[3 * b + a];
+    m3mul(T, R, Ib);
+    m3mul(W, T, Rt);
+    double Iw[6] = {W[0], W[4], W[8], W[1], W[2], W[5]};
+#pragma unroll
+    for (int a = 0; a < 6; a++) L.Iw[i][a] = Iw[a];
+    sinertia_body(L.cI[i], m.body_mass[i], c, Iw);
+  }
+  wave_sync();
+  // ---- velocity recursion + composite inertia (wave-uniform serial passes) ----
+  for (int i = NV - 1; i >= 1; i--) {
+    int par = m.body_parent[i];
+    for (int a = 0; a < 10; a++) L.cI[par][a] += L.cI[i][a];
+  }
+  for (int i = 0; i < NV; i++) {
+    int par = m.body_parent[i];
+    double pw[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, paw[3] = {0, 0, 0}, pav[3];
+    v3scl(pav, m.gravity, -1.0);
+    if (par >= 0) { v3cpy(pw, L.vw[par]); v3cpy(pv, L.vv[par]); v3cpy(paw, L.aw[par]); v3cpy(pav, L.av[par]); }
+    double jw[3], jv[3], vw[3], vv[3], t1[3], t2[3], t3[3], aw[3], av[3];
+    const double qd = L.st.qvel[i];
+    v3scl(jw, L.Sw[i], qd);
+    v3scl(jv, L.Sv[i], qd);
+    v3add(vw, pw, jw);
+    v3add(vv, pv, jv);
+    v3cross(t1, vw, jw);
+    v3cross(t2, vw, jv);
+    v3cross(t3, vv, jw);
+    v3add(aw, paw, t1);
+    v3add(av, pav, t2);
+    v3add(av, av, t3);
+    v3cpy(L.vw[i], vw); v3cpy(L.vv[i], vv); v3cpy(L.aw[i], aw); v3cpy(L.av[i], av);
+  }
+  // ---- per-body terms on lanes = bodies ----
+  if (lane < NV) {
+    const int i = lane;
+    double n[3], f[3];
+    sinertia_mul(n, f, L.cI[i], L.Sw[i], L.Sv[i]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
+    double s[10], n1[3], f1[3], n2[3], f2[3], t1[3], t2[3], t3[3];
+    sinertia_body(s, m.body_mass[i], L.com[i], L.Iw[i]);
+    sinertia_mul(n1, f1, s, L.aw[i], L.av[i]);
+    sinertia_mul(n2, f2, s, L.vw[i], L.vv[i]);
+    v3cross(t1, L.vw[i], n2);
+    v3cross(t2, L.vv[i], f2);
+    v3cross(t3, L.vw[i], f2);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { L.fn[i][a] = n1[a] + t1[a] + t2[a]; L.ff[i][a] = f1[a] + t3[a]; }
+  }
+  wave_sync();
+  { // mass matrix: lane (i,j)
+    const int i = lane >> 3, j = lane & 7;
+    double v = 0;
+    if ((dm->anc_mask[j] >> i) & 1) v = v3dot(L.Sw[i], &L.F[j][0]) + v3dot(L.Sv[i], &L.F[j][3]);
+    else if ((dm->anc_mask[i] >> j) & 1) v = v3dot(L.Sw[j], &L.F[i][0]) + v3dot(L.Sv[j], &L.F[i][3]);
+    if (i == j) v += m.jnt_armature[i];
+    L.M[lane] = v;
+  }
+  // bias: backward accumulation (wave-uniform)
+  for (int i = NV - 1; i >= 0; i--) {
+    L.bias[i] = v3dot(L.Sw[i], L.fn[i]) + v3dot(L.Sv[i], L.ff[i]);
+    int par = m.body_parent[i];
+    if (par >= 0) for (int a = 0; a < 3; a++) { L.fn[par][a] += L.fn[i][a]; L.ff[par][a] += L.ff[i][a]; }
+  }
+  wave_sync();
+}
+
+DI void robot_point_vel(const Lds& L, int b, const double* r, double* v) {
+  if (b < 0) { v3set(v, 0, 0, 0); return; }
+  double t[3];
+  v3cross(t, L.vw[b], r);
+  v3add(v, L.vv[b], t);
+}
+
+// ================================================================================================ human
+// HumanEnv._control_human (human_env.py:1710-1767) + kinematics of the 24-body tree on lanes = bodies.
+DI int clip_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int anim_index) {
+  double u = rng_u01(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_ANIM, (uint64_t)anim_index);
+  int c = (int)(u * dm->m.n_clips);
+  return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
+}
+
+DI void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+  const hrg_model_desc& m = dm->m;
+  const int b = lane < HRG_NHB ? lane : 0;
+  double R[9], p[3], Rloc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, anchor[3];
+  v3cpy(anchor, m.hb_anchor[b]);
+  quat2mat(R, mocap_quat);
+  v3cpy(p, mocap_pos);
+  if (lane >= 1 && lane < HRG_NHB) {
+    double qz = 0, qy = 0, qx = 0;
+    if (qh) { qz = qh[3 * (b - 1)]; qy = qh[3 * (b - 1) + 1]; qx = qh[3 * (b - 1) + 2]; }
+    const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+    double Rz[9], Ry[9], Rx[9];
+    axisangle2mat(Rz, ez, qz);
+    axisangle2mat(Ry, ey, qy);
+    axisangle2mat(Rx, ex, qx);
+    // R_b = ((R_par Rz) Ry) Rx ; keep the oracle's association by deferring the parent factor
+    m3mul(Rloc, Rz, Ry);
+    m3mul(Rloc, Rloc, Rx);
+  }
+  const int par = lane >= 1 && lane < HRG_NHB ? m.hb_parent[b] : 0;
+  const int depth = lane < HRG_NHB ? m.hb_depth[b] : -1;
+  for (int level = 1; level <= dm->hb_maxdepth; level++) {
+    double Rp[9], pp[3];
+#pragma unroll
+    for (int k = 0; k < 9; k++) Rp[k] = __shfl(R[k], par, 64);
+#pragma unroll
+    for (int k = 0; k < 3; k++) pp[k] = __shfl(p[k], par, 64);
+    if (depth == level) {
+      double t[3], anc[3];
+      m3mul(R, Rp, Rloc);
+      m3mulv(t, Rp, anchor);
+      v3add(anc, pp, t);
+      m3mulv(t, R, anchor);
+      v3sub(p, anc, t);
+    }
+  }
+  if (lane < HRG_NHB) {
+    double t[3];
+    m3mulv(t, R, m.hcap_p1[b]); v3add(&L.hcap[b][0], p, t);
+    m3mulv(t, R, m.hcap_p2[b]); v3add(&L.hcap[b][3], p, t);
+  }
+  // sites of the measured joints: site k sits at the anchor of body meas_body[k]
+  {
+    const int k = lane < HRG_NHJ ? lane : 0;
+    const int sb = m.meas_body[k];
+    double Rs[9], ps[3];
+#pragma unroll
+    for (int a = 0; a < 9; a++) Rs[a] = __shfl(R[a], sb, 64);
+#pragma unroll
+    for (int a = 0; a < 3; a++) ps[a] = __shfl(p[a], sb, 64);
+    if (lane < HRG_NHJ) {
+      double t[3];
+      m3mulv(t, Rs, m.hb_anchor[sb]);
+      v3add(L.st.human_site[k], ps, t);
+    }
+  }
+  wave_sync();
+}
+
+DI void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  // human_env.py:1719-1731 (wave-uniform)
+  int control_time = (int)floor((double)s.low_level_time / m.anim_step_length);
+  int at = control_time - s.anim_start_time;
+  int anim_index = s.anim_index, anim_start = s.anim_start_time;
+  int clip = clip_of(dm, gid, s.episode, anim_index);
+  if (at > dm->clips.clip_len[clip] - 1) {
+    anim_index = (anim_index + 1) % m.n_anim_ids; // human_env.py:1704-1708
+    at = 0;
+    anim_start = control_time;
+    clip = clip_of(dm, gid, s.episode, anim_index);
+  }
+  s.anim_index = anim_index; s.anim_start_time = anim_start; s.animation_time = at;
+  const double* fr = dm->clips.frames + (dm->clips.clip_offset[clip] + at) * HRG_FRAME_DIM;
+  // human_env.py:1736-1763
+  double qi[4] = {dm->clips.clip_quat[clip][3], dm->clips.clip_quat[clip][0], dm->clips.clip_quat[clip][1], dm->clips.clip_quat[clip][2]};
+  double qbi[4], Rbi[9], pa[3], pr[3], mp[3], mq[4], q1[4];
+  quatmul(qbi, m.human_base_quat, qi);
+  quat2mat(Rbi, qbi);
+  for (int a = 0; a < 3; a++) pa[a] = fr[a] + dm->clips.clip_pos_offset[clip][a];
+  m3mulv(pr, Rbi, pa);
+  v3add(mp, pr, s.human_pos_offset);
+  double qa[4] = {fr[6], fr[3], fr[4], fr[5]};
+  quatmul(q1, s.human_rot_offset, qbi);
+  quatmul(mq, q1, qa);
+  human_fk_lanes(dm, L, lane, mp, mq, fr + 7);
+}
+
+// ================================================================================================ shield
+// SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
+// restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
+// human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
+DI void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  const double dt = m.timestep, t = s.time;
+  const bool shield_on = m.shield_type != HRG_SHIELD_OFF;
+  const bool have_vel = s.n_meas >= 1 && t > s.meas_prev_t;
+  if (lane < NARM) {
+    double qq, q1, q2;
+    ltt_eval(&s.ltt, lane, s.path_s, &qq, &q1, &q2);
+    L.cq[lane] = qq; L.cv[lane] = q1 * s.path_v; L.ca[lane] = q1 * s.path_a + q2 * s.path_v * s.path_v;
+  }
+  wave_sync();
+  int use_cand = 0;
+  if (s.new_goal) {
+    const bool bad = lane < NARM && fabs(L.ca[lane]) > m.a_max_ltt[lane];
+    if (!__any(bad)) {
+      use_cand = 1;
+      double tj = 0;
+      if (lane < NARM) {
+        ltt_plan_joint(&L.u.cand, lane, L.cq[lane], L.cv[lane], L.ca[lane], s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
+        for (int i = 0; i < HRG_LTT_NSEG; i++) tj += L.u.cand.dur[lane][i];
+      }
+      L.u.cand.T = wave_max(tj);
+    }
+    wave_sync();
+  }
+  const hrg_ltt* Lp = use_cand ? &L.u.cand : &s.ltt;
+  const double ps = use_cand ? 0.0 : s.path_s, pv = use_cand ? 1.0 : s.path_v, pa = use_cand ? 0.0 : s.path_a;
+  hrg_path rec, fs2;
+  double s1, v1, a1, se, ve_, ae;
+  path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
+  path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
+  path_plan(&fs2, s1, v1, a1, 0.0, m.path_amax, m.path_jmax);
+  const double Tb = path_total(&fs2);
+  path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+  if (shield_on && lane < NARM) {
+    double d1, d2, qv;
+    ltt_eval(Lp, lane, se, &qv, &d1, &d2);
+    L.qe[lane] = qv;
+  }
+  wave_sync();
+  robot_chain_fk(dm, L, lane, shield_on);
+  int safe = 1;
+  if (shield_on) {
+    const double sdiff = se - ps;
+    if (lane < HRG_NSHIELD_RCAP) {
+      const int c = lane;
+      double d[3], l1, l2;
+      v3sub(d, &L.scap[0][c][0], &L.scap[1][c][0]); l1 = v3norm(d);
+      v3sub(d, &L.scap[0][c][3], &L.scap[1][c][3]); l2 = v3norm(d);
+      for (int a = 0; a < 6; a++) L.rc[c][a] = 0.5 * (L.scap[0][c][a] + L.scap[1][c][a]);
+      L.rc[c][6] = m.scap_r[c] + m.secure_radius + 0.5 * (l1 > l2 ? l1 : l2) + m.scap_alpha[c] * sdiff * sdiff / 8.0;
+      if (dbg_r) for (int a = 0; a < 7; a++) dbg_r[((size_t)e * HRG_NSHIELD_RCAP + c) * 7 + a] = L.rc[c][a];
+    }
+    wave_sync();
+    // lanes = human reach capsules
+    const int nh = dm->hc_n;
+    bool hit = false;
+    int mdl = 0;
+    if (lane < nh) {
+      const int kind = dm->hc_kind[lane], j1 = dm->hc_j1[lane], j2 = dm->hc_j2[lane];
+      const double Td = dt + Tb + m.delay;
+      double c1[3], c2[3], r;
+      if (kind == 0) {
+        double va[3], vb[3];
+        for (int a = 0; a < 3; a++) {
+          va[a] = have_vel ? (s.human_site[j1][a] - s.meas_prev[j1][a]) / (t - s.meas_prev_t) : 0.0;
+          vb[a] = have_vel ? (s.human_site[j2][a] - s.meas_prev[j2][a]) / (t - s.meas_prev_t) : 0.0;
+        }
+        const double base = 0.5 * dm->hc_a[lane] * Td * Td + m.meas_err_pos + m.meas_err_vel * Td;
+        const double r1 = v3norm(va) * Td * 0.5 + base, r2 = v3norm(vb) * Td * 0.5 + base;
+        v3madd(c1, s.human_site[j1], va, 0.5 * Td);
+        v3madd(c2, s.human_site[j2], vb, 0.5 * Td);
+        r = (r1 > r2 ? r1 : r2) + dm->hc_th[lane];
+        mdl = 0;
+      } else if (kind == 2) {
+        v3cpy(c1, s.human_site[j1]);
+        v3cpy(c2, s.human_site[j1]);
+        r = dm->hc_len[lane] + dm->hc_th[lane] + m.meas_err_pos + dm->hc_v[lane] * Td;
+        mdl = 2;
+      } else {
+        v3cpy(c1, s.human_site[j1]);
+        v3cpy(c2, s.human_site[j2]);
+        r = dm->hc_th[lane] + m.meas_err_pos + dm->hc_v[lane] * Td;
+        mdl = kind == 1 ? 1 : 2;
+      }
+      for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+        double x1[3], x2[3];
+        const double rr = L.rc[c][6] + r;
+        if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true;
+      }
+      if (dbg_h) {
+        double* o = dbg_h + ((size_t)e * HRG_NHCAP_MAX + lane) * 7;
+        o[0] = c1[0]; o[1] = c1[1]; o[2] = c1[2]; o[3] = c2[0]; o[4] = c2[1]; o[5] = c2[2]; o[6] = r;
+      }
+    }
+    if (dbg_nh && lane == 0) dbg_nh[e] = nh;
+    const bool hitA = __any(hit && mdl == 0) || !have_vel;
+    const bool hitV = __any(hit && mdl == 1);
+    const bool hitP = __any(hit && mdl == 2);
+    safe = !(hitA && hitV && hitP);
+  }
+  wave_sync();
+  // humanMeasurement bookkeeping: previous measurement <- current sites
+  for (int k = lane; k < HRG_NHJ * 3; k += 64) (&s.meas_prev[0][0])[k] = (&s.human_site[0][0])[k];
+  s.meas_prev_t = t;
+  if (s.n_meas < 2) s.n_meas = s.n_meas + 1;
+  if (safe) {
+    if (use_cand) {
+      double* dst = (double*)&s.ltt;
+      const double* src = (const double*)&L.u.cand;
+      for (int k = lane; k < (int)(sizeof(hrg_ltt) / sizeof(double)); k += 64) dst[k] = src[k];
+      s.new_goal = 0;
+    }
+    s.path_s = s1; s.path_v = v1; s.path_a = a1;
+    s.safe_path = fs2;
+  } else {
+    const double k = s.safe_path.k + 1.0;
+    s.safe_path.k = k;
+    double ns, nv, na;
+    path_eval(&s.safe_path, k * dt, 0.0, &ns, &nv, &na);
+    s.path_s = ns; s.path_v = nv; s.path_a = na;
+  }
+  s.is_safe = safe;
+  wave_sync();
+  if (lane < NARM) {
+    double qq, q1, q2;
+    ltt_eval(&s.ltt, lane, s.path_s, &qq, &q1, &q2);
+    s.des_q[lane] = qq; s.des_v[lane] = q1 * s.path_v; s.des_a[lane] = q1 * s.path_a + q2 * s.path_v * s.path_v;
+  }
+  wave_sync();
+}
+
+DI void shield_reset(const DevModel* __restrict__ dm, Lds& L, int lane) {
+  hrg_env_state& s = L.st;
+  // ltt_const + zero paths: the state block was zeroed by the caller
+  if (lane < NARM) {
+    const double q = s.qpos[lane];
+    s.ltt.q0[lane] = q; s.ltt.qT[lane] = q;
+    s.des_q[lane] = q; s.new_goal_q[lane] = q; s.goal_qpos[lane] = q;
+  }
+  s.is_safe = 1;
+}
+
+// ================================================================================================ contacts
+// Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
+DI void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
+  const hrg_model_desc& m = dm->m;
+  if (lane < HRG_NRCAP) {
+    const int c = lane, b = m.rcap_body[c];
+    const double* R = b < 0 ? dm->Rbase : L.kR[b];
+    const double* p = b < 0 ? m.base_pos : L.kp[b];
+    double t[3], mid[3];
+    m3mulv(t, R, m.rcap_p1[c]); v3add(&L.rcapw[c][0], p, t);
+    m3mulv(t, R, m.rcap_p2[c]); v3add(&L.rcapw[c][3], p, t);
+    for (int a = 0; a < 3; a++) mid[a] = 0.5 * (m.rcap_p1[c][a] + m.rcap_p2[c][a]);
+    m3mulv(t, R, mid);
+    v3add(L.rcen[c], p, t);
+  }
+  wave_sync();
+  int base = 0;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  // rounds: 0 = robot-robot, 1..4 = robot-human (240 pairs), 5 = planes
+  for (int round = 0; round < 6; round++) {
+    bool hit = false;
+    Contact c;
+    c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
+    if (round <= 4) {
+      int i = 0, g2 = 0;
+      double r2 = 0, margin = 0;
+      const double *a1, *a2;
+      bool valid;
+      if (round == 0) {
+        valid = lane < dm->n_self;
+        i = valid ? dm->self_i[lane] : 0;
+        const int j = valid ? dm->self_j[lane] : 1;
+        g2 = j; a1 = &L.rcapw[j][0]; a2 = &L.rcapw[j][3]; r2 = m.rcap_r[j];
+        c.b2 = m.rcap_body[j];
+      } else {
+        const int pidx = (round - 1) * 64 + lane;
+        valid = pidx < HRG_NRCAP * HRG_NHB;
+        i = valid ? pidx / HRG_NHB : 0;
+        const int hb = valid ? pidx % HRG_NHB : 0;
+        g2 = GEOM_HUMAN0 + hb; a1 = &L.hcap[hb][0]; a2 = &L.hcap[hb][3]; r2 = m.hcap_r[hb];
+        margin = m.contact_margin_human;
+        c.b2 = -2;
+      }
+      if (valid) {
+        double c1[3], c2[3], d[3];
+        const double d2 = seg_seg(&L.rcapw[i][0], &L.rcapw[i][3], a1, a2, c1, c2), dd = sqrt(d2), dist = dd - m.rcap_r[i] - r2;
+        if (dist < margin) {
+          hit = true;
+          v3sub(d, c2, c1);
+          if (dd > 1e-12) v3scl(c.n, d, 1.0 / dd);
+          v3madd(c.pos, c1, c.n, m.rcap_r[i] + 0.5 * dist);
+          c.g1 = i; c.g2 = g2; c.b1 = m.rcap_body[i]; c.dist = dist;
+        }
+      }
+    } else if (lane < 4 * HRG_NRCAP) {
+      const int pl = lane / (2 * HRG_NRCAP), i = (lane % (2 * HRG_NRCAP)) >> 1, en = lane & 1;
+      if (m.rcap_body[i] >= 0) {
+        const double* p = &L.rcapw[i][3 * en];
+        const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - m.rcap_r[i] - z0;
+        bool ok = true;
+        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] + m.rcap_r[i] > z0 - 0.05;
+        if (ok && dist < 0) {
+          hit = true;
+          v3set(c.n, 0, 0, -1);
+          v3set(c.pos, p[0], p[1], z0 + 0.5 * dist);
+          c.g1 = i; c.g2 = pl ? GEOM_FLOOR : GEOM_TABLE; c.b1 = m.rcap_body[i]; c.b2 = -1; c.dist = dist;
+        }
+      }
+    }
+    const uint64_t mask = __ballot(hit);
+    if (hit) {
+      const int idx = base + __popcll(mask & lt);
+      if (idx < HRG_NCON_MAX) L.con[idx] = c;
+    }
+    base += __popcll(mask);
+  }
+  *ncon_out = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
+  wave_sync();
+}
+
+DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : HRG_GEOM_STATIC); }
+DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
+
+// HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
+DI void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
+  const hrg_model_desc& m = dm->m;
+  hrg_env_state& s = L.st;
+  int cur[HRG_NPREV_MAX], ncur = 0;
+  const double tm = s.debounce_timer - m.timestep;
+  double deb = tm > 0 ? tm : 0;
+  const int n_prev = s.n_prev;
+  for (int c = 0; c < ncon; c++) {
+    const int g1 = L.con[c].g1, g2 = L.con[c].g2;
+    const int t1 = geom_class(g1), t2 = geom_class(g2);
+    if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
+    const int h12 = cantor(g1, g2), h21 = cantor(g2, g1);
+    if (ncur + 2 <= HRG_NPREV_MAX) { cur[ncur++] = h12; cur[ncur++] = h21; }
+    int seen = 0;
+    for (int i = 0; i < n_prev; i++) if (s.prev_pairs[i] == h12) seen = 1;
+    if (seen) continue;
+    const int rg = t1 == HRG_GEOM_ROBOT ? g1 : g2;
+    const int ot = t1 == HRG_GEOM_ROBOT ? t2 : t1;
+    *has_collision = 1;
+    if (ot == HRG_GEOM_ROBOT) { *collision_type |= HRG_COL_ROBOT; s.n_collisions_robot = s.n_collisions_robot + 1; }
+    else if (ot == HRG_GEOM_HUMAN) {
+      if (deb > 0) continue;
+      deb = m.collision_debounce_delay;
+      double v[3];
+      robot_point_vel(L, m.rcap_body[rg], L.rcen[rg], v);
+      if (v3norm(v) <= m.safe_vel) { *collision_type |= HRG_COL_HUMAN; s.n_collisions_human = s.n_collisions_human + 1; }
+      else { *collision_type |= HRG_COL_HUMAN_CRIT; s.n_collisions_critical = s.n_collisions_critical + 1; }
+    } else { *collision_type |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + 1; }
+  }
+  s.debounce_timer = deb;
+  s.n_prev = ncur;
+  for (int i = 0; i < HRG_NPREV_MAX; i++) if (i < ncur) s.prev_pairs[i] = cur[i];
+}

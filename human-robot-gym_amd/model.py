@@ -1,0 +1,382 @@
+"""Host-side model builder: env kwargs (+ the compiled asset tables) -> hrg_model_desc.
+
+Mirrors what `robosuite.make("ReachHuman", **env_kwargs)` + `FailsafeController.__init__` assemble in the
+reference (human_env.py:269-451, reach_human_env.py:226-377, failsafe_controller.py:113-191,
+training_utils.py:48-88), but produces one plain-C parameter block for the HIP stepper.
+
+Everything that the reference takes from packages absent from its checkout is a documented SYNTHETIC default
+here: the RethinkGripper/RethinkMount geometry [robosuite 1.3.2], MuJoCo solver
+defaults, and the three sara-shield YAML files (robot/trajectory/mocap parameters).
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+from ._cstruct import CONST, ModelDesc
+
+_ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
+
+# models/robots/config/schunk.json (qpos_limits) — the only key of that file the controller reads
+SCHUNK_QPOS_LIMITS = [[-2.9, -1.8, -2.60, -2.9, -1.85, -2.9], [2.9, 1.8, 2.60, 2.9, 1.85, 2.9]]
+# controllers/failsafe_controller/config/failsafe.json
+FAILSAFE_CONFIG = dict(input_max=1, input_min=-1, output_max=0.2, output_min=-0.2, kp=100, damping_ratio=1)
+
+# models/objects/human/human.py:57-81 — order of the 23 measured joints handed to the shield
+HUMAN_JOINT_ELEMENTS = [
+    "L_Hip", "R_Hip", "Torso", "L_Knee", "R_Knee", "Spine", "L_Ankle", "R_Ankle", "Chest", "L_Toe", "R_Toe",
+    "Neck", "L_Thorax", "R_Thorax", "Head", "L_Shoulder", "R_Shoulder", "L_Elbow", "R_Elbow", "L_Wrist",
+    "R_Wrist", "L_Hand", "R_Hand",
+]
+
+# default kwargs = HumanEnv/ReachHuman constructor defaults overlaid with config/environment/reach_human.yaml
+DEFAULT_ENV_KWARGS = dict(
+    robots="Schunk",
+    robot_base_offset=[0.0, 0.0, 0.0],
+    reward_scale=1.0,
+    reward_shaping=False,
+    collision_reward=0,
+    task_reward=1,
+    done_at_collision=False,
+    done_at_success=True,
+    control_freq=10,
+    horizon=100,
+    shield_type="SSM",
+    control_sample_time=0.004,
+    base_human_pos_offset=[0.0, 0.0, 0.0],
+    human_animation_freq=120,
+    human_rand=[0.0, 0.0, 0.0],
+    n_animations_sampled_per_100_steps=5,
+    n_goals_sampled_per_100_steps=20,
+    goal_dist=0.1,
+    safe_vel=0.01,
+    collision_debounce_delay=0.01,
+    seed=0,
+)
+
+# Synthetic shield parameters (stand-ins for sara-shield's trajectory_parameters_schunk.yaml,
+# robot_parameters_schunk.yaml, mujoco_mocap.yaml, which are absent from the reference checkout).
+SHIELD_DEFAULTS = dict(
+    v_max_allowed=1.0, a_max_allowed=10.0, j_max_allowed=400.0,
+    v_max_ltt=1.0, a_max_ltt=2.0, j_max_ltt=15.0,
+    secure_radius=0.02,
+    meas_err_pos=0.0, meas_err_vel=0.0, delay=0.0,
+)
+# body parts: (proximal joint, distal joint, thickness [m], v_max [m/s], a_max [m/s^2], kept in POS model)
+BODY_PARTS = [
+    ("L_Hip", "L_Knee", 0.13, 1.6, 20.0, 0), ("R_Hip", "R_Knee", 0.13, 1.6, 20.0, 0),
+    ("L_Knee", "L_Ankle", 0.10, 1.6, 20.0, 0), ("R_Knee", "R_Ankle", 0.10, 1.6, 20.0, 0),
+    ("L_Ankle", "L_Toe", 0.08, 1.6, 20.0, 0), ("R_Ankle", "R_Toe", 0.08, 1.6, 20.0, 0),
+    ("L_Hip", "R_Hip", 0.18, 1.6, 20.0, 1), ("Torso", "Chest", 0.20, 1.6, 20.0, 1),
+    ("Chest", "Neck", 0.18, 1.6, 20.0, 1), ("Neck", "Head", 0.15, 1.6, 20.0, 1),
+    ("L_Thorax", "L_Shoulder", 0.10, 1.6, 20.0, 1), ("R_Thorax", "R_Shoulder", 0.10, 1.6, 20.0, 1),
+    ("L_Shoulder", "L_Elbow", 0.10, 2.0, 50.0, 0), ("R_Shoulder", "R_Elbow", 0.10, 2.0, 50.0, 0),
+    ("L_Elbow", "L_Wrist", 0.08, 2.0, 50.0, 0), ("R_Elbow", "R_Wrist", 0.08, 2.0, 50.0, 0),
+    ("L_Wrist", "L_Hand", 0.10, 2.0, 50.0, 0), ("R_Wrist", "R_Hand", 0.10, 2.0, 50.0, 0),
+]
+# extremities of the POS model: (proximal joint, chain of joints to the tip, thickness, v_max of the proximal joint)
+EXTREMITIES = [
+    ("L_Shoulder", ["L_Elbow", "L_Wrist", "L_Hand"], 0.10, 1.6),
+    ("R_Shoulder", ["R_Elbow", "R_Wrist", "R_Hand"], 0.10, 1.6),
+    ("L_Hip", ["L_Knee", "L_Ankle", "L_Toe"], 0.13, 1.6),
+    ("R_Hip", ["R_Knee", "R_Ankle", "R_Toe"], 0.13, 1.6),
+]
+
+# Synthetic RethinkGripper / mount stand-in (robosuite 1.3.2 MJCF is not in the reference tree)
+GRIPPER = dict(
+    base_z=0.912,                      # height of the robot root on the RethinkMount pedestal
+    hand_mass=0.3, hand_inertia=[3e-4, 3e-4, 3e-4],
+    finger_mass=0.03, finger_inertia=[0.02, 0.02, 0.02],
+    finger_pos=[[0.0, 0.01, 0.0444], [0.0, -0.01, 0.0444]],
+    finger_axis=[0.0, 1.0, 0.0],
+    finger_range=[[-0.0115, 0.020833], [-0.020833, 0.0115]],
+    finger_damping=100.0, finger_armature=1.0, finger_frictionloss=1.0,
+    finger_kp=1000.0, finger_forcerange=[-20.0, 20.0],
+    finger_init_qpos=[0.0118366, -0.011499],   # RethinkValidGripper.qpos_range[1], rethink_valid_gripper.py:37-42
+    speed=0.01,
+    grip_site=[0.0, 0.0, 0.109],
+    base_capsule=([0.0, 0.0, 0.0], [0.0, 0.0, 0.06], 0.045),
+    finger_capsule=([0.0, 0.0, 0.0], [0.0, 0.0075, 0.075], 0.012),
+    shield_capsule=([0.0, 0.0, 0.0], [0.0, 0.0, 0.11], 0.07),
+)
+
+
+def _quat2mat(q):
+    w, x, y, z = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _merge_inertia(parts):
+    """Merge rigid parts [(mass, com(3), I_com(3x3))] expressed in one frame -> (mass, com, I about com)."""
+    m = sum(p[0] for p in parts)
+    c = sum(p[0] * np.asarray(p[1]) for p in parts) / m
+    I = np.zeros((3, 3))
+    for mass, com, Ic in parts:
+        d = np.asarray(com) - c
+        I += np.asarray(Ic) + mass * (d @ d * np.eye(3) - np.outer(d, d))
+    return m, c, I
+
+
+def _seg_seg_dist(p1, q1, p2, q2):
+    d1, d2, r = q1 - p1, q2 - p2, p1 - p2
+    a, e, f = d1 @ d1, d2 @ d2, d2 @ r
+    if a <= 1e-12 and e <= 1e-12:
+        s = t = 0.0
+    elif a <= 1e-12:
+        s, t = 0.0, min(1.0, max(0.0, f / e))
+    else:
+        c = d1 @ r
+        if e <= 1e-12:
+            t, s = 0.0, min(1.0, max(0.0, -c / a))
+        else:
+            b = d1 @ d2
+            den = a * e - b * b
+            s = min(1.0, max(0.0, (b * f - c * e) / den)) if den > 1e-12 * a * e else 0.0
+            t = (b * s + f) / e
+            if t < 0:
+                t, s = 0.0, min(1.0, max(0.0, -c / a))
+            elif t > 1:
+                t, s = 1.0, min(1.0, max(0.0, (b - c) / a))
+    return float(np.linalg.norm((p1 + s * d1) - (p2 + t * d2)))
+
+
+def load_assets(name="reach_human_schunk.json"):
+    with open(os.path.join(_ASSETS, name)) as f:
+        return json.load(f)
+
+
+def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None):
+    """Return a filled `ModelDesc` for ReachHuman/Schunk.
+
+    `env_kwargs` takes the same keys as the reference's environment config
+    (training/config/environment/reach_human.yaml, default/human_env.yaml)."""
+    kw = dict(DEFAULT_ENV_KWARGS)
+    kw.update(env_kwargs or {})
+    sp = dict(SHIELD_DEFAULTS)
+    sp.update(shield_params or {})
+    A = assets or load_assets()
+    robots = kw["robots"]
+    if isinstance(robots, (list, tuple)):
+        robots = robots[0]
+    if robots != "Schunk":
+        raise NotImplementedError(f"robot {robots!r}: only the Schunk LWA-4P tables are compiled")
+    NV, NARM = CONST["HRG_NV"], CONST["HRG_NARM"]
+    d = ModelDesc()
+    chain = A["robot"]["chain"]  # link0, link1..link6, right_hand
+    off = np.asarray(kw["robot_base_offset"], float)
+    d.base_pos[:] = (off + np.array([0.0, 0.0, GRIPPER["base_z"]])).tolist()
+    d.base_quat[:] = [1.0, 0.0, 0.0, 0.0]
+    links = chain[1:7]
+    hand = chain[7]
+    R_hand = _quat2mat(np.asarray(hand["quat"]) / np.linalg.norm(hand["quat"]))
+    p_hand = np.asarray(hand["pos"])
+    for i, L in enumerate(links):
+        d.body_pos[i][:] = L["pos"]
+        q = np.asarray(L["quat"], float)
+        d.body_quat[i][:] = (q / np.linalg.norm(q)).tolist()
+        d.body_parent[i] = i - 1
+        d.jnt_type[i] = 0
+        d.jnt_axis[i][:] = L["axis"]
+        d.jnt_range[i][:] = L["range"]
+        d.jnt_damping[i] = L["damping"]           # schunk_robot.py:42-45 re-sets the same 1e-4
+        d.jnt_frictionloss[i] = L["frictionloss"]
+        d.jnt_armature[i] = L["armature"]
+        parts = [(L["mass"], L["ipos"], np.diag(L["diaginertia"]))]
+        if i == NARM - 1:  # right_hand body + gripper base are welded to link6
+            parts.append((hand["mass"], p_hand, np.diag(hand["diaginertia"])))
+            parts.append((GRIPPER["hand_mass"], p_hand + R_hand @ np.array([0, 0, 0.03]), np.diag(GRIPPER["hand_inertia"])))
+        m, c, I = _merge_inertia(parts)
+        d.body_mass[i] = m
+        d.body_com[i][:] = c.tolist()
+        d.body_inertia[i][:] = [I[0, 0], I[1, 1], I[2, 2], I[0, 1], I[0, 2], I[1, 2]]
+    # quaternion of the hand frame for the finger bodies
+    qh = np.asarray(hand["quat"], float)
+    qh = qh / np.linalg.norm(qh)
+    for f in range(2):
+        i = NARM + f
+        d.body_pos[i][:] = (p_hand + R_hand @ np.asarray(GRIPPER["finger_pos"][f])).tolist()
+        d.body_quat[i][:] = qh.tolist()
+        d.body_parent[i] = NARM - 1
+        d.jnt_type[i] = 1
+        d.jnt_axis[i][:] = GRIPPER["finger_axis"]
+        d.jnt_range[i][:] = GRIPPER["finger_range"][f]
+        d.jnt_damping[i] = GRIPPER["finger_damping"]
+        d.jnt_frictionloss[i] = GRIPPER["finger_frictionloss"]
+        d.jnt_armature[i] = GRIPPER["finger_armature"]
+        d.body_mass[i] = GRIPPER["finger_mass"]
+        d.body_com[i][:] = [0.0, 0.0, 0.03]
+        d.body_inertia[i][:] = GRIPPER["finger_inertia"] + [0.0, 0.0, 0.0]
+        d.finger_ctrlrange[f][:] = GRIPPER["finger_range"][f]
+        d.finger_init_qpos[f] = GRIPPER["finger_init_qpos"][f]
+    d.gravity[:] = [0.0, 0.0, -9.81]
+    d.eef_pos[:] = (p_hand + R_hand @ np.asarray(GRIPPER["grip_site"])).tolist()
+    for i in range(NARM):
+        d.arm_ctrlrange[i][:] = A["robot"]["ctrlrange"][i]
+    d.finger_kp = GRIPPER["finger_kp"]
+    d.finger_forcerange[:] = GRIPPER["finger_forcerange"]
+    d.gripper_speed = GRIPPER["speed"]
+    # solver: MuJoCo 2.1 defaults (solref 0.02 1, solimp .9 .95 .001 .5 2, Newton 100 iters tol 1e-8)
+    d.timestep = float(kw["control_sample_time"])
+    d.solref[:] = [0.02, 1.0]
+    d.solimp[:] = [0.9, 0.95, 0.001, 0.5, 2.0]
+    d.contact_margin_human = A["human"]["margin"]
+    d.friction_static = 1.0
+    d.solver_iters = 30
+    d.solver_tol = 1e-10
+    # ---- collision capsules
+    caps = [(-1, chain[0]["capsules"][0])]
+    for i, L in enumerate(links):
+        caps.append((i, L["capsules"][0]))
+    bc = GRIPPER["base_capsule"]
+    caps.append((NARM - 1, dict(p1=(p_hand + R_hand @ np.asarray(bc[0])).tolist(), p2=(p_hand + R_hand @ np.asarray(bc[1])).tolist(), r=bc[2])))
+    fc = GRIPPER["finger_capsule"]
+    caps.append((NARM, dict(p1=fc[0], p2=fc[1], r=fc[2])))
+    caps.append((NARM + 1, dict(p1=fc[0], p2=[fc[1][0], -fc[1][1], fc[1][2]], r=fc[2])))
+    assert len(caps) == CONST["HRG_NRCAP"]
+    for c, (b, cap) in enumerate(caps):
+        d.rcap_body[c] = b
+        d.rcap_p1[c][:] = cap["p1"]
+        d.rcap_p2[c][:] = cap["p2"]
+        d.rcap_r[c] = cap["r"]
+    d.table_top_z = A["arena"]["table_top_z"]
+    d.table_half[:] = A["arena"]["table_half"]
+    d.floor_z = A["arena"]["floor_z"]
+    # self-collision candidates: not same body / parent-child, not colliding in the home pose
+    # (the rule the reference applies to its pinocchio model: pinocchio_manipulator_model.py:238-270)
+    R, p = robot_fk_numpy(d, np.concatenate([np.zeros(NARM), GRIPPER["finger_init_qpos"]]))
+    wp = []
+    for c, (b, cap) in enumerate(caps):
+        Rb, pb = (np.eye(3), np.asarray(d.base_pos[:])) if b < 0 else (R[b], p[b])
+        wp.append((pb + Rb @ np.asarray(cap["p1"]), pb + Rb @ np.asarray(cap["p2"]), cap["r"]))
+    for i in range(len(caps)):
+        mask = 0
+        for j in range(i + 1, len(caps)):
+            bi, bj = caps[i][0], caps[j][0]
+            if bi == bj or d.body_parent[bj] == bi or (bi >= 0 and d.body_parent[bi] == bj):
+                continue
+            if bi >= NARM and bj >= NARM:  # finger-finger
+                continue
+            if _seg_seg_dist(wp[i][0], wp[i][1], wp[j][0], wp[j][1]) - wp[i][2] - wp[j][2] < 0.01:
+                continue
+            mask |= 1 << j
+        d.rcap_selfmask[i] = mask
+    # ---- human
+    HB = A["human"]["bodies"]
+    names = [b["name"] for b in HB]
+    for i, b in enumerate(HB):
+        d.hb_parent[i] = b["parent"]
+        d.hb_depth[i] = 0 if b["parent"] < 0 else d.hb_depth[b["parent"]] + 1
+        d.hb_anchor[i][:] = b["anchor"]
+        d.hcap_p1[i][:] = b["capsule"]["p1"]
+        d.hcap_p2[i][:] = b["capsule"]["p2"]
+        d.hcap_r[i] = b["capsule"]["r"]
+        if i > 0:
+            assert b["joint_axes"] == [[0, 0, 1], [0, 1, 0], [1, 0, 0]], "human.xml joint order is z,y,x"
+    for k, n in enumerate(HUMAN_JOINT_ELEMENTS):
+        d.meas_body[k] = names.index(n)
+    d.site_lhand = HUMAN_JOINT_ELEMENTS.index("L_Hand")
+    d.site_rhand = HUMAN_JOINT_ELEMENTS.index("R_Hand")
+    d.site_head = HUMAN_JOINT_ELEMENTS.index("Head")
+    d.human_base_quat[:] = [0.5, 0.5, 0.5, 0.5]  # scipy (x,y,z,w)=(.5,.5,.5,.5) -> (w,x,y,z), human_env.py:373
+    d.base_human_pos_offset[:] = [float(x) for x in kw["base_human_pos_offset"]]
+    d.human_rand[:] = [float(x) for x in kw["human_rand"]]
+    # ---- controller
+    fcg = dict(FAILSAFE_CONFIG)
+    fcg.update(kw.get("controller_configs") or {})
+    d.kp = float(fcg["kp"])
+    d.kd = 2.0 * math.sqrt(d.kp) * float(fcg["damping_ratio"])
+    d.act_in_min, d.act_in_max = float(fcg["input_min"]), float(fcg["input_max"])
+    d.act_out_min, d.act_out_max = float(fcg["output_min"]), float(fcg["output_max"])
+    lim = fcg.get("qpos_limits") or SCHUNK_QPOS_LIMITS
+    for j in range(NARM):
+        d.qpos_limits[0][j] = lim[0][j]
+        d.qpos_limits[1][j] = lim[1][j]
+        d.init_qpos[j] = 0.0  # schunk_robot.py:62-65
+    d.init_noise = 0.02
+    # ---- shield
+    st = {"OFF": CONST["HRG_SHIELD_OFF"], "SSM": CONST["HRG_SHIELD_SSM"], "PFL": CONST["HRG_SHIELD_PFL"]}
+    d.shield_type = st[kw["shield_type"]]
+    for j in range(NARM):
+        d.v_max_allowed[j], d.a_max_allowed[j], d.j_max_allowed[j] = sp["v_max_allowed"], sp["a_max_allowed"], sp["j_max_allowed"]
+        d.v_max_ltt[j], d.a_max_ltt[j], d.j_max_ltt[j] = sp["v_max_ltt"], sp["a_max_ltt"], sp["j_max_ltt"]
+    d.path_amax = (sp["a_max_allowed"] - sp["a_max_ltt"]) / sp["v_max_ltt"]
+    d.path_jmax = (sp["j_max_allowed"] - sp["j_max_ltt"] - 3.0 * sp["a_max_ltt"] * d.path_amax) / sp["v_max_ltt"]
+    assert d.path_amax > 0 and d.path_jmax > 0
+    for c in range(NARM):
+        d.scap_body[c] = c
+        d.scap_p1[c][:] = links[c]["capsules"][0]["p1"]
+        d.scap_p2[c][:] = links[c]["capsules"][0]["p2"]
+        d.scap_r[c] = links[c]["capsules"][0]["r"]
+    sc = GRIPPER["shield_capsule"]
+    d.scap_body[NARM] = NARM - 1
+    d.scap_p1[NARM][:] = (p_hand + R_hand @ np.asarray(sc[0])).tolist()
+    d.scap_p2[NARM][:] = (p_hand + R_hand @ np.asarray(sc[1])).tolist()
+    d.scap_r[NARM] = sc[2]
+    base = np.asarray(d.base_pos[:])
+    for c in range(CONST["HRG_NSHIELD_RCAP"]):
+        b = d.scap_body[c]
+        reach = max(np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p1[c][:]) - base), np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p2[c][:]) - base))
+        d.scap_alpha[c] = reach * (sp["a_max_allowed"] + sp["v_max_allowed"] ** 2)
+    d.secure_radius = sp["secure_radius"]
+    d.n_bodypart = len(BODY_PARTS)
+    for k, (a, b, th, vm, am, inpos) in enumerate(BODY_PARTS):
+        d.bp_joint[k][:] = [HUMAN_JOINT_ELEMENTS.index(a), HUMAN_JOINT_ELEMENTS.index(b)]
+        d.bp_thickness[k], d.bp_vmax[k], d.bp_amax[k], d.bp_in_pos[k] = th, vm, am, inpos
+    d.n_extremity = len(EXTREMITIES)
+    anchor = {b["name"]: np.asarray(b["anchor"]) for b in HB}
+    for k, (prox, ch, th, vm) in enumerate(EXTREMITIES):
+        d.ext_joint[k] = HUMAN_JOINT_ELEMENTS.index(prox)
+        pts = [anchor[prox]] + [anchor[c] for c in ch]
+        d.ext_length[k] = float(sum(np.linalg.norm(pts[i + 1] - pts[i]) for i in range(len(pts) - 1))) + 0.1
+        d.ext_thickness[k], d.ext_vmax[k] = th, vm
+    d.meas_err_pos, d.meas_err_vel, d.delay = sp["meas_err_pos"], sp["meas_err_vel"], sp["delay"]
+    n_h = 2 * d.n_bodypart + d.n_extremity + sum(x[5] for x in BODY_PARTS)
+    assert n_h <= CONST["HRG_NHCAP_MAX"], n_h
+    # ---- task
+    control_timestep = 1.0 / kw["control_freq"]
+    d.n_cycles = int(control_timestep / kw["control_sample_time"])  # human_env.py:503
+    d.horizon = int(kw["horizon"])
+    d.n_goals = max(int(kw["horizon"] * kw["n_goals_sampled_per_100_steps"] / 100), 1)       # reach_human_env.py:318-321
+    d.n_anim_ids = max(int(kw["horizon"] * kw["n_animations_sampled_per_100_steps"] / 100), 1)  # human_env.py:379-382
+    d.n_clips = int(n_clips)
+    d.anim_step_length = int(1 / kw["control_sample_time"]) / kw["human_animation_freq"]  # human_env.py:1462-1465
+    assert d.anim_step_length >= 1
+    d.goal_dist = float(kw["goal_dist"])
+    d.reward_scale = 1.0 if kw["reward_scale"] is None else float(kw["reward_scale"])
+    d.task_reward = float(kw["task_reward"])
+    d.collision_reward = float(kw["collision_reward"])
+    d.sim_crash_reward = -10.0  # human_env.py:410
+    d.reward_shaping = int(bool(kw["reward_shaping"]))
+    d.done_at_collision = int(bool(kw["done_at_collision"]))
+    d.done_at_success = int(bool(kw["done_at_success"]))
+    d.safe_vel = float(kw["safe_vel"])
+    d.collision_debounce_delay = float(kw["collision_debounce_delay"])
+    d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
+    return d
+
+
+def robot_fk_numpy(d, q):
+    """Body frames of the 8 moving robot bodies (host-side table building only)."""
+    NV = CONST["HRG_NV"]
+    R, p = [None] * NV, [None] * NV
+    Rb, pb = _quat2mat(d.base_quat[:]), np.asarray(d.base_pos[:])
+    for i in range(NV):
+        par = d.body_parent[i]
+        Rp, pp = (Rb, pb) if par < 0 else (R[par], p[par])
+        Rl = Rp @ _quat2mat(d.body_quat[i][:])
+        pi = pp + Rp @ np.asarray(d.body_pos[i][:])
+        ax = np.asarray(d.jnt_axis[i][:])
+        if d.jnt_type[i] == 0:
+            c, s = math.cos(q[i]), math.sin(q[i])
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            R[i] = Rl @ (np.eye(3) + s * K + (1 - c) * (K @ K))
+            p[i] = pi
+        else:
+            R[i] = Rl
+            p[i] = pi + Rl @ ax * q[i]
+    return R, p

@@ -1,0 +1,259 @@
+/* hrgym.h — C ABI of libhrgym_hip.so, the MI355X-native batched stepper for human-robot-gym's
+ * ReachHuman hot path (HumanEnv.step = 25 x {mj_forward, SafetyShield.step, controller, human playback,
+ * contact bookkeeping, mj_step} + observation/reward/done/info + auto-reset).
+ *
+ * The reference has NO C interface for this path: it reaches its native engines through two Python
+ * extension modules (mujoco_py's MjSim, safety_shield_py's SafetyShield).  Each entry point below names
+ * the reference call site(s) it replaces (paths relative to the reference checkout):
+ *
+ *   hrg_batch_create   <- robosuite.make("ReachHuman", **env_kwargs)      utils/env_util.py:21-26
+ *                         + FailsafeController.__init__ / SafetyShield(...) controllers/failsafe_controller/
+ *                                                                          failsafe_controller/failsafe_controller.py:113-191
+ *                         + SubprocVecEnv([...]) worker spawn              utils/env_util_SB3.py:75-87
+ *   hrg_batch_reset    <- VecEnv.reset -> ReachHuman.reset -> HumanEnv._reset_internal
+ *                                                                          environments/manipulation/human_env.py:1604-1673
+ *                                                                          environments/manipulation/reach_human_env.py:509-523
+ *                         + FailsafeController.reset / SafetyShield.reset  failsafe_controller.py:204-250
+ *   hrg_batch_step     <- VecEnv.step_async/step_wait -> HumanEnv.step     human_env.py:470-586
+ *                         (sim.forward x2 + sim.step per cycle: 504,519,523; SafetyShield.step:
+ *                          failsafe_controller.py:329; humanMeasurement: 310; newLongTermTrajectory: 300)
+ *                         + ReachHuman.step goal cycling                   reach_human_env.py:383-410
+ *                         + TimeLimit.step                                 wrappers/time_limit.py:31-44
+ *                         + SubprocVecEnv auto-reset / terminal_observation [SB3 1.5.0]
+ *   hrg_batch_contacts <- sim.data.contact[:ncon] as read by HumanEnv._collision_detection
+ *                                                                          human_env.py:1082-1123
+ *   hrg_batch_get_state / hrg_batch_set_state
+ *                      <- HumanEnv.get/set_environment_state               human_env.py:1845-1900
+ *   hrg_batch_capsules <- SafetyShield.getRobotReachCapsules / getHumanReachCapsules
+ *                                                                          failsafe_controller.py:393,416
+ *
+ * Conventions: every function returns 0 on success or a negative hrg_status; hrg_last_error() gives the
+ * message (thread local).  All `dev` pointers are device (HBM) pointers owned by the caller (e.g.
+ * torch tensors' data_ptr()); `host` pointers are host memory.  A batch is bound to one HIP device, is not
+ * thread-safe, and orders its work on the stream handed to each call (0 = the null stream).  A simulation
+ * that diverges is not an error: the env reports done=1, reward += -10, info[HRG_INFO_SIM_CRASH]=1
+ * (mirrors the MujocoException handler at human_env.py:527-546).
+ */
+#ifndef HRGYM_H
+#define HRGYM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------ sizes */
+#define HRG_NARM 6        /* Schunk LWA-4P arm hinges (robot.xml:33-58) */
+#define HRG_NFINGER 2     /* RethinkValidGripper slide joints (rethink_valid_gripper.py:37-42) */
+#define HRG_NV (HRG_NARM + HRG_NFINGER)
+#define HRG_NHB 24        /* human bodies incl. pelvis (human.xml:45-330) */
+#define HRG_NHJ 23        /* measured human joints (models/objects/human/human.py:57-81) */
+#define HRG_NHQ 69        /* human hinge DoF = 23 x 3 */
+#define HRG_NRCAP 10      /* robot collision capsules: link0..link6, gripper base, 2 fingers */
+#define HRG_NSHIELD_RCAP 7 /* robot capsules the shield tracks: 6 links + gripper */
+#define HRG_NBODYPART_MAX 20 /* human body parts (capsule between two measured joints) */
+#define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
+#define HRG_NHCAP_MAX 64  /* human reach capsules over all three models (fits one wavefront) */
+#define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
+#define HRG_OBS_DIM 18    /* object-state(12) + goal_difference(6): human_reach_ppo_parallel.yaml:14-16 */
+#define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
+#define HRG_INFO_DIM 12
+#define HRG_NCON_MAX 32   /* contacts reported per env per substep */
+#define HRG_NCON_DYN 10   /* contacts that enter the constraint solve (4 pyramid rows each) */
+#define HRG_NPREV_MAX 32  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
+#define HRG_MAX_CLIPS 16
+
+/* info columns (human_env.py:752-763 + TimeLimit + sim crash) */
+enum {
+  HRG_INFO_COLLISION = 0,
+  HRG_INFO_COLLISION_TYPE = 1,
+  HRG_INFO_N_COLLISIONS = 2,
+  HRG_INFO_N_COLLISIONS_STATIC = 3,
+  HRG_INFO_N_COLLISIONS_ROBOT = 4,
+  HRG_INFO_N_COLLISIONS_HUMAN = 5,
+  HRG_INFO_N_COLLISIONS_CRITICAL = 6,
+  HRG_INFO_TIMEOUT = 7,
+  HRG_INFO_FAILSAFE_INTERVENTIONS = 8,
+  HRG_INFO_N_GOAL_REACHED = 9,
+  HRG_INFO_TRUNCATED = 10, /* TimeLimit.truncated (time_limit.py:42) */
+  HRG_INFO_SIM_CRASH = 11
+};
+
+/* COLLISION_TYPE flag values, human_env.py:55-77 */
+enum { HRG_COL_NULL = 0, HRG_COL_ALLOWED = 1, HRG_COL_HUMAN = 2, HRG_COL_ROBOT = 4, HRG_COL_STATIC = 8, HRG_COL_HUMAN_CRIT = 16 };
+
+/* shield types, failsafe_controller.py:23,173 */
+enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
+
+/* geom classes used by the contact classifier (human_env.py:948-964) */
+enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
+
+typedef enum {
+  HRG_OK = 0,
+  HRG_ERR_INVALID = -1,
+  HRG_ERR_HIP = -2,
+  HRG_ERR_NOMEM = -3,
+  HRG_ERR_UNSUPPORTED = -4
+} hrg_status;
+
+/* ------------------------------------------------------------------------------------------ model (POD) */
+
+/* One constant-model description: kinematic/inertial tables, collision capsules, controller and shield
+ * parameters, env (task) parameters.  Plain doubles/ints so that ctypes can fill it. */
+typedef struct hrg_model_desc {
+  /* ---- robot tree: 8 moving bodies (link1..link6, finger_l, finger_r), each with one joint ---------- */
+  double base_pos[3];           /* world pose of the robot root (link0 frame) */
+  double base_quat[4];          /* (w,x,y,z) */
+  double body_pos[HRG_NV][3];   /* frame offset in parent body frame */
+  double body_quat[HRG_NV][4];
+  int32_t body_parent[HRG_NV];  /* index of parent moving body, -1 = base */
+  int32_t jnt_type[HRG_NV];     /* 0 hinge, 1 slide */
+  double jnt_axis[HRG_NV][3];   /* in body frame */
+  double jnt_range[HRG_NV][2];
+  double jnt_damping[HRG_NV];
+  double jnt_frictionloss[HRG_NV];
+  double jnt_armature[HRG_NV];
+  double body_mass[HRG_NV];     /* welded children already merged in */
+  double body_com[HRG_NV][3];   /* in body frame */
+  double body_inertia[HRG_NV][6]; /* about com, body frame: xx yy zz xy xz yz */
+  double gravity[3];
+  double eef_pos[3];            /* grip site in the link6 body frame */
+  /* actuation: arm motors (robot.xml:4-9), finger position servos */
+  double arm_ctrlrange[HRG_NARM][2];
+  double finger_kp;
+  double finger_ctrlrange[HRG_NFINGER][2];
+  double finger_forcerange[2];
+  double finger_init_qpos[HRG_NFINGER];
+  double gripper_speed;         /* RethinkGripper.format_action step */
+  /* ---- constraint solver (MuJoCo-style soft constraints) -------------------------------------------- */
+  double timestep;              /* opt.timestep = control_sample_time (human_env.py:332) */
+  double solref[2];             /* timeconst, dampratio */
+  double solimp[5];             /* dmin dmax width midpoint power */
+  double contact_margin_human;  /* human.xml:5 margin */
+  double friction_static;       /* tangential friction of robot-static contacts (pyramidal) */
+  int32_t solver_iters;
+  double solver_tol;
+  /* ---- collision capsules ---------------------------------------------------------------------------- */
+  int32_t rcap_body[HRG_NRCAP]; /* moving-body index, -1 = base (link0) */
+  double rcap_p1[HRG_NRCAP][3];
+  double rcap_p2[HRG_NRCAP][3];
+  double rcap_r[HRG_NRCAP];
+  uint32_t rcap_selfmask[HRG_NRCAP]; /* bit j set: pair (i,j), j>i, is a candidate self-collision pair */
+  double table_top_z, table_half[2], floor_z;
+  /* ---- human -------------------------------------------------------------------------------------------- */
+  int32_t hb_parent[HRG_NHB];
+  int32_t hb_depth[HRG_NHB];
+  double hb_anchor[HRG_NHB][3]; /* joint anchor = site position, model frame (human.xml site pos) */
+  double hcap_p1[HRG_NHB][3];   /* collision capsule, model frame */
+  double hcap_p2[HRG_NHB][3];
+  double hcap_r[HRG_NHB];
+  int32_t meas_body[HRG_NHJ];   /* measured joint k -> human body index (human.py:57-81 order) */
+  int32_t site_lhand, site_rhand, site_head; /* indices into the measured-joint list */
+  double human_base_quat[4];    /* (w,x,y,z) of Rotation.from_quat([.5,.5,.5,.5]) human_env.py:373 */
+  double base_human_pos_offset[3];
+  double human_rand[3];
+  /* ---- controller (failsafe.json, schunk.json) ----------------------------------------------------- */
+  double kp, kd;
+  double act_in_min, act_in_max, act_out_min, act_out_max;
+  double qpos_limits[2][HRG_NARM];
+  double init_qpos[HRG_NARM];
+  double init_noise;            /* robosuite "default" initialization noise magnitude */
+  /* ---- shield (synthetic stand-ins for sara-shield's three YAML files) ----------------------------- */
+  int32_t shield_type;
+  double v_max_allowed[HRG_NARM], a_max_allowed[HRG_NARM], j_max_allowed[HRG_NARM];
+  double v_max_ltt[HRG_NARM], a_max_ltt[HRG_NARM], j_max_ltt[HRG_NARM];
+  double path_amax, path_jmax;  /* limits on s'' and s''' of fail-safe / recovery manoeuvres */
+  int32_t scap_body[HRG_NSHIELD_RCAP];
+  double scap_p1[HRG_NSHIELD_RCAP][3];
+  double scap_p2[HRG_NSHIELD_RCAP][3];
+  double scap_r[HRG_NSHIELD_RCAP];
+  double scap_alpha[HRG_NSHIELD_RCAP]; /* max Cartesian acceleration bound of the capsule end points */
+  double secure_radius;
+  int32_t n_bodypart;
+  int32_t bp_joint[HRG_NBODYPART_MAX][2]; /* measured-joint indices (proximal, distal) */
+  double bp_thickness[HRG_NBODYPART_MAX];
+  double bp_vmax[HRG_NBODYPART_MAX];
+  double bp_amax[HRG_NBODYPART_MAX];
+  int32_t bp_in_pos[HRG_NBODYPART_MAX];   /* part keeps its VEL capsule in the POS model (torso, head) */
+  int32_t n_extremity;
+  int32_t ext_joint[HRG_NEXTREMITY_MAX];  /* proximal measured joint */
+  double ext_length[HRG_NEXTREMITY_MAX];
+  double ext_thickness[HRG_NEXTREMITY_MAX];
+  double ext_vmax[HRG_NEXTREMITY_MAX];
+  double meas_err_pos, meas_err_vel, delay;
+  /* ---- task / env (reach_human.yaml, human_env.yaml) ---------------------------------------------- */
+  int32_t n_cycles;             /* int(control_timestep / control_sample_time) human_env.py:503 */
+  int32_t horizon;
+  int32_t n_goals;              /* reach_human_env.py:318-321 */
+  int32_t n_anim_ids;           /* human_env.py:379-382 */
+  int32_t n_clips;
+  double anim_step_length;      /* int(1/timestep)/human_animation_freq, human_env.py:1462-1465 */
+  double goal_dist, reward_scale, task_reward, collision_reward, sim_crash_reward;
+  int32_t reward_shaping, done_at_collision, done_at_success;
+  double safe_vel, collision_debounce_delay;
+  uint64_t seed;
+} hrg_model_desc;
+
+/* Human animation clips, shared by all envs of a batch.  Frame layout (doubles):
+ *   [0:3] Pelvis_pos_{x,y,z}   [3:7] Pelvis_quat (x,y,z,w — scipy order, convert_bvh.py:84-101)
+ *   [7:76] 69 joint angles in qpos order of human.xml (body DFS order, per body z,y,x)
+ * plus per-clip info (position_offset[3], orientation_quat[4] (x,y,z,w)): animation_utils.py:50-54 */
+#define HRG_FRAME_DIM 76
+typedef struct hrg_clip_table {
+  int32_t n_clips;
+  int32_t clip_len[HRG_MAX_CLIPS];     /* frames */
+  int64_t clip_offset[HRG_MAX_CLIPS];  /* first frame index into `frames` */
+  double clip_pos_offset[HRG_MAX_CLIPS][3];
+  double clip_quat[HRG_MAX_CLIPS][4];  /* (x,y,z,w) */
+  const double* frames;                /* host pointer, [total_frames][HRG_FRAME_DIM] */
+  int64_t total_frames;
+} hrg_clip_table;
+
+typedef struct hrg_batch hrg_batch; /* opaque */
+
+/* ----------------------------------------------------------------------------------------------- entry points */
+const char* hrg_last_error(void);
+const char* hrg_version(void);
+
+/* size in bytes of one env's resident state block (for get/set_state buffers) */
+size_t hrg_state_bytes(void);
+
+/* Create n_envs environments with global ids [env_id0, env_id0+n_envs) on HIP device `device`.
+ * Per-env random draws are keyed by (desc->seed, global env id, episode index), so the results do not
+ * depend on how the global batch is sharded over GPUs. */
+int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs,
+                     int64_t env_id0, int32_t device, hrg_batch** out);
+void hrg_batch_destroy(hrg_batch* b);
+
+/* Reset envs whose mask byte is non-zero (mask == NULL: all).  mask is a DEVICE pointer [n_envs].
+ * obs_dev: float[n_envs][HRG_OBS_DIM], rows of reset envs are overwritten (others untouched). */
+int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream);
+
+/* One policy step of every env: n_cycles shield cycles, observation, reward, done, info, auto-reset.
+ *   actions_dev  const double[n_envs][HRG_ACT_DIM]
+ *   obs_dev      float[n_envs][HRG_OBS_DIM]   (observation AFTER auto-reset where done)
+ *   term_obs_dev float[n_envs][HRG_OBS_DIM]   (observation BEFORE auto-reset; may be NULL)
+ *   reward_dev   float[n_envs];  done_dev uint8_t[n_envs];  info_dev int32_t[n_envs][HRG_INFO_DIM]
+ * Asynchronous with respect to the host. */
+int hrg_batch_step(hrg_batch* b, const double* actions_dev, float* obs_dev, float* term_obs_dev,
+                   float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream);
+
+/* Parity hooks (synchronous, host buffers). */
+/* contacts of the LAST substep of the last step: pairs_host int32[n_envs][HRG_NCON_MAX][2], ncon_host int32[n_envs] */
+int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host);
+/* reach capsules of the last shield cycle: robot double[n_envs][HRG_NSHIELD_RCAP][7],
+ * human double[n_envs][HRG_NHCAP_MAX][7] (p1,p2,r), n_human int32[n_envs] */
+int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int32_t* n_human_host);
+int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
+int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
+
+/* Kernel timing hook for bench.py: records HIP events on the launch stream around every step kernel
+ * since the last call; returns average kernel milliseconds and the number of launches measured. */
+int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRGYM_H */

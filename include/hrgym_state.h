@@ -1,0 +1,82 @@
+/* hrgym_state.h — layout of one environment's resident state block.
+ *
+ * This is the byte image exchanged by hrg_batch_get_state / hrg_batch_set_state (the batched equivalent of
+ * HumanEnvState / ReachHumanEnvState, human_env.py:80-103, reach_human_env.py:33-54: flattened sim state
+ * + animation / goal bookkeeping) and the block the step kernel streams HBM -> LDS -> HBM once per policy
+ * step.  All doubles first, then int32s; sizeof is a multiple of 8.
+ */
+#ifndef HRGYM_STATE_H
+#define HRGYM_STATE_H
+
+#include "hrgym.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Long-term trajectory: per joint an initial state and HRG_LTT_NSEG constant-jerk segments
+ * (replaces sara-shield's sampled LongTermTraj; evaluated in closed form at path parameter s). */
+typedef struct hrg_ltt {
+  double q0[HRG_NARM], v0[HRG_NARM], a0[HRG_NARM];
+  double qT[HRG_NARM]; /* goal configuration (state after the last segment) */
+  double dur[HRG_NARM][HRG_LTT_NSEG];
+  double jerk[HRG_NARM][HRG_LTT_NSEG];
+  double T; /* duration of the slowest joint */
+} hrg_ltt;
+
+/* Three-phase constant-jerk profile of the path parameter s (sara-shield `Path`). */
+typedef struct hrg_path {
+  double s0, v0, a0;
+  double dur[3];
+  double jerk[3];
+  double k; /* whole sample steps elapsed since the profile start */
+} hrg_path;
+
+typedef struct hrg_env_state {
+  /* ---- MjSimState slice that is dynamic in this model (robot tree) ---- */
+  double qpos[HRG_NV], qvel[HRG_NV], qacc_warmstart[HRG_NV];
+  double time;
+  /* ---- controller (FailsafeController / SingleArm) ---- */
+  double goal_qpos[HRG_NARM];
+  double mass_matrix[HRG_NARM * HRG_NARM]; /* stale 6x6 block, refreshed on policy steps only */
+  double grip_action;                      /* RethinkGripper.current_action */
+  double torque[HRG_NARM];                 /* last applied arm torques */
+  /* ---- shield ---- */
+  hrg_ltt ltt;
+  hrg_path safe_path;       /* last verified fail-safe profile */
+  double path_s, path_v, path_a; /* current path state on `ltt` */
+  double new_goal_q[HRG_NARM];
+  double meas_prev[HRG_NHJ][3];
+  double meas_prev_t;
+  double des_q[HRG_NARM], des_v[HRG_NARM], des_a[HRG_NARM]; /* last Motion returned by the shield */
+  /* ---- human ---- */
+  double human_site[HRG_NHJ][3]; /* world positions of the 23 joint sites at the current pose */
+  double human_pos_offset[3];
+  double human_rot_offset[4];    /* (w,x,y,z) */
+  double debounce_timer;
+  double eef_pos[3];             /* grip-site position of the last forward pass (observable source) */
+  /* ---- integers ---- */
+  int32_t timestep;          /* policy steps in this episode */
+  int32_t low_level_time;    /* human_env.py:526 */
+  int32_t anim_index;        /* _human_animation_ids_index */
+  int32_t anim_start_time;
+  int32_t animation_time;
+  int32_t goal_index;        /* _desired_goals_index */
+  int32_t episode;           /* episode counter = RNG key */
+  int32_t new_goal;          /* shield: goal pending */
+  int32_t is_safe;
+  int32_t n_meas;            /* measurements received since reset (0,1,2+) */
+  int32_t failsafe_interventions;
+  int32_t n_collisions_static, n_collisions_robot, n_collisions_human, n_collisions_critical;
+  int32_t n_goal_reached;
+  int32_t n_prev;                    /* previous_robot_collisions (cantor hashes of both orders) */
+  int32_t prev_pairs[HRG_NPREV_MAX];
+  int32_t ncon;                      /* contacts of the last substep (parity hook) */
+  int32_t con_pairs[HRG_NCON_MAX][2];
+  int32_t pad_;
+} hrg_env_state;
+
+#ifdef __cplusplus
+}
+#endif
+#endif

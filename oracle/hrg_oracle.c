@@ -1,0 +1,1250 @@
+/* hrg_oracle.c — CPU restatement (plain scalar C, double precision) of human-robot-gym's ReachHuman
+ * hot path.  TEST INFRASTRUCTURE ONLY: nothing in the product path (human-robot-gym_amd/, bench.py's GPU leg)
+ * may link, import or execute this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and there only as the checker.
+ *
+ * PARITY UNPINNED.  The reference's arithmetic for this path lives in three packages whose sources are
+ * absent from the reference checkout and not installed here: MuJoCo 2.1.0 (via mujoco_py==2.1.2.14,
+ * requirements.txt:4), sara-shield (git submodule, branch main, unpinned commit, .gitmodules:1-4, directory
+ * empty) and robosuite==1.3.2 (requirements.txt:8).  The reference holds no golden vectors, known-answer
+ * tests or fixtures for mj_step, SafetyShield.step or env.step.  This file therefore
+ * restates (i) the reference's own Python control flow line by line where it exists (cited below as
+ * file:line relative to the reference root) and (ii) the published algorithms of the absent engines
+ * (Featherstone CRBA/RNEA; MuJoCo's soft-constraint formulation; Thumm & Althoff's fail-safe shield,
+ * arXiv 2205.06311; SaRA reachable sets).  What the tests pin is agreement between this restatement and
+ * the HIP kernels, plus analytic known-answer tests of the pieces — NOT agreement with MuJoCo/sara-shield.
+ * Deviations from the reference stack that are deliberate in this round are listed in DESIGN.md §4.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/hrgym.h"
+#include "../include/hrgym_state.h"
+
+#define NV HRG_NV
+#define NARM HRG_NARM
+#define NEFC_MAX 64
+#define PI 3.14159265358979323846
+
+/* =============================================================================================== vec/quat */
+static void v3set(double* r, double a, double b, double c) { r[0] = a; r[1] = b; r[2] = c; }
+static void v3cpy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+static void v3add(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+static void v3sub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+static void v3scl(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
+static void v3madd(double* r, const double* a, const double* b, double s) { r[0] = a[0] + b[0] * s; r[1] = a[1] + b[1] * s; r[2] = a[2] + b[2] * s; }
+static double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+static double v3norm(const double* a) { return sqrt(v3dot(a, a)); }
+static void v3cross(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+/* row-major 3x3 */
+static void m3mulv(double* r, const double* M, const double* v) {
+  double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
+  double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
+  double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void m3mul(double* R, const double* A, const double* B) {
+  double T[9];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) T[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+  memcpy(R, T, sizeof T);
+}
+/* quaternion (w,x,y,z) -> rotation matrix */
+static void quat2mat(double* M, const double* q) {
+  double w = q[0], x = q[1], y = q[2], z = q[3];
+  M[0] = 1 - 2 * (y * y + z * z); M[1] = 2 * (x * y - w * z); M[2] = 2 * (x * z + w * y);
+  M[3] = 2 * (x * y + w * z); M[4] = 1 - 2 * (x * x + z * z); M[5] = 2 * (y * z - w * x);
+  M[6] = 2 * (x * z - w * y); M[7] = 2 * (y * z + w * x); M[8] = 1 - 2 * (x * x + y * y);
+}
+static void quatmul(double* r, const double* a, const double* b) {
+  double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
+  double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
+  double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
+  double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
+  r[0] = w; r[1] = x; r[2] = y; r[3] = z;
+}
+/* rotation about a unit axis by angle, as a matrix */
+static void axisangle2mat(double* M, const double* ax, double ang) {
+  double c = cos(ang), s = sin(ang), t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
+  M[0] = t * x * x + c; M[1] = t * x * y - s * z; M[2] = t * x * z + s * y;
+  M[3] = t * x * y + s * z; M[4] = t * y * y + c; M[5] = t * y * z - s * x;
+  M[6] = t * x * z - s * y; M[7] = t * y * z + s * x; M[8] = t * z * z + c;
+}
+static double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+
+/* =============================================================================================== RNG
+ * The reference draws from the process-global legacy numpy stream seeded with seed+rank
+ * (human_env.py:336,1637; reach_human_env.py:536).  A batched env cannot share one sequential stream,
+ * so draws are counter-based: u = hash(seed, global env id, episode, stream, index).  Same distributions,
+ * different numbers; independent of how envs are sharded over GPUs. */
+static uint64_t mix64(uint64_t x) {
+  x += 0x9E3779B97F4A7C15ULL;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ULL;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBULL;
+  return x ^ (x >> 31);
+}
+static double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream, uint64_t idx) {
+  uint64_t h = mix64(seed);
+  h = mix64(h ^ (env * 0xD1B54A32D192ED03ULL));
+  h = mix64(h ^ (episode * 0x8CB92BA72F3D8DD7ULL));
+  h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
+  return (double)(h >> 11) * (1.0 / 9007199254740992.0);
+}
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3 };
+static double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
+  double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
+  return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * PI * u2);
+}
+
+/* =============================================================================================== batch */
+typedef struct hrgo_batch {
+  hrg_model_desc m;
+  hrg_clip_table clips;
+  double* frames; /* owned copy */
+  int32_t n_envs;
+  int64_t env_id0;
+  hrg_env_state* st;
+  /* parity taps of the last shield cycle */
+  double (*rcaps)[HRG_NSHIELD_RCAP][7];
+  double (*hcaps)[HRG_NHCAP_MAX][7];
+  int32_t* n_hcaps;
+} hrgo_batch;
+
+/* =============================================================================================== robot
+ * Kinematics + CRBA + RNEA of the 8-DoF robot tree in world coordinates about the world origin
+ * (Featherstone, RBDA ch. 5-6; the quantities mj_kinematics/mj_crb/mj_rne produce for this tree:
+ * SURVEY.md Appendix B.1). */
+typedef struct {
+  double R[NV][9], p[NV][3]; /* body frames */
+  double Sw[NV][3], Sv[NV][3]; /* joint motion subspace: angular, linear (about world origin) */
+  double com[NV][3];           /* world com */
+  double Iw[NV][6];            /* world rotational inertia about com: xx yy zz xy xz yz */
+  double vw[NV][3], vv[NV][3]; /* body spatial velocity (filled by robot_bias) */
+} robot_kin;
+
+static void robot_fk(const hrg_model_desc* m, const double* q, robot_kin* k) {
+  double Rb[9];
+  quat2mat(Rb, m->base_quat);
+  for (int i = 0; i < NV; i++) {
+    const double *Rp, *pp;
+    int par = m->body_parent[i];
+    if (par < 0) { Rp = Rb; pp = m->base_pos; } else { Rp = k->R[par]; pp = k->p[par]; }
+    double Rq[9], Rl[9], t[3], axw[3];
+    quat2mat(Rq, m->body_quat[i]);
+    m3mul(Rl, Rp, Rq);
+    m3mulv(t, Rp, m->body_pos[i]);
+    v3add(k->p[i], pp, t);
+    if (m->jnt_type[i] == 0) {
+      double Rj[9];
+      axisangle2mat(Rj, m->jnt_axis[i], q[i]);
+      m3mul(k->R[i], Rl, Rj);
+      m3mulv(axw, k->R[i], m->jnt_axis[i]);
+      v3cpy(k->Sw[i], axw);
+      v3cross(k->Sv[i], k->p[i], axw);
+    } else {
+      memcpy(k->R[i], Rl, sizeof Rl);
+      m3mulv(axw, k->R[i], m->jnt_axis[i]);
+      v3madd(k->p[i], k->p[i], axw, q[i]);
+      v3set(k->Sw[i], 0, 0, 0);
+      v3cpy(k->Sv[i], axw);
+    }
+    m3mulv(t, k->R[i], m->body_com[i]);
+    v3add(k->com[i], k->p[i], t);
+    /* Iw = R I R^T */
+    const double* I = m->body_inertia[i];
+    double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Rt[9], W[9];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) Rt[3 * a + b] = k->R[i][3 * b + a];
+    m3mul(T, k->R[i], Ib);
+    m3mul(W, T, Rt);
+    k->Iw[i][0] = W[0]; k->Iw[i][1] = W[4]; k->Iw[i][2] = W[8]; k->Iw[i][3] = W[1]; k->Iw[i][4] = W[2]; k->Iw[i][5] = W[5];
+  }
+}
+
+/* spatial inertia about the world origin in additive form: m, h = m*c, IO(6) */
+typedef struct { double m, h[3], I[6]; } sinertia;
+static void sinertia_body(sinertia* s, double m, const double* c, const double* Ic) {
+  s->m = m;
+  v3scl(s->h, c, m);
+  double cc = v3dot(c, c);
+  s->I[0] = Ic[0] + m * (cc - c[0] * c[0]);
+  s->I[1] = Ic[1] + m * (cc - c[1] * c[1]);
+  s->I[2] = Ic[2] + m * (cc - c[2] * c[2]);
+  s->I[3] = Ic[3] - m * c[0] * c[1];
+  s->I[4] = Ic[4] - m * c[0] * c[2];
+  s->I[5] = Ic[5] - m * c[1] * c[2];
+}
+/* force = I * motion : n = IO w + h x v ; f = m v - h x w */
+static void sinertia_mul(double* n, double* f, const sinertia* s, const double* w, const double* v) {
+  double hv[3], hw[3];
+  v3cross(hv, s->h, v);
+  v3cross(hw, s->h, w);
+  n[0] = s->I[0] * w[0] + s->I[3] * w[1] + s->I[4] * w[2] + hv[0];
+  n[1] = s->I[3] * w[0] + s->I[1] * w[1] + s->I[5] * w[2] + hv[1];
+  n[2] = s->I[4] * w[0] + s->I[5] * w[1] + s->I[2] * w[2] + hv[2];
+  f[0] = s->m * v[0] - hw[0];
+  f[1] = s->m * v[1] - hw[1];
+  f[2] = s->m * v[2] - hw[2];
+}
+
+/* composite-rigid-body mass matrix (dense NV x NV, row major), armature on the diagonal */
+static void robot_crba(const hrg_model_desc* m, const robot_kin* k, double* M) {
+  sinertia c[NV];
+  for (int i = 0; i < NV; i++) sinertia_body(&c[i], m->body_mass[i], k->com[i], k->Iw[i]);
+  for (int i = NV - 1; i >= 0; i--) {
+    int par = m->body_parent[i];
+    if (par >= 0) {
+      c[par].m += c[i].m;
+      for (int a = 0; a < 3; a++) c[par].h[a] += c[i].h[a];
+      for (int a = 0; a < 6; a++) c[par].I[a] += c[i].I[a];
+    }
+  }
+  memset(M, 0, sizeof(double) * NV * NV);
+  for (int j = 0; j < NV; j++) {
+    double n[3], f[3];
+    sinertia_mul(n, f, &c[j], k->Sw[j], k->Sv[j]);
+    for (int i = j; i >= 0; i = m->body_parent[i]) {
+      double v = v3dot(k->Sw[i], n) + v3dot(k->Sv[i], f);
+      M[i * NV + j] = v;
+      M[j * NV + i] = v;
+    }
+    M[j * NV + j] += m->jnt_armature[j];
+  }
+}
+
+/* bias forces c(q, qd) = RNEA(q, qd, 0) incl. gravity; also leaves body velocities in k */
+static void robot_bias(const hrg_model_desc* m, robot_kin* k, const double* qd, double* bias) {
+  double aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
+  for (int i = 0; i < NV; i++) {
+    int par = m->body_parent[i];
+    double pw[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, paw[3] = {0, 0, 0}, pav[3];
+    v3scl(pav, m->gravity, -1.0);
+    if (par >= 0) { v3cpy(pw, k->vw[par]); v3cpy(pv, k->vv[par]); v3cpy(paw, aw[par]); v3cpy(pav, av[par]); }
+    double jw[3], jv[3];
+    v3scl(jw, k->Sw[i], qd[i]);
+    v3scl(jv, k->Sv[i], qd[i]);
+    v3add(k->vw[i], pw, jw);
+    v3add(k->vv[i], pv, jv);
+    /* a = a_parent + crm(v_i) (S qd) : [w x jw ; w x jv + v x jw] */
+    double t1[3], t2[3], t3[3];
+    v3cross(t1, k->vw[i], jw);
+    v3cross(t2, k->vw[i], jv);
+    v3cross(t3, k->vv[i], jw);
+    v3add(aw[i], paw, t1);
+    v3add(av[i], pav, t2);
+    v3add(av[i], av[i], t3);
+    /* f = I a + crf(v)(I v) : [w x n + v x f ; w x f] */
+    sinertia s;
+    sinertia_body(&s, m->body_mass[i], k->com[i], k->Iw[i]);
+    double n1[3], f1[3], n2[3], f2[3];
+    sinertia_mul(n1, f1, &s, aw[i], av[i]);
+    sinertia_mul(n2, f2, &s, k->vw[i], k->vv[i]);
+    v3cross(t1, k->vw[i], n2);
+    v3cross(t2, k->vv[i], f2);
+    v3cross(t3, k->vw[i], f2);
+    for (int a = 0; a < 3; a++) { fn[i][a] = n1[a] + t1[a] + t2[a]; ff[i][a] = f1[a] + t3[a]; }
+  }
+  for (int i = NV - 1; i >= 0; i--) {
+    bias[i] = v3dot(k->Sw[i], fn[i]) + v3dot(k->Sv[i], ff[i]);
+    int par = m->body_parent[i];
+    if (par >= 0) for (int a = 0; a < 3; a++) { fn[par][a] += fn[i][a]; ff[par][a] += ff[i][a]; }
+  }
+}
+
+/* velocity of a world point rigidly attached to body b (b<0: static) */
+static void robot_point_vel(const robot_kin* k, int b, const double* r, double* v) {
+  if (b < 0) { v3set(v, 0, 0, 0); return; }
+  double t[3];
+  v3cross(t, k->vw[b], r);
+  v3add(v, k->vv[b], t);
+}
+/* Jacobian row: d/dqd of (dir . velocity of point r on body b) */
+static void robot_point_jac(const hrg_model_desc* m, const robot_kin* k, int b, const double* r, const double* dir, double sign, double* J) {
+  for (int i = b; i >= 0; i = m->body_parent[i]) {
+    double t[3], v[3];
+    v3cross(t, k->Sw[i], r);
+    v3add(v, k->Sv[i], t);
+    J[i] += sign * v3dot(dir, v);
+  }
+}
+
+/* Cholesky of an n x n SPD matrix in place (lower), returns 0 if not PD */
+static int chol(double* A, int n) {
+  for (int j = 0; j < n; j++) {
+    double d = A[j * n + j];
+    for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+    if (!(d > 0)) return 0;
+    d = sqrt(d);
+    A[j * n + j] = d;
+    for (int i = j + 1; i < n; i++) {
+      double s = A[i * n + j];
+      for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+      A[i * n + j] = s / d;
+    }
+  }
+  return 1;
+}
+static void chol_solve(const double* L, int n, double* x) {
+  for (int i = 0; i < n; i++) {
+    double s = x[i];
+    for (int k = 0; k < i; k++) s -= L[i * n + k] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+  for (int i = n - 1; i >= 0; i--) {
+    double s = x[i];
+    for (int k = i + 1; k < n; k++) s -= L[k * n + i] * x[k];
+    x[i] = s / L[i * n + i];
+  }
+}
+
+/* =============================================================================================== capsules */
+/* closest points of two segments (Ericson, Real-Time Collision Detection 5.1.9; the clamped
+ * closest-point computation SURVEY.md B.3 names).  Returns squared distance, c1/c2 closest points. */
+static double seg_seg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) {
+  double d1[3], d2[3], r[3];
+  v3sub(d1, q1, p1);
+  v3sub(d2, q2, p2);
+  v3sub(r, p1, p2);
+  double a = v3dot(d1, d1), e = v3dot(d2, d2), f = v3dot(d2, r), s, t;
+  const double EPS = 1e-12;
+  if (a <= EPS && e <= EPS) { s = t = 0; }
+  else if (a <= EPS) { s = 0; t = clampd(f / e, 0, 1); }
+  else {
+    double c = v3dot(d1, r);
+    if (e <= EPS) { t = 0; s = clampd(-c / a, 0, 1); }
+    else {
+      double b = v3dot(d1, d2), den = a * e - b * b;
+      s = den > EPS * a * e ? clampd((b * f - c * e) / den, 0, 1) : 0;
+      t = (b * s + f) / e;
+      if (t < 0) { t = 0; s = clampd(-c / a, 0, 1); }
+      else if (t > 1) { t = 1; s = clampd((b - c) / a, 0, 1); }
+    }
+  }
+  v3madd(c1, p1, d1, s);
+  v3madd(c2, p2, d2, t);
+  double d[3];
+  v3sub(d, c1, c2);
+  return v3dot(d, d);
+}
+
+/* =============================================================================================== human
+ * Animation clock and root/joint pose: HumanEnv._control_human, human_env.py:1710-1767.
+ * Kinematics of the 24-body tree: the mj_kinematics rule for bodies whose three hinges share an anchor
+ * (R_b = R_parent Rz Ry Rx ; the anchor stays fixed), human.xml:50-59. */
+typedef struct {
+  double R[HRG_NHB][9], p[HRG_NHB][3];
+  double cap1[HRG_NHB][3], cap2[HRG_NHB][3]; /* world collision capsules */
+} human_kin;
+
+static int clip_of(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int anim_index) {
+  double u = rng_u01(b->m.seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_ANIM, (uint64_t)anim_index);
+  int c = (int)(u * b->m.n_clips);
+  return c >= b->m.n_clips ? b->m.n_clips - 1 : c;
+}
+
+static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, double* mocap_pos, double* mocap_quat, const double** qh) {
+  const hrg_model_desc* m = &b->m;
+  /* human_env.py:1719-1731 */
+  int control_time = (int)floor((double)s->low_level_time / m->anim_step_length);
+  int at = control_time - s->anim_start_time;
+  s->animation_time = at;
+  int clip = clip_of(b, gid, s, s->anim_index);
+  if (at > b->clips.clip_len[clip] - 1) {
+    s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
+    s->animation_time = 0;
+    s->anim_start_time = control_time;
+    clip = clip_of(b, gid, s, s->anim_index);
+  }
+  const double* fr = b->frames + (b->clips.clip_offset[clip] + s->animation_time) * HRG_FRAME_DIM;
+  /* human_env.py:1736-1763: pos = R(base*info) (p_anim + off_info) + offset_env ; rot = rot_env*base*info*pelvis */
+  double qi[4] = {b->clips.clip_quat[clip][3], b->clips.clip_quat[clip][0], b->clips.clip_quat[clip][1], b->clips.clip_quat[clip][2]};
+  double qbi[4], Rbi[9], pa[3], pr[3];
+  quatmul(qbi, m->human_base_quat, qi);
+  quat2mat(Rbi, qbi);
+  for (int a = 0; a < 3; a++) pa[a] = fr[a] + b->clips.clip_pos_offset[clip][a];
+  m3mulv(pr, Rbi, pa);
+  v3add(mocap_pos, pr, s->human_pos_offset);
+  double qa[4] = {fr[6], fr[3], fr[4], fr[5]}, q1[4];
+  quatmul(q1, s->human_rot_offset, qbi);
+  quatmul(mocap_quat, q1, qa);
+  *qh = fr + 7;
+}
+
+static void human_fk(const hrg_model_desc* m, const double* mocap_pos, const double* mocap_quat, const double* qh, human_kin* h, double site[HRG_NHJ][3]) {
+  static const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+  quat2mat(h->R[0], mocap_quat);
+  v3cpy(h->p[0], mocap_pos);
+  for (int b = 1; b < HRG_NHB; b++) {
+    int par = m->hb_parent[b];
+    double Rz[9], Ry[9], Rx[9], T[9], anc[3], t[3];
+    const double* q = qh + 3 * (b - 1); /* z, y, x (human.xml joint order) */
+    axisangle2mat(Rz, ez, q[0]);
+    axisangle2mat(Ry, ey, q[1]);
+    axisangle2mat(Rx, ex, q[2]);
+    m3mul(T, h->R[par], Rz);
+    m3mul(T, T, Ry);
+    m3mul(h->R[b], T, Rx);
+    m3mulv(t, h->R[par], m->hb_anchor[b]);
+    v3add(anc, h->p[par], t);
+    m3mulv(t, h->R[b], m->hb_anchor[b]);
+    v3sub(h->p[b], anc, t);
+  }
+  for (int b = 0; b < HRG_NHB; b++) {
+    double t[3];
+    m3mulv(t, h->R[b], m->hcap_p1[b]); v3add(h->cap1[b], h->p[b], t);
+    m3mulv(t, h->R[b], m->hcap_p2[b]); v3add(h->cap2[b], h->p[b], t);
+  }
+  for (int j = 0; j < HRG_NHJ; j++) {
+    int b = m->meas_body[j];
+    double t[3];
+    m3mulv(t, h->R[b], m->hb_anchor[b]);
+    v3add(site[j], h->p[b], t);
+  }
+}
+
+/* =============================================================================================== LTT
+ * Long-term trajectory: per joint jerk-limited point-to-point profile from (q0,v0,a0) to (goal,0,0)
+ * (role of sara-shield LongTermPlanner behind SafetyShield.newLongTermTrajectory,
+ * failsafe_controller.py:300).  Own construction (the planner source is absent): ramp a->0, then
+ * S-curve / cruise / S-curve with the cruise velocity found by bisection; joints are not time-synchronised. */
+static int scurve(double va, double vb, double amax, double jmax, double* dur, double* jerk) {
+  double d = vb - va, ad = fabs(d), sg = d >= 0 ? 1.0 : -1.0;
+  if (ad >= amax * amax / jmax) {
+    double tj = amax / jmax;
+    dur[0] = tj; dur[1] = ad / amax - tj; dur[2] = tj;
+  } else {
+    double tj = sqrt(ad / jmax);
+    dur[0] = tj; dur[1] = 0; dur[2] = tj;
+  }
+  jerk[0] = sg * jmax; jerk[1] = 0; jerk[2] = -sg * jmax;
+  return 3;
+}
+static double scurve_time(double dv, double amax, double jmax) {
+  double ad = fabs(dv);
+  return ad >= amax * amax / jmax ? ad / amax + amax / jmax : 2 * sqrt(ad / jmax);
+}
+/* distance of [S-curve va->vc][S-curve vc->0] without cruise */
+static double dist_nocruise(double va, double vc, double amax, double jmax) {
+  return 0.5 * (va + vc) * scurve_time(vc - va, amax, jmax) + 0.5 * vc * scurve_time(vc, amax, jmax);
+}
+
+static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax) {
+  double* dur = L->dur[j];
+  double* jerk = L->jerk[j];
+  for (int i = 0; i < HRG_LTT_NSEG; i++) { dur[i] = 0; jerk[i] = 0; }
+  L->q0[j] = q0; L->v0[j] = v0; L->a0[j] = a0; L->qT[j] = goal;
+  int n = 0;
+  double q = q0, v = v0;
+  /* seg 0: acceleration to zero */
+  if (a0 != 0) {
+    double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
+    dur[n] = t; jerk[n] = jj; n++;
+    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
+    v += a0 * t + 0.5 * jj * t * t;
+  } else n++;
+  double D = goal - q;
+  double dstop = 0.5 * v * scurve_time(v, amax, jmax);
+  double sg = (D - dstop) >= 0 ? 1.0 : -1.0;
+  if (sg * v < 0) {
+    /* moving away from where we must go: stop first, continue from rest */
+    n += scurve(v, 0, amax, jmax, dur + n, jerk + n);
+    D -= dstop;
+    v = 0;
+  } else n += 3;
+  /* now sg*v >= 0 and sg*(D - dstop(v)) >= 0: find cruise velocity vc = sg*w, w in [|v|, wmax] */
+  double w_lo = fabs(v), w_hi = vmax > w_lo ? vmax : w_lo, w, tc = 0;
+  double Dm = sg * D, vm = sg * v; /* mirrored problem: everything positive */
+  if (Dm >= dist_nocruise(vm, w_hi, amax, jmax)) {
+    w = w_hi;
+    tc = w > 0 ? (Dm - dist_nocruise(vm, w, amax, jmax)) / w : 0;
+  } else {
+    double lo = w_lo, hi = w_hi;
+    for (int it = 0; it < 64; it++) {
+      double mid = 0.5 * (lo + hi);
+      if (dist_nocruise(vm, mid, amax, jmax) <= Dm) lo = mid; else hi = mid;
+    }
+    w = lo;
+  }
+  n += scurve(v, sg * w, amax, jmax, dur + n, jerk + n);
+  dur[n] = tc; jerk[n] = 0; n++;
+  n += scurve(sg * w, 0, amax, jmax, dur + n, jerk + n);
+}
+
+static void ltt_plan(const hrg_model_desc* m, hrg_ltt* L, const double* q0, const double* v0, const double* a0, const double* goal) {
+  double T = 0;
+  for (int j = 0; j < NARM; j++) {
+    ltt_plan_joint(L, j, q0[j], v0[j], a0[j], goal[j], m->v_max_ltt[j], m->a_max_ltt[j], m->j_max_ltt[j]);
+    double t = 0;
+    for (int i = 0; i < HRG_LTT_NSEG; i++) t += L->dur[j][i];
+    if (t > T) T = t;
+  }
+  L->T = T;
+}
+static void ltt_const(hrg_ltt* L, const double* q) {
+  memset(L, 0, sizeof *L);
+  for (int j = 0; j < NARM; j++) { L->q0[j] = q[j]; L->qT[j] = q[j]; }
+}
+/* state of joint j at trajectory time s: q, q', q'' (derivatives w.r.t. s) */
+static void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double* a) {
+  double qq = L->q0[j], vv = L->v0[j], aa = L->a0[j], t = s;
+  if (t < 0) t = 0;
+  for (int i = 0; i < HRG_LTT_NSEG; i++) {
+    double d = L->dur[j][i], jj = L->jerk[j][i];
+    if (t < d) {
+      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *v = vv + aa * t + 0.5 * jj * t * t;
+      *a = aa + jj * t;
+      return;
+    }
+    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    vv += aa * d + 0.5 * jj * d * d;
+    aa += jj * d;
+    t -= d;
+  }
+  *q = L->qT[j]; *v = 0; *a = 0;
+}
+
+/* =============================================================================================== path
+ * Three-phase jerk-limited profile of the path velocity from (v0,a0) to (ve,0): the fail-safe (ve=0) and
+ * recovery (ve=1) manoeuvres of the shield (sara-shield planSafetyShield; Beckert/Pereira/Althoff 2017). */
+static void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, double amax, double jmax) {
+  P->s0 = s0; P->v0 = v0; P->a0 = a0; P->k = 0;
+  for (int i = 0; i < 3; i++) { P->dur[i] = 0; P->jerk[i] = 0; }
+  if (fabs(v0 - ve) < 1e-12 && fabs(a0) < 1e-12) { P->v0 = ve; P->a0 = 0; return; }
+  double v_at = v0 + a0 * fabs(a0) / (2 * jmax);
+  double dir = ve >= v_at ? 1.0 : -1.0;
+  double A = dir * a0, dv = dir * (ve - v0);
+  double apk = amax > A ? amax : A;
+  double t1 = (apk - A) / jmax, t3 = apk / jmax;
+  double dv2 = dv - 0.5 * (A + apk) * t1 - 0.5 * apk * t3, t2;
+  if (dv2 >= 0) t2 = dv2 / apk;
+  else {
+    double r = 0.5 * A * A + jmax * dv;
+    apk = sqrt(r > 0 ? r : 0);
+    if (apk < A) apk = A;
+    t1 = (apk - A) / jmax; t2 = 0; t3 = apk / jmax;
+  }
+  P->dur[0] = t1; P->dur[1] = t2; P->dur[2] = t3;
+  P->jerk[0] = dir * jmax; P->jerk[1] = 0; P->jerk[2] = -dir * jmax;
+}
+static double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
+static void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
+  double ss = P->s0, vv = P->v0, aa = P->a0;
+  for (int i = 0; i < 3; i++) {
+    double d = P->dur[i], jj = P->jerk[i];
+    if (t < d) {
+      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *v = vv + aa * t + 0.5 * jj * t * t;
+      *a = aa + jj * t;
+      return;
+    }
+    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    vv += aa * d + 0.5 * jj * d * d;
+    aa += jj * d;
+    t -= d;
+  }
+  /* profile finished: hold the end velocity exactly */
+  *s = ss + ve * t; *v = ve; *a = 0;
+}
+
+/* =============================================================================================== shield
+ * SafetyShield.step / humanMeasurement / newLongTermTrajectory / getSafety as called from
+ * failsafe_controller.py:300,310,329-332,381 — restated after SURVEY.md B.3 and arXiv 2205.06311:
+ * candidate = one recovery step then fail-safe braking; robot reach capsules over the candidate; human reach
+ * capsules (ACC / VEL / POS models) over the braking time; safe iff some model is disjoint from the robot. */
+static void shield_arm_fk(const hrg_model_desc* m, const double* q6, double cp1[HRG_NSHIELD_RCAP][3], double cp2[HRG_NSHIELD_RCAP][3]) {
+  double q[NV];
+  robot_kin k;
+  for (int i = 0; i < NARM; i++) q[i] = q6[i];
+  for (int i = NARM; i < NV; i++) q[i] = 0;
+  robot_fk(m, q, &k);
+  for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+    int b = m->scap_body[c];
+    double t[3];
+    m3mulv(t, k.R[b], m->scap_p1[c]); v3add(cp1[c], k.p[b], t);
+    m3mulv(t, k.R[b], m->scap_p2[c]); v3add(cp2[c], k.p[b], t);
+  }
+}
+
+static void motion_at(const hrg_ltt* L, double s, double sv, double sa, double* q, double* v, double* a) {
+  for (int j = 0; j < NARM; j++) {
+    double qq, q1, q2;
+    ltt_eval(L, j, s, &qq, &q1, &q2);
+    q[j] = qq; v[j] = q1 * sv; a[j] = q1 * sa + q2 * sv * sv;
+  }
+}
+
+static void shield_reset(const hrg_model_desc* m, hrg_env_state* s, const double* q) {
+  ltt_const(&s->ltt, q);
+  path_plan(&s->safe_path, 0, 0, 0, 0, m->path_amax, m->path_jmax);
+  s->path_s = 0; s->path_v = 0; s->path_a = 0;
+  s->new_goal = 0; s->is_safe = 1; s->n_meas = 0;
+  for (int j = 0; j < NARM; j++) { s->des_q[j] = q[j]; s->des_v[j] = 0; s->des_a[j] = 0; s->new_goal_q[j] = q[j]; }
+  memset(s->meas_prev, 0, sizeof s->meas_prev);
+  s->meas_prev_t = 0;
+}
+
+/* human reach capsules for the horizon T; returns count; model id per capsule in mdl[] (0 ACC,1 VEL,2 POS) */
+static int human_reach(const hrg_model_desc* m, const double meas[HRG_NHJ][3], const double vel[HRG_NHJ][3], int have_vel, double T,
+                       double caps[HRG_NHCAP_MAX][7], int* mdl) {
+  int n = 0;
+  double Td = T + m->delay;
+  for (int b = 0; b < m->n_bodypart; b++) { /* ACC */
+    int i1 = m->bp_joint[b][0], i2 = m->bp_joint[b][1];
+    double r1 = v3norm(vel[i1]) * Td * 0.5 + 0.5 * m->bp_amax[b] * Td * Td + m->meas_err_pos + m->meas_err_vel * Td;
+    double r2 = v3norm(vel[i2]) * Td * 0.5 + 0.5 * m->bp_amax[b] * Td * Td + m->meas_err_pos + m->meas_err_vel * Td;
+    v3madd(caps[n], meas[i1], vel[i1], 0.5 * Td);
+    v3madd(caps[n] + 3, meas[i2], vel[i2], 0.5 * Td);
+    caps[n][6] = (r1 > r2 ? r1 : r2) + m->bp_thickness[b];
+    mdl[n++] = 0;
+  }
+  for (int b = 0; b < m->n_bodypart; b++) { /* VEL */
+    int i1 = m->bp_joint[b][0], i2 = m->bp_joint[b][1];
+    v3cpy(caps[n], meas[i1]);
+    v3cpy(caps[n] + 3, meas[i2]);
+    caps[n][6] = m->bp_thickness[b] + m->meas_err_pos + m->bp_vmax[b] * Td;
+    mdl[n++] = 1;
+  }
+  for (int e = 0; e < m->n_extremity; e++) { /* POS: ball at the proximal joint */
+    int i = m->ext_joint[e];
+    v3cpy(caps[n], meas[i]);
+    v3cpy(caps[n] + 3, meas[i]);
+    caps[n][6] = m->ext_length[e] + m->ext_thickness[e] + m->meas_err_pos + m->ext_vmax[e] * Td;
+    mdl[n++] = 2;
+  }
+  for (int b = 0; b < m->n_bodypart; b++) { /* POS: non-extremity parts keep their VEL capsule */
+    if (!m->bp_in_pos[b]) continue;
+    int i1 = m->bp_joint[b][0], i2 = m->bp_joint[b][1];
+    v3cpy(caps[n], meas[i1]);
+    v3cpy(caps[n] + 3, meas[i2]);
+    caps[n][6] = m->bp_thickness[b] + m->meas_err_pos + m->bp_vmax[b] * Td;
+    mdl[n++] = 2;
+  }
+  (void)have_vel;
+  return n;
+}
+
+static void shield_step(hrgo_batch* B, int e, double t) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  const double dt = m->timestep;
+  /* ---- humanMeasurement (failsafe_controller.py:302-310): finite-difference joint velocities ---- */
+  double vel[HRG_NHJ][3];
+  int have_vel = s->n_meas >= 1 && t > s->meas_prev_t;
+  for (int j = 0; j < HRG_NHJ; j++)
+    for (int a = 0; a < 3; a++) vel[j][a] = have_vel ? (s->human_site[j][a] - s->meas_prev[j][a]) / (t - s->meas_prev_t) : 0.0;
+  memcpy(s->meas_prev, s->human_site, sizeof s->meas_prev);
+  s->meas_prev_t = t;
+  if (s->n_meas < 2) s->n_meas++;
+  /* ---- current motion ---- */
+  double cq[NARM], cv[NARM], ca[NARM];
+  motion_at(&s->ltt, s->path_s, s->path_v, s->path_a, cq, cv, ca);
+  /* ---- new goal: plan a candidate long-term trajectory from the current motion ---- */
+  hrg_ltt cand;
+  int use_cand = 0;
+  if (s->new_goal) {
+    int plannable = 1;
+    for (int j = 0; j < NARM; j++) if (fabs(ca[j]) > m->a_max_ltt[j]) plannable = 0;
+    if (plannable) { ltt_plan(m, &cand, cq, cv, ca, s->new_goal_q); use_cand = 1; }
+  }
+  const hrg_ltt* L = use_cand ? &cand : &s->ltt;
+  double ps = use_cand ? 0.0 : s->path_s, pv = use_cand ? 1.0 : s->path_v, pa = use_cand ? 0.0 : s->path_a;
+  /* ---- candidate: one recovery step towards s'=1, then fail-safe brake to s'=0 ---- */
+  hrg_path rec, fs2;
+  double s1, v1, a1, se, ve_, ae;
+  path_plan(&rec, ps, pv, pa, 1.0, m->path_amax, m->path_jmax);
+  path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
+  path_plan(&fs2, s1, v1, a1, 0.0, m->path_amax, m->path_jmax);
+  double Tb = path_total(&fs2);
+  path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+  int safe = 1;
+  if (m->shield_type != HRG_SHIELD_OFF) {
+    /* robot reach over [current config, config at the end of the brake] */
+    double qe[NARM], d1, d2;
+    for (int j = 0; j < NARM; j++) ltt_eval(L, j, se, &qe[j], &d1, &d2);
+    double a1p[HRG_NSHIELD_RCAP][3], a2p[HRG_NSHIELD_RCAP][3], b1p[HRG_NSHIELD_RCAP][3], b2p[HRG_NSHIELD_RCAP][3];
+    shield_arm_fk(m, cq, a1p, a2p);
+    shield_arm_fk(m, qe, b1p, b2p);
+    double sdiff = se - ps;
+    double (*rc)[7] = B->rcaps[e];
+    for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+      double d[3], l1, l2;
+      v3sub(d, a1p[c], b1p[c]); l1 = v3norm(d);
+      v3sub(d, a2p[c], b2p[c]); l2 = v3norm(d);
+      for (int a = 0; a < 3; a++) { rc[c][a] = 0.5 * (a1p[c][a] + b1p[c][a]); rc[c][3 + a] = 0.5 * (a2p[c][a] + b2p[c][a]); }
+      rc[c][6] = m->scap_r[c] + m->secure_radius + 0.5 * (l1 > l2 ? l1 : l2) + m->scap_alpha[c] * sdiff * sdiff / 8.0;
+    }
+    /* human reach over the braking time */
+    int mdl[HRG_NHCAP_MAX];
+    double (*hc)[7] = B->hcaps[e];
+    int nh = human_reach(m, (const double(*)[3])s->human_site, (const double(*)[3])vel, have_vel, dt + Tb, hc, mdl);
+    B->n_hcaps[e] = nh;
+    int hit[3] = {0, 0, 0};
+    if (!have_vel) hit[0] = 1; /* no velocity estimate yet: the ACC model cannot certify */
+    for (int k = 0; k < nh; k++)
+      for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+        double c1[3], c2[3], rr = rc[c][6] + hc[k][6];
+        if (seg_seg(rc[c], rc[c] + 3, hc[k], hc[k] + 3, c1, c2) < rr * rr) hit[mdl[k]] = 1;
+      }
+    safe = !(hit[0] && hit[1] && hit[2]);
+  }
+  if (safe) {
+    if (use_cand) { s->ltt = cand; s->new_goal = 0; }
+    s->path_s = s1; s->path_v = v1; s->path_a = a1;
+    s->safe_path = fs2;
+  } else {
+    s->safe_path.k += 1.0;
+    path_eval(&s->safe_path, s->safe_path.k * dt, 0.0, &s->path_s, &s->path_v, &s->path_a);
+  }
+  s->is_safe = safe;
+  motion_at(&s->ltt, s->path_s, s->path_v, s->path_a, s->des_q, s->des_v, s->des_a);
+}
+
+/* =============================================================================================== contacts
+ * Stand-in for mj_collision on this model: every collision geom is the bounding capsule of the reference
+ * mesh (tools/compile_model.py), the table is its top face with the slab footprint, the floor a plane.
+ * geom ids: robot capsules 0..9, human bodies 10..33, table 34, floor 35.  Contacts are emitted in pair
+ * enumeration order (robot-robot, robot-human, robot-table, robot-floor), which is the order
+ * HumanEnv._collision_detection walks (human_env.py:1094). */
+#define GEOM_HUMAN0 HRG_NRCAP
+#define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
+#define GEOM_FLOOR (GEOM_TABLE + 1)
+typedef struct {
+  int g1, g2, b1, b2; /* geom ids, robot body of each side (-1 static, -2 not robot) */
+  double dist, n[3], pos[3];
+} contact_t;
+
+static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, contact_t* con) {
+  double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3];
+  double Rb[9];
+  quat2mat(Rb, m->base_quat);
+  for (int c = 0; c < HRG_NRCAP; c++) {
+    int b = m->rcap_body[c];
+    const double* R = b < 0 ? Rb : k->R[b];
+    const double* p = b < 0 ? m->base_pos : k->p[b];
+    double t[3];
+    m3mulv(t, R, m->rcap_p1[c]); v3add(rp1[c], p, t);
+    m3mulv(t, R, m->rcap_p2[c]); v3add(rp2[c], p, t);
+  }
+  int n = 0;
+#define EMIT(G1, G2, B1, B2, DIST, NRM, POS) \
+  do { if (n < HRG_NCON_MAX) { con[n].g1 = G1; con[n].g2 = G2; con[n].b1 = B1; con[n].b2 = B2; con[n].dist = DIST; v3cpy(con[n].n, NRM); v3cpy(con[n].pos, POS); n++; } } while (0)
+  for (int i = 0; i < HRG_NRCAP; i++)
+    for (int j = i + 1; j < HRG_NRCAP; j++) {
+      if (!((m->rcap_selfmask[i] >> j) & 1u)) continue;
+      double c1[3], c2[3], d[3], nn[3] = {0, 0, 1}, pos[3];
+      double d2 = seg_seg(rp1[i], rp2[i], rp1[j], rp2[j], c1, c2), dd = sqrt(d2), dist = dd - m->rcap_r[i] - m->rcap_r[j];
+      if (dist < 0) {
+        v3sub(d, c2, c1);
+        if (dd > 1e-12) v3scl(nn, d, 1.0 / dd);
+        v3madd(pos, c1, nn, m->rcap_r[i] + 0.5 * dist);
+        EMIT(i, j, m->rcap_body[i], m->rcap_body[j], dist, nn, pos);
+      }
+    }
+  for (int i = 0; i < HRG_NRCAP; i++)
+    for (int b = 0; b < HRG_NHB; b++) {
+      double c1[3], c2[3], d[3], nn[3] = {0, 0, 1}, pos[3];
+      double d2 = seg_seg(rp1[i], rp2[i], h->cap1[b], h->cap2[b], c1, c2), dd = sqrt(d2), dist = dd - m->rcap_r[i] - m->hcap_r[b];
+      if (dist < m->contact_margin_human) {
+        v3sub(d, c2, c1);
+        if (dd > 1e-12) v3scl(nn, d, 1.0 / dd);
+        v3madd(pos, c1, nn, m->rcap_r[i] + 0.5 * dist);
+        EMIT(i, GEOM_HUMAN0 + b, m->rcap_body[i], -2, dist, nn, pos);
+      }
+    }
+  for (int pl = 0; pl < 2; pl++)
+    for (int i = 0; i < HRG_NRCAP; i++) {
+      if (m->rcap_body[i] < 0) continue; /* welded to the world: static-static pairs are filtered */
+      for (int e = 0; e < 2; e++) {
+        const double* p = e ? rp2[i] : rp1[i];
+        double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - m->rcap_r[i] - z0;
+        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] + m->rcap_r[i] > z0 - 0.05)) continue;
+        if (dist < 0) {
+          double nn[3] = {0, 0, -1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
+          EMIT(i, pl ? GEOM_FLOOR : GEOM_TABLE, m->rcap_body[i], -1, dist, nn, pos);
+        }
+      }
+    }
+#undef EMIT
+  return n;
+}
+
+static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : HRG_GEOM_STATIC); }
+static int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; } /* utils/pairing.py:4-16 */
+
+/* HumanEnv._collision_detection + _on_*_detected, human_env.py:966-1123 */
+static void classify(const hrg_model_desc* m, const robot_kin* k, hrg_env_state* s, const contact_t* con, int ncon,
+                     const double rcap_center[HRG_NRCAP][3], int* has_collision, int* collision_type) {
+  int cur[HRG_NPREV_MAX], ncur = 0;
+  double tm = s->debounce_timer - m->timestep; /* human_env.py:1090 */
+  s->debounce_timer = tm > 0 ? tm : 0;
+  for (int c = 0; c < ncon; c++) {
+    int t1 = geom_class(con[c].g1), t2 = geom_class(con[c].g2);
+    if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
+    int h12 = cantor(con[c].g1, con[c].g2), h21 = cantor(con[c].g2, con[c].g1);
+    if (ncur + 2 <= HRG_NPREV_MAX) { cur[ncur++] = h12; cur[ncur++] = h21; }
+    int seen = 0;
+    for (int i = 0; i < s->n_prev; i++) if (s->prev_pairs[i] == h12) seen = 1;
+    if (seen) continue;
+    int rg = t1 == HRG_GEOM_ROBOT ? con[c].g1 : con[c].g2;
+    int ot = t1 == HRG_GEOM_ROBOT ? t2 : t1;
+    *has_collision = 1; /* human_env.py:1055 */
+    if (ot == HRG_GEOM_ROBOT) { *collision_type |= HRG_COL_ROBOT; s->n_collisions_robot++; }
+    else if (ot == HRG_GEOM_HUMAN) {
+      if (s->debounce_timer > 0) continue; /* human_env.py:981-983 */
+      s->debounce_timer = m->collision_debounce_delay;
+      double v[3];
+      robot_point_vel(k, m->rcap_body[rg], rcap_center[rg], v); /* geom_xvelp, human_env.py:1008 */
+      if (v3norm(v) <= m->safe_vel) { *collision_type |= HRG_COL_HUMAN; s->n_collisions_human++; }
+      else { *collision_type |= HRG_COL_HUMAN_CRIT; s->n_collisions_critical++; }
+    } else if (ot == HRG_GEOM_ALLOWED) { *collision_type |= HRG_COL_ALLOWED; }
+    else { *collision_type |= HRG_COL_STATIC; s->n_collisions_static++; }
+  }
+  s->n_prev = ncur;
+  for (int i = 0; i < ncur; i++) s->prev_pairs[i] = cur[i];
+}
+
+/* =============================================================================================== solver
+ * mj_step for the robot tree: unconstrained acceleration, soft constraints (friction loss, joint limits,
+ * pyramidal frictional contacts) solved by a primal Newton method with exact line search on MuJoCo's convex
+ * objective  1/2 (a-a0)' M (a-a0) + sum_i s_i(J_i a - aref_i), then semi-implicit Euler with implicit joint
+ * damping. */
+enum { ROW_FRICTION = 0, ROW_UNILATERAL = 1 };
+typedef struct {
+  int n;
+  int type[NEFC_MAX];
+  double J[NEFC_MAX][NV], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
+} efc_t;
+
+static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* imp, double* K, double* Bd) {
+  double d0 = m->solimp[0], dmax = m->solimp[1], width = m->solimp[2], mid = m->solimp[3], power = m->solimp[4];
+  double x = fabs(pos_minus_margin) / width, y;
+  if (x >= 1) y = 1;
+  else if (x <= 0) y = 0;
+  else if (x <= mid) y = pow(x / mid, power) * mid;
+  else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+  *imp = d0 + y * (dmax - d0);
+  double tc = m->solref[0], dr = m->solref[1];
+  if (tc < 2 * m->timestep) tc = 2 * m->timestep;
+  *K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+  *Bd = 2.0 / (dmax * tc);
+}
+
+static void efc_add(const hrg_model_desc* m, efc_t* E, const double* LM, const double* J, const double* qd, int type, double pos, double margin, double floss) {
+  if (E->n >= NEFC_MAX) return;
+  double x[NV], A = 0, vel = 0;
+  for (int i = 0; i < NV; i++) { x[i] = J[i]; vel += J[i] * qd[i]; }
+  chol_solve(LM, NV, x);
+  for (int i = 0; i < NV; i++) A += J[i] * x[i];
+  if (!(A > 1e-14)) return; /* row does not act on the robot tree */
+  double imp, K, Bd;
+  impedance(m, pos - margin, &imp, &K, &Bd);
+  int r = E->n++;
+  memcpy(E->J[r], J, sizeof(double) * NV);
+  E->type[r] = type;
+  E->aref[r] = -Bd * vel - K * imp * (pos - margin);
+  E->D[r] = 1.0 / ((1 - imp) / imp * A);
+  E->floss[r] = floss;
+}
+
+/* cost pieces of one row at x = J a - aref: value, first and second derivative */
+static void row_cost(const efc_t* E, int r, double x, double* c, double* g, double* h) {
+  double D = E->D[r];
+  if (E->type[r] == ROW_UNILATERAL) {
+    if (x < 0) { *c = 0.5 * D * x * x; *g = D * x; *h = D; } else { *c = 0; *g = 0; *h = 0; }
+  } else {
+    double f = E->floss[r], lim = f / D;
+    if (x <= -lim) { *c = f * (-x - 0.5 * lim); *g = -f; *h = 0; }
+    else if (x >= lim) { *c = f * (x - 0.5 * lim); *g = f; *h = 0; }
+    else { *c = 0.5 * D * x * x; *g = D * x; *h = D; }
+  }
+}
+
+static void solve(const hrg_model_desc* m, const double* M, const double* a0, const efc_t* E, double* a) {
+  /* a: in = warm start, out = solution */
+  double Ma0[NV];
+  for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a0[j]; Ma0[i] = t; }
+  if (E->n == 0) { memcpy(a, a0, sizeof(double) * NV); return; }
+  /* pick the better of warm start and unconstrained acceleration */
+  double cost_ws = 0, cost_a0 = 0;
+  for (int pass = 0; pass < 2; pass++) {
+    const double* x = pass ? a0 : a;
+    double c = 0;
+    for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * (x[j] - a0[j]); c += 0.5 * (x[i] - a0[i]) * t; }
+    for (int r = 0; r < E->n; r++) {
+      double y = -E->aref[r], cc, g, h;
+      for (int i = 0; i < NV; i++) y += E->J[r][i] * x[i];
+      row_cost(E, r, y, &cc, &g, &h);
+      c += cc;
+    }
+    if (pass) cost_a0 = c; else cost_ws = c;
+  }
+  if (!(cost_ws < cost_a0)) memcpy(a, a0, sizeof(double) * NV);
+  for (int it = 0; it < m->solver_iters; it++) {
+    double x[NEFC_MAX], g[NV], H[NV * NV];
+    for (int i = 0; i < NV; i++) { double t = -Ma0[i]; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a[j]; g[i] = t; }
+    memcpy(H, M, sizeof H);
+    for (int r = 0; r < E->n; r++) {
+      double y = -E->aref[r], cc, gg, hh;
+      for (int i = 0; i < NV; i++) y += E->J[r][i] * a[i];
+      x[r] = y;
+      row_cost(E, r, y, &cc, &gg, &hh);
+      for (int i = 0; i < NV; i++) g[i] += E->J[r][i] * gg;
+      if (hh != 0) for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) H[i * NV + j] += hh * E->J[r][i] * E->J[r][j];
+    }
+    double gn = 0, sc = 0;
+    for (int i = 0; i < NV; i++) { gn += g[i] * g[i]; sc += Ma0[i] * Ma0[i]; }
+    if (sqrt(gn) <= m->solver_tol * (1.0 + sqrt(sc))) break;
+    double d[NV], Md[NV], p[NEFC_MAX];
+    for (int i = 0; i < NV; i++) d[i] = -g[i];
+    if (!chol(H, NV)) break;
+    chol_solve(H, NV, d);
+    for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * d[j]; Md[i] = t; }
+    for (int r = 0; r < E->n; r++) { double t = 0; for (int i = 0; i < NV; i++) t += E->J[r][i] * d[i]; p[r] = t; }
+    /* exact line search on phi(al) = cost(a + al d): safeguarded Newton on phi' */
+    double dMd = 0, gd0 = 0;
+    for (int i = 0; i < NV; i++) { dMd += d[i] * Md[i]; double t = -Ma0[i]; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a[j]; gd0 += d[i] * t; }
+    double al = 1.0, lo = 0, hi = -1, d1_0 = 0;
+    for (int ls = 0; ls < 40; ls++) {
+      double d1 = gd0 + al * dMd, d2 = dMd;
+      for (int r = 0; r < E->n; r++) {
+        double cc, gg, hh;
+        row_cost(E, r, x[r] + al * p[r], &cc, &gg, &hh);
+        d1 += gg * p[r];
+        d2 += hh * p[r] * p[r];
+      }
+      if (ls == 0) { /* also need phi'(0) for the stopping scale */
+        d1_0 = gd0;
+        for (int r = 0; r < E->n; r++) { double cc, gg, hh; row_cost(E, r, x[r], &cc, &gg, &hh); d1_0 += gg * p[r]; }
+      }
+      if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+      if (d1 < 0) lo = al; else hi = al;
+      double nx = al - d1 / d2;
+      if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
+      else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+      al = nx;
+    }
+    for (int i = 0; i < NV; i++) a[i] += al * d[i];
+  }
+}
+
+/* =============================================================================================== env */
+static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const double* goal, float* obs) {
+  /* object-state: vec/dist eef -> {L hand, R hand, head} (human_env.py:1536-1590, reach_human_env.py:637-640),
+   * then goal_difference (reach_human_env.py:649-651) */
+  int sites[3] = {m->site_lhand, m->site_rhand, m->site_head};
+  for (int i = 0; i < 3; i++) {
+    double d[3];
+    v3sub(d, s->human_site[sites[i]], s->eef_pos);
+    obs[4 * i] = (float)d[0]; obs[4 * i + 1] = (float)d[1]; obs[4 * i + 2] = (float)d[2];
+    obs[4 * i + 3] = (float)v3norm(d);
+  }
+  for (int j = 0; j < NARM; j++) obs[12 + j] = (float)(goal[j] - s->qpos[j]);
+}
+
+static void goal_of(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, int idx, double* g) {
+  /* ReachHuman._sample_valid_pos without the pinocchio check (reach_human_env.py:525-548, else branch) */
+  const hrg_model_desc* m = &B->m;
+  for (int j = 0; j < NARM; j++) {
+    double u = rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_GOAL, (uint64_t)(idx * NARM + j));
+    g[j] = m->qpos_limits[0][j] + (m->qpos_limits[1][j] - m->qpos_limits[0][j]) * u;
+  }
+}
+
+static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
+  double t[3];
+  m3mulv(t, k->R[NARM - 1], m->eef_pos);
+  v3add(eef, k->p[NARM - 1], t);
+}
+
+static void env_reset(hrgo_batch* B, int e, float* obs) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  int64_t gid = B->env_id0 + e;
+  int episode = s->episode + 1;
+  memset(s, 0, sizeof *s);
+  s->episode = episode;
+  /* robot.reset: init_qpos + N(0, 0.02^2) (robosuite "default" initialization_noise) */
+  for (int j = 0; j < NARM; j++) s->qpos[j] = m->init_qpos[j] + m->init_noise * rng_gauss(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)j);
+  for (int j = 0; j < HRG_NFINGER; j++) s->qpos[NARM + j] = m->finger_init_qpos[j];
+  /* human placement: x, y, yaw uniform in +-human_rand (human_env.py:1376-1387, 1650-1656) */
+  double ux = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 0), uy = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 1),
+         uz = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 2);
+  s->human_pos_offset[0] = m->base_human_pos_offset[0] + (2 * ux - 1) * m->human_rand[0];
+  s->human_pos_offset[1] = m->base_human_pos_offset[1] + (2 * uy - 1) * m->human_rand[1];
+  s->human_pos_offset[2] = m->base_human_pos_offset[2];
+  double yaw = (2 * uz - 1) * m->human_rand[2];
+  s->human_rot_offset[0] = cos(0.5 * yaw); s->human_rot_offset[1] = 0; s->human_rot_offset[2] = 0; s->human_rot_offset[3] = sin(0.5 * yaw);
+  s->animation_time = -1; /* human_env.py:1644 */
+  /* human pose before the first _control_human: qpos0 at the mocap body's default pose (origin, identity) */
+  {
+    human_kin h;
+    double zero[HRG_NHQ], p0[3] = {0, 0, 0}, q0[4] = {1, 0, 0, 0};
+    memset(zero, 0, sizeof zero);
+    human_fk(m, p0, q0, zero, &h, s->human_site);
+  }
+  robot_kin k;
+  robot_fk(m, s->qpos, &k);
+  eef_of(m, &k, s->eef_pos);
+  shield_reset(m, s, s->qpos); /* FailsafeController.reset, failsafe_controller.py:204-250 */
+  for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
+  if (obs) { double g[NARM]; goal_of(B, gid, s, 0, g); compute_obs(m, s, g, obs); }
+}
+
+static void env_step(hrgo_batch* B, int e, const double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  int64_t gid = B->env_id0 + e;
+  const double h = m->timestep;
+  s->timestep += 1; /* human_env.py:490 */
+  int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
+  robot_kin k;
+  human_kin hk;
+  double M[NV * NV], bias[NV];
+  for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
+    /* ---- sim.forward() #1 (human_env.py:504): positions, M, bias at the current state ---- */
+    robot_fk(m, s->qpos, &k);
+    robot_crba(m, &k, M);
+    robot_bias(m, &k, s->qvel, bias);
+    /* ---- controller (SingleArm.control -> set_goal / run_controller) ---- */
+    if (cyc == 0) { /* policy step: failsafe_controller.py:252-300 */
+      for (int i = 0; i < NARM; i++) for (int j = 0; j < NARM; j++) s->mass_matrix[i * NARM + j] = M[i * NV + j];
+      double scale = fabs(m->act_out_max - m->act_out_min) / fabs(m->act_in_max - m->act_in_min);
+      double otr = 0.5 * (m->act_out_max + m->act_out_min), itr = 0.5 * (m->act_in_max + m->act_in_min);
+      for (int j = 0; j < NARM; j++) {
+        double a = clampd(action[j], m->act_in_min, m->act_in_max);
+        double g = s->qpos[j] + ((a - itr) * scale + otr);
+        s->goal_qpos[j] = clampd(g, m->qpos_limits[0][j], m->qpos_limits[1][j]);
+        s->new_goal_q[j] = s->goal_qpos[j];
+      }
+      s->new_goal = 1; /* newLongTermTrajectory, failsafe_controller.py:300 */
+    }
+    shield_step(B, e, s->time); /* humanMeasurement + SafetyShield.step, human_env.py:505, failsafe_controller.py:329 */
+    double ctrl[NV];
+    for (int i = 0; i < NARM; i++) { /* failsafe_controller.py:356-369 */
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += s->mass_matrix[i * NARM + j] * (m->kp * (s->des_q[j] - s->qpos[j]) + m->kd * (s->des_v[j] - s->qvel[j]) + s->des_a[j]);
+      s->torque[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
+      ctrl[i] = s->torque[i];
+    }
+    { /* RethinkGripper.format_action + actuator ctrl range mapping */
+      double a = action[NARM], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
+      s->grip_action = clampd(s->grip_action + m->gripper_speed * sg, -1.0, 1.0);
+      for (int f = 0; f < HRG_NFINGER; f++) {
+        double lo = m->finger_ctrlrange[f][0], hi = m->finger_ctrlrange[f][1];
+        ctrl[NARM + f] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (f == 0 ? s->grip_action : -s->grip_action);
+      }
+    }
+    if (!failsafe_intervention && !s->is_safe) { failsafe_intervention = 1; s->failsafe_interventions++; } /* human_env.py:509-513 */
+    /* ---- _control_human + sim.forward() #2 (human_env.py:516-519) ---- */
+    double mp[3], mq[4];
+    const double* qh;
+    human_control(B, gid, s, mp, mq, &qh);
+    human_fk(m, mp, mq, qh, &hk, s->human_site);
+    /* ---- contacts + bookkeeping (human_env.py:522) ---- */
+    contact_t con[HRG_NCON_MAX];
+    int ncon = collide(m, &k, &hk, con);
+    double rc[HRG_NRCAP][3], Rb[9];
+    quat2mat(Rb, m->base_quat);
+    for (int c = 0; c < HRG_NRCAP; c++) {
+      int b = m->rcap_body[c];
+      double t[3], mid[3];
+      for (int a = 0; a < 3; a++) mid[a] = 0.5 * (m->rcap_p1[c][a] + m->rcap_p2[c][a]);
+      m3mulv(t, b < 0 ? Rb : k.R[b], mid);
+      v3add(rc[c], b < 0 ? m->base_pos : k.p[b], t);
+    }
+    classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
+    s->ncon = ncon;
+    for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
+    /* ---- sim.step() (human_env.py:523): smooth acceleration, constraints, Euler ---- */
+    double LM[NV * NV], a0[NV], frc[NV];
+    memcpy(LM, M, sizeof LM);
+    if (!chol(LM, NV)) { crash = 1; break; }
+    for (int i = 0; i < NV; i++) {
+      double act = ctrl[i];
+      if (i >= NARM) act = clampd(m->finger_kp * (ctrl[i] - s->qpos[i]), m->finger_forcerange[0], m->finger_forcerange[1]);
+      frc[i] = act - m->jnt_damping[i] * s->qvel[i] - bias[i];
+      a0[i] = frc[i];
+    }
+    chol_solve(LM, NV, a0);
+    efc_t E;
+    E.n = 0;
+    for (int i = 0; i < NV; i++) /* friction loss rows */
+      if (m->jnt_frictionloss[i] > 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, LM, J, s->qvel, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i]); }
+    for (int i = 0; i < NV; i++) { /* joint limit rows */
+      double dlo = s->qpos[i] - m->jnt_range[i][0], dhi = m->jnt_range[i][1] - s->qpos[i];
+      if (dlo < 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, dlo, 0, 0); }
+      if (dhi < 0) { double J[NV] = {0}; J[i] = -1; efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, dhi, 0, 0); }
+    }
+    for (int c = 0; c < ncon && c < HRG_NCON_DYN; c++) { /* pyramidal frictional contact rows */
+      const double* n = con[c].n;
+      double t1[3], t2[3], e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+      v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+      v3scl(t1, t1, 1.0 / v3norm(t1));
+      v3cross(t2, n, t1);
+      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      for (int d = 0; d < 4; d++) {
+        double dir[3], J[NV] = {0};
+        const double* tt = d < 2 ? t1 : t2;
+        double sg = (d & 1) ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m->friction_static * tt[a];
+        /* separation velocity along n (from geom1 to geom2): v2 - v1 */
+        if (con[c].b1 >= 0) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
+        if (con[c].b2 >= 0) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
+        efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, con[c].dist, margin, 0);
+      }
+    }
+    double qacc[NV];
+    memcpy(qacc, s->qacc_warmstart, sizeof qacc);
+    solve(m, M, a0, &E, qacc);
+    /* mj_checkAcc -> MujocoException handler (human_env.py:527-546) */
+    for (int i = 0; i < NV; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
+    if (crash) break;
+    memcpy(s->qacc_warmstart, qacc, sizeof qacc);
+    /* mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc */
+    double Mh[NV * NV], rhs[NV];
+    memcpy(Mh, M, sizeof Mh);
+    for (int i = 0; i < NV; i++) { Mh[i * NV + i] += h * m->jnt_damping[i]; double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * qacc[j]; rhs[i] = t; }
+    if (!chol(Mh, NV)) { crash = 1; break; }
+    chol_solve(Mh, NV, rhs);
+    for (int i = 0; i < NV; i++) { s->qvel[i] += h * rhs[i]; s->qpos[i] += h * s->qvel[i]; }
+    s->time += h;
+    eef_of(m, &k, s->eef_pos); /* site_xpos of the forward pass inside mj_step (pre-integration) */
+    s->low_level_time += 1; /* human_env.py:526 */
+  }
+  /* ---- observation, success, info, reward, done (human_env.py:561-581) ---- */
+  double goal[NARM];
+  goal_of(B, gid, s, s->goal_index, goal);
+  compute_obs(m, s, goal, term_obs);
+  double dist2 = 0;
+  for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
+  double dist = sqrt(dist2);
+  int goal_reached = !crash && dist <= m->goal_dist; /* reach_human_env.py:457-475 */
+  if (goal_reached) s->n_goal_reached++;
+  int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0; /* human_env.py:860-878 */
+  double r = goal_reached ? m->task_reward : -1.0; /* human_env.py:666-691 */
+  if (m->reward_shaping) r += 1.0 + (-0.1 * dist); /* human_env.py:650-651, reach_human_env.py:437-455 */
+  if (illegal) r += m->collision_reward;
+  r *= m->reward_scale;
+  int d = 0;
+  if (crash) { r += m->sim_crash_reward; d = 1; }
+  else {
+    if (m->done_at_collision && illegal) d = 1; /* human_env.py:835-858 */
+    if (m->done_at_success && goal_reached) d = 1;
+  }
+  int ncoll = s->n_collisions_static + s->n_collisions_robot + s->n_collisions_human + s->n_collisions_critical;
+  info[HRG_INFO_COLLISION] = has_collision;
+  info[HRG_INFO_COLLISION_TYPE] = collision_type;
+  info[HRG_INFO_N_COLLISIONS] = ncoll;
+  info[HRG_INFO_N_COLLISIONS_STATIC] = s->n_collisions_static;
+  info[HRG_INFO_N_COLLISIONS_ROBOT] = s->n_collisions_robot;
+  info[HRG_INFO_N_COLLISIONS_HUMAN] = s->n_collisions_human;
+  info[HRG_INFO_N_COLLISIONS_CRITICAL] = s->n_collisions_critical;
+  info[HRG_INFO_TIMEOUT] = s->timestep >= m->horizon;
+  info[HRG_INFO_FAILSAFE_INTERVENTIONS] = s->failsafe_interventions;
+  info[HRG_INFO_N_GOAL_REACHED] = s->n_goal_reached;
+  info[HRG_INFO_SIM_CRASH] = crash;
+  info[HRG_INFO_TRUNCATED] = 0;
+  if (goal_reached) s->goal_index = (s->goal_index + 1) % m->n_goals; /* reach_human_env.py:399-407 */
+  if (s->timestep >= m->horizon) { info[HRG_INFO_TRUNCATED] = !d; d = 1; } /* time_limit.py:40-43 */
+  *reward = (float)r;
+  *done = (uint8_t)d;
+  if (d) env_reset(B, e, obs); /* VecEnv auto-reset; terminal observation stays in term_obs */
+  else memcpy(obs, term_obs, sizeof(float) * HRG_OBS_DIM);
+}
+
+/* =============================================================================================== API */
+int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, hrgo_batch** out) {
+  hrgo_batch* B = (hrgo_batch*)calloc(1, sizeof *B);
+  B->m = *desc;
+  B->clips = *clips;
+  B->frames = (double*)malloc(sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames);
+  memcpy(B->frames, clips->frames, sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames);
+  B->clips.frames = B->frames;
+  B->n_envs = n_envs;
+  B->env_id0 = env_id0;
+  B->st = (hrg_env_state*)calloc((size_t)n_envs, sizeof(hrg_env_state));
+  B->rcaps = calloc((size_t)n_envs, sizeof *B->rcaps);
+  B->hcaps = calloc((size_t)n_envs, sizeof *B->hcaps);
+  B->n_hcaps = calloc((size_t)n_envs, sizeof(int32_t));
+  for (int e = 0; e < n_envs; e++) B->st[e].episode = -1;
+  *out = B;
+  return 0;
+}
+void hrgo_destroy(hrgo_batch* B) {
+  if (!B) return;
+  free(B->frames); free(B->st); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
+}
+int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
+  for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
+  return 0;
+}
+int hrgo_step(hrgo_batch* B, const double* actions, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+  for (int e = 0; e < B->n_envs; e++) {
+    float tmp[HRG_OBS_DIM];
+    env_step(B, e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : tmp,
+             reward + e, done + e, info + (size_t)e * HRG_INFO_DIM);
+  }
+  return 0;
+}
+/* step a sub-range only (CPU baseline workers) */
+int hrgo_step_range(hrgo_batch* B, int e0, int e1, const double* actions, float* obs, float* reward, uint8_t* done, int32_t* info) {
+  for (int e = e0; e < e1; e++) {
+    float tmp[HRG_OBS_DIM];
+    env_step(B, e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tmp, reward + e, done + e, info + (size_t)e * HRG_INFO_DIM);
+  }
+  return 0;
+}
+int hrgo_get_state(hrgo_batch* B, int e, void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_env_state)) return -1;
+  memcpy(buf, &B->st[e], bytes);
+  return 0;
+}
+int hrgo_set_state(hrgo_batch* B, int e, const void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_env_state)) return -1;
+  memcpy(&B->st[e], buf, bytes);
+  return 0;
+}
+size_t hrgo_state_bytes(void) { return sizeof(hrg_env_state); }
+size_t hrgo_desc_bytes(void) { return sizeof(hrg_model_desc); }
+int hrgo_contacts(hrgo_batch* B, int32_t* pairs, int32_t* ncon) {
+  for (int e = 0; e < B->n_envs; e++) {
+    ncon[e] = B->st[e].ncon;
+    memcpy(pairs + (size_t)e * HRG_NCON_MAX * 2, B->st[e].con_pairs, sizeof(int32_t) * HRG_NCON_MAX * 2);
+  }
+  return 0;
+}
+int hrgo_capsules(hrgo_batch* B, double* robot, double* human, int32_t* n_human) {
+  memcpy(robot, B->rcaps, sizeof(*B->rcaps) * (size_t)B->n_envs);
+  memcpy(human, B->hcaps, sizeof(*B->hcaps) * (size_t)B->n_envs);
+  memcpy(n_human, B->n_hcaps, sizeof(int32_t) * (size_t)B->n_envs);
+  return 0;
+}
+
+/* ---- unit-level taps used by tests/ (known-answer tests of the pieces) ---- */
+void hrgo_test_robot(const hrg_model_desc* m, const double* q, const double* qd, double* M, double* bias, double* eef) {
+  robot_kin k;
+  robot_fk(m, q, &k);
+  robot_crba(m, &k, M);
+  robot_bias(m, &k, qd, bias);
+  eef_of(m, &k, eef);
+}
+double hrgo_test_segseg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) { return seg_seg(p1, q1, p2, q2, c1, c2); }
+void hrgo_test_ltt(const hrg_model_desc* m, const double* q0, const double* v0, const double* a0, const double* goal, hrg_ltt* L) { ltt_plan(m, L, q0, v0, a0, goal); }
+void hrgo_test_ltt_eval(const hrg_ltt* L, int j, double s, double* out3) { ltt_eval(L, j, s, out3, out3 + 1, out3 + 2); }
+void hrgo_test_path(double s0, double v0, double a0, double ve, double amax, double jmax, double t, double* out4) {
+  hrg_path P;
+  path_plan(&P, s0, v0, a0, ve, amax, jmax);
+  path_eval(&P, t, ve, out4, out4 + 1, out4 + 2);
+  out4[3] = path_total(&P);
+}
+void hrgo_test_human_fk(const hrg_model_desc* m, const double* mp, const double* mq, const double* qh, double* sites, double* caps) {
+  human_kin h;
+  human_fk(m, mp, mq, qh, &h, (double(*)[3])sites);
+  for (int b = 0; b < HRG_NHB; b++) { memcpy(caps + 6 * b, h.cap1[b], 24); memcpy(caps + 6 * b + 3, h.cap2[b], 24); }
+}
+double hrgo_test_u01(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) { return rng_u01(seed, env, ep, stream, idx); }

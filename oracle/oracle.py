@@ -1,0 +1,106 @@
+"""ctypes wrapper of the CPU oracle (oracle/hrg_oracle.c).  TEST INFRASTRUCTURE ONLY — imported by tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg; never by the product package."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libhrg_oracle.so")
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "hrg_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+def load():
+    if not os.path.exists(_SO):
+        build()
+    lib = ctypes.CDLL(_SO)
+    lib.hrgo_state_bytes.restype = ctypes.c_size_t
+    lib.hrgo_desc_bytes.restype = ctypes.c_size_t
+    lib.hrgo_test_segseg.restype = ctypes.c_double
+    lib.hrgo_test_u01.restype = ctypes.c_double
+    lib.hrgo_test_u01.argtypes = [ctypes.c_uint64] * 5
+    lib.hrgo_test_path.argtypes = [ctypes.c_double] * 7 + [ctypes.c_void_p]
+    lib.hrgo_test_ltt_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    return lib
+
+
+def _p(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+class OracleBatch:
+    """Same surface as human_robot_gym_amd._lib.HipBatch, on numpy arrays."""
+
+    def __init__(self, desc, clips, n_envs, env_id0=0):
+        from human_robot_gym_amd._cstruct import CONST, EnvState
+        self.C = CONST
+        self.EnvState = EnvState
+        self.lib = load()
+        assert self.lib.hrgo_state_bytes() == ctypes.sizeof(EnvState)
+        assert self.lib.hrgo_desc_bytes() == ctypes.sizeof(type(desc))
+        self.n = n_envs
+        self._clips = clips
+        self._table = clips.table()
+        self.h = ctypes.c_void_p()
+        rc = self.lib.hrgo_create(ctypes.byref(desc), ctypes.byref(self._table), ctypes.c_int32(n_envs), ctypes.c_int64(env_id0), ctypes.byref(self.h))
+        assert rc == 0
+        C = CONST
+        self.obs = np.zeros((n_envs, C["HRG_OBS_DIM"]), np.float32)
+        self.term_obs = np.zeros((n_envs, C["HRG_OBS_DIM"]), np.float32)
+        self.reward = np.zeros(n_envs, np.float32)
+        self.done = np.zeros(n_envs, np.uint8)
+        self.info = np.zeros((n_envs, C["HRG_INFO_DIM"]), np.int32)
+
+    def reset(self, mask=None):
+        m = None if mask is None else np.ascontiguousarray(mask, np.uint8)
+        self.lib.hrgo_reset(self.h, None if m is None else _p(m), _p(self.obs))
+        return self.obs.copy()
+
+    def step(self, actions):
+        a = np.ascontiguousarray(actions, np.float64)
+        assert a.shape == (self.n, self.C["HRG_ACT_DIM"])
+        self.lib.hrgo_step(self.h, _p(a), _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.done), _p(self.info))
+        return self.obs.copy(), self.reward.copy(), self.done.copy(), self.info.copy()
+
+    def step_range(self, e0, e1, actions):
+        a = np.ascontiguousarray(actions, np.float64)
+        self.lib.hrgo_step_range(self.h, ctypes.c_int(e0), ctypes.c_int(e1), _p(a), _p(self.obs), _p(self.reward), _p(self.done), _p(self.info))
+
+    def get_state(self, e):
+        s = self.EnvState()
+        assert self.lib.hrgo_get_state(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+        return s
+
+    def set_state(self, e, s):
+        assert self.lib.hrgo_set_state(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+
+    def contacts(self):
+        pairs = np.zeros((self.n, self.C["HRG_NCON_MAX"], 2), np.int32)
+        ncon = np.zeros(self.n, np.int32)
+        self.lib.hrgo_contacts(self.h, _p(pairs), _p(ncon))
+        return pairs, ncon
+
+    def capsules(self):
+        r = np.zeros((self.n, self.C["HRG_NSHIELD_RCAP"], 7))
+        h = np.zeros((self.n, self.C["HRG_NHCAP_MAX"], 7))
+        nh = np.zeros(self.n, np.int32)
+        self.lib.hrgo_capsules(self.h, _p(r), _p(h), _p(nh))
+        return r, h, nh
+
+    def close(self):
+        if self.h:
+            self.lib.hrgo_destroy(self.h)
+            self.h = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

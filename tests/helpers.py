@@ -1,0 +1,48 @@
+"""Shared helpers for the parity tests (oracle = checker, HIP library = unit under test)."""
+import ctypes
+
+import numpy as np
+
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd._cstruct import CONST, struct_to_dict
+
+# tolerance stated by BASELINE.json north_star: qpos/obs within 1e-5 relative
+RTOL = 1e-5
+ATOL = 1e-7
+
+
+def make_pair(n_envs, env_kwargs=None, n_clips=3, clip_seed=0, env_id0=0, clips=None):
+    """(OracleBatch, HipBatch) on identical model / clips / seeds."""
+    from oracle.oracle import OracleBatch
+    from human_robot_gym_amd._lib import HipBatch
+    clips = clips or hrg.synthetic_clips(n_clips, seed=clip_seed, min_frames=300, max_frames=600)
+    d1 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    d2 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    return OracleBatch(d1, clips, n_envs, env_id0), HipBatch(d2, clips, n_envs, env_id0)
+
+
+def flat_state(s):
+    """hrg_env_state -> (float vector, int vector) for comparisons."""
+    d = struct_to_dict(s)
+    fl, it = [], []
+
+    def walk(x, isint):
+        if isinstance(x, dict):
+            for k, v in x.items():
+                walk(v, isint)
+        elif isinstance(x, list):
+            for v in x:
+                walk(v, isint)
+        elif isinstance(x, float):
+            fl.append(x)
+        else:
+            it.append(int(x))
+    walk(d, False)
+    return np.array(fl), np.array(it)
+
+
+def assert_state_close(so, sg, what=""):
+    fo, io = flat_state(so)
+    fg, ig = flat_state(sg)
+    np.testing.assert_array_equal(io, ig, err_msg=f"integer state differs {what}")
+    np.testing.assert_allclose(fg, fo, rtol=RTOL, atol=ATOL, err_msg=f"float state differs {what}")
