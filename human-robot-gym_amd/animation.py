@@ -68,7 +68,7 @@ class ClipSet:
         return t
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0):
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -93,8 +93,11 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         anim["Pelvis_quat"] = np.stack([np.zeros(n), np.sin(yaw / 2), np.zeros(n), np.cos(yaw / 2)], 1)  # about Y (up)
         for name in order:
             sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else 0.3  # convert_bvh.py:55-72 None joints
-            anim[name] = np.clip(band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.zeros(n)
-        info = {"position_offset": [0.0, 0.0, 0.0], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
+            mean = {"L_Shoulder_z": -1.1, "R_Shoulder_z": 1.1}.get(name, 0.0)  # arms hang down instead of the T-pose
+            anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.zeros(n)
+        # the clip's info file places the human at the table edge in front of the robot: BVH +z maps to world +x
+        # under human_base_quat (human_env.py:373), so 1.2 m along z = 1.2 m in front of the robot base
+        info = {"position_offset": [0.0, 0.0, stand_off], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
         clips.append((anim, info))
     return ClipSet(clips)
 

@@ -216,7 +216,7 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
   L->q0[j] = q0; L->v0[j] = v0; L->a0[j] = a0; L->qT[j] = goal;
   int n = 0;
   double q = q0, v = v0;
-  if (a0 != 0) {
+  if (fabs(a0) > 1e-9) { /* below that the ramp is a no-op (and the sign of rounding noise must not matter) */
     double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
     dur[n] = t; jerk[n] = jj; n++;
     q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
@@ -225,7 +225,7 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
   double D = goal - q;
   double dstop = 0.5 * v * scurve_time(v, amax, jmax);
   double sg = (D - dstop) >= 0 ? 1.0 : -1.0;
-  if (sg * v < 0) {
+  if (sg * v < -1e-9) {
     scurve(v, 0, amax, jmax, dur + n, jerk + n);
     D -= dstop;
     v = 0;

@@ -64,11 +64,11 @@ DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon
   for (int i = 0; i < NV; i++) J[i] = 0;
   int type = 1;
   bool cand = false;
-  double pos = 0, margin = 0, floss = 0;
+  double pos = 0, margin = 0, floss = 0, diag = 0;
   const int r = lane;
   if (r < NV) {
     if (m.jnt_frictionloss[r] > 0) {
-      cand = true; type = 0; floss = m.jnt_frictionloss[r];
+      cand = true; type = 0; floss = m.jnt_frictionloss[r]; diag = m.dof_invweight0[r];
 #pragma unroll
       for (int i = 0; i < NV; i++) J[i] = (i == r) ? 1.0 : 0.0;
     }
@@ -76,7 +76,7 @@ DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon
     const int k = r - 8, dof = k >> 1, side = k & 1;
     const double dist = side ? m.jnt_range[dof][1] - s.qpos[dof] : s.qpos[dof] - m.jnt_range[dof][0];
     if (dist < 0) {
-      cand = true; pos = dist;
+      cand = true; pos = dist; diag = m.dof_invweight0[dof];
 #pragma unroll
       for (int i = 0; i < NV; i++) J[i] = (i == dof) ? (side ? -1.0 : 1.0) : 0.0;
     }
@@ -97,6 +97,7 @@ DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon
       for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * tt[a];
       pos = cc.dist;
       margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+      diag = ((cc.b1 >= 0 ? m.body_invweight0[cc.b1] : 0.0) + (cc.b2 >= 0 ? m.body_invweight0[cc.b2] : 0.0)) * (1.0 + m.friction_static * m.friction_static);
       const int am1 = cc.b1 >= 0 ? dm->anc_mask[cc.b1] : 0, am2 = cc.b2 >= 0 ? dm->anc_mask[cc.b2] : 0;
 #pragma unroll
       for (int i = 0; i < NV; i++) {
@@ -114,32 +115,15 @@ DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon
   double aref = 0, D = 0;
   bool active = false;
   {
-    double x[NV], A = 0, vel = 0;
+    double vel = 0, nz = 0;
 #pragma unroll
-    for (int i = 0; i < NV; i++) { x[i] = J[i]; vel += J[i] * s.qvel[i]; }
-    // per-lane triangular solves against the shared factor
-#pragma unroll
-    for (int i = 0; i < NV; i++) {
-      double t = x[i];
-#pragma unroll
-      for (int k = 0; k < i; k++) t -= L.LM[i * NV + k] * x[k];
-      x[i] = t / L.LM[i * NV + i];
-    }
-#pragma unroll
-    for (int i = NV - 1; i >= 0; i--) {
-      double t = x[i];
-#pragma unroll
-      for (int k = i + 1; k < NV; k++) t -= L.LM[k * NV + i] * x[k];
-      x[i] = t / L.LM[i * NV + i];
-    }
-#pragma unroll
-    for (int i = 0; i < NV; i++) A += J[i] * x[i];
-    active = cand && A > 1e-14;
+    for (int i = 0; i < NV; i++) { vel += J[i] * s.qvel[i]; nz += fabs(J[i]); }
+    active = cand && nz > 0 && diag > 0;
     if (active) {
       double imp, K, Bd;
       impedance(m, pos - margin, &imp, &K, &Bd);
       aref = -Bd * vel - K * imp * (pos - margin);
-      D = 1.0 / ((1 - imp) / imp * A);
+      D = 1.0 / ((1 - imp) / imp * diag);
     }
   }
 #pragma unroll

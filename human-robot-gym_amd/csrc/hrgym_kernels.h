@@ -455,7 +455,7 @@ DI void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out
         const double* p = &L.rcapw[i][3 * en];
         const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - m.rcap_r[i] - z0;
         bool ok = true;
-        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] + m.rcap_r[i] > z0 - 0.05;
+        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.025;  // end point above the mid-plane of the 0.05 m slab
         if (ok && dist < 0) {
           hit = true;
           v3set(c.n, 0, 0, -1);

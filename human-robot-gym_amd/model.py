@@ -265,6 +265,29 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
                 continue
             mask |= 1 << j
         d.rcap_selfmask[i] = mask
+    # MuJoCo's constant inverse-weight approximations at qpos0 (mj_setM0 / set0): used for constraint regularisation
+    R0, p0 = robot_fk_numpy(d, np.zeros(NV))
+    Jv, Jw = np.zeros((NV, 3, NV)), np.zeros((NV, 3, NV))
+    M0 = np.zeros((NV, NV))
+    for b in range(NV):
+        com = p0[b] + R0[b] @ np.asarray(d.body_com[b][:])
+        k = b
+        while k >= 0:
+            ax = R0[k] @ np.asarray(d.jnt_axis[k][:])
+            if d.jnt_type[k] == 0:
+                Jw[b][:, k] = ax
+                Jv[b][:, k] = np.cross(ax, com - p0[k])
+            else:
+                Jv[b][:, k] = ax
+            k = d.body_parent[k]
+        I = np.asarray(d.body_inertia[b][:])
+        Ib = np.array([[I[0], I[3], I[4]], [I[3], I[1], I[5]], [I[4], I[5], I[2]]])
+        M0 += d.body_mass[b] * Jv[b].T @ Jv[b] + Jw[b].T @ (R0[b] @ Ib @ R0[b].T) @ Jw[b]
+    M0 += np.diag([d.jnt_armature[i] for i in range(NV)])
+    M0inv = np.linalg.inv(M0)
+    for i in range(NV):
+        d.dof_invweight0[i] = float(M0inv[i, i])
+        d.body_invweight0[i] = float(np.trace(Jv[i] @ M0inv @ Jv[i].T) / 3.0)
     # ---- human
     HB = A["human"]["bodies"]
     names = [b["name"] for b in HB]

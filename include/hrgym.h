@@ -118,6 +118,8 @@ typedef struct hrg_model_desc {
   double body_mass[HRG_NV];     /* welded children already merged in */
   double body_com[HRG_NV][3];   /* in body frame */
   double body_inertia[HRG_NV][6]; /* about com, body frame: xx yy zz xy xz yz */
+  double dof_invweight0[HRG_NV];  /* (M^-1)_ii at qpos0 (MuJoCo dof_invweight0) */
+  double body_invweight0[HRG_NV]; /* trace(Jv M^-1 Jv')/3 of the body com at qpos0 (MuJoCo body_invweight0, translational) */
   double gravity[3];
   double eef_pos[3];            /* grip site in the link6 body frame */
   /* actuation: arm motors (robot.xml:4-9), finger position servos */

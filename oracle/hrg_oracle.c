@@ -28,6 +28,9 @@
 #define NEFC_MAX 64
 #define PI 3.14159265358979323846
 
+#include <stdio.h>
+static int g_debug = 0;
+void hrgo_set_debug(int d) { g_debug = d; }
 /* =============================================================================================== vec/quat */
 static void v3set(double* r, double a, double b, double c) { r[0] = a; r[1] = b; r[2] = c; }
 static void v3cpy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
@@ -440,7 +443,7 @@ static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, d
   int n = 0;
   double q = q0, v = v0;
   /* seg 0: acceleration to zero */
-  if (a0 != 0) {
+  if (fabs(a0) > 1e-9) { /* below that the ramp is a no-op (and the sign of rounding noise must not matter) */
     double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
     dur[n] = t; jerk[n] = jj; n++;
     q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
@@ -449,7 +452,7 @@ static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, d
   double D = goal - q;
   double dstop = 0.5 * v * scurve_time(v, amax, jmax);
   double sg = (D - dstop) >= 0 ? 1.0 : -1.0;
-  if (sg * v < 0) {
+  if (sg * v < -1e-9) {
     /* moving away from where we must go: stop first, continue from rest */
     n += scurve(v, 0, amax, jmax, dur + n, jerk + n);
     D -= dstop;
@@ -762,7 +765,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       for (int e = 0; e < 2; e++) {
         const double* p = e ? rp2[i] : rp1[i];
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - m->rcap_r[i] - z0;
-        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] + m->rcap_r[i] > z0 - 0.05)) continue;
+        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.025)) /* end point above the mid-plane of the 0.05 m slab */ continue;
         if (dist < 0) {
           double nn[3] = {0, 0, -1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
           EMIT(i, pl ? GEOM_FLOOR : GEOM_TABLE, m->rcap_body[i], -1, dist, nn, pos);
@@ -834,20 +837,20 @@ static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* 
   *Bd = 2.0 / (dmax * tc);
 }
 
-static void efc_add(const hrg_model_desc* m, efc_t* E, const double* LM, const double* J, const double* qd, int type, double pos, double margin, double floss) {
+static void efc_add(const hrg_model_desc* m, efc_t* E, const double* J, const double* qd, int type, double pos, double margin, double floss, double diag) {
+  /* R = (1-imp)/imp * diagApprox with MuJoCo's constant approximations (dof_invweight0 for joint rows, sum of
+   * the two bodies' translational body_invweight0 for contact rows), not the exact J M^-1 J' */
   if (E->n >= NEFC_MAX) return;
-  double x[NV], A = 0, vel = 0;
-  for (int i = 0; i < NV; i++) { x[i] = J[i]; vel += J[i] * qd[i]; }
-  chol_solve(LM, NV, x);
-  for (int i = 0; i < NV; i++) A += J[i] * x[i];
-  if (!(A > 1e-14)) return; /* row does not act on the robot tree */
+  double vel = 0, nz = 0;
+  for (int i = 0; i < NV; i++) { vel += J[i] * qd[i]; nz += fabs(J[i]); }
+  if (!(nz > 0) || !(diag > 0)) return; /* row does not act on the robot tree */
   double imp, K, Bd;
   impedance(m, pos - margin, &imp, &K, &Bd);
   int r = E->n++;
   memcpy(E->J[r], J, sizeof(double) * NV);
   E->type[r] = type;
   E->aref[r] = -Bd * vel - K * imp * (pos - margin);
-  E->D[r] = 1.0 / ((1 - imp) / imp * A);
+  E->D[r] = 1.0 / ((1 - imp) / imp * diag);
   E->floss[r] = floss;
 }
 
@@ -1074,11 +1077,11 @@ static void env_step(hrgo_batch* B, int e, const double* action, float* obs, flo
     efc_t E;
     E.n = 0;
     for (int i = 0; i < NV; i++) /* friction loss rows */
-      if (m->jnt_frictionloss[i] > 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, LM, J, s->qvel, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i]); }
+      if (m->jnt_frictionloss[i] > 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, J, s->qvel, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i], m->dof_invweight0[i]); }
     for (int i = 0; i < NV; i++) { /* joint limit rows */
       double dlo = s->qpos[i] - m->jnt_range[i][0], dhi = m->jnt_range[i][1] - s->qpos[i];
-      if (dlo < 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, dlo, 0, 0); }
-      if (dhi < 0) { double J[NV] = {0}; J[i] = -1; efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, dhi, 0, 0); }
+      if (dlo < 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, dlo, 0, 0, m->dof_invweight0[i]); }
+      if (dhi < 0) { double J[NV] = {0}; J[i] = -1; efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, dhi, 0, 0, m->dof_invweight0[i]); }
     }
     for (int c = 0; c < ncon && c < HRG_NCON_DYN; c++) { /* pyramidal frictional contact rows */
       const double* n = con[c].n;
@@ -1095,12 +1098,19 @@ static void env_step(hrgo_batch* B, int e, const double* action, float* obs, flo
         /* separation velocity along n (from geom1 to geom2): v2 - v1 */
         if (con[c].b1 >= 0) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
         if (con[c].b2 >= 0) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
-        efc_add(m, &E, LM, J, s->qvel, ROW_UNILATERAL, con[c].dist, margin, 0);
+        double diag = (con[c].b1 >= 0 ? m->body_invweight0[con[c].b1] : 0.0) + (con[c].b2 >= 0 ? m->body_invweight0[con[c].b2] : 0.0);
+        efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
       }
     }
     double qacc[NV];
     memcpy(qacc, s->qacc_warmstart, sizeof qacc);
     solve(m, M, a0, &E, qacc);
+    if (g_debug && (ncon > 0 || g_debug > 1)) {
+      double mx = 0; for (int i = 0; i < NV; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
+      fprintf(stderr, "[oracle] env %d cyc %d ncon %d nefc %d max|qacc| %.3e", e, cyc, ncon, E.n, mx);
+      for (int c = 0; c < ncon; c++) fprintf(stderr, " (%d,%d d=%.4f)", con[c].g1, con[c].g2, con[c].dist);
+      fprintf(stderr, "\n");
+    }
     /* mj_checkAcc -> MujocoException handler (human_env.py:527-546) */
     for (int i = 0; i < NV; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
     if (crash) break;

@@ -21,28 +21,36 @@ def make_pair(n_envs, env_kwargs=None, n_clips=3, clip_seed=0, env_id0=0, clips=
     return OracleBatch(d1, clips, n_envs, env_id0), HipBatch(d2, clips, n_envs, env_id0)
 
 
-def flat_state(s):
+def flat_state(s, names=None):
     """hrg_env_state -> (float vector, int vector) for comparisons."""
     d = struct_to_dict(s)
     fl, it = [], []
 
-    def walk(x, isint):
+    def walk(x, path):
         if isinstance(x, dict):
             for k, v in x.items():
-                walk(v, isint)
+                walk(v, path + "." + k)
         elif isinstance(x, list):
-            for v in x:
-                walk(v, isint)
+            for i, v in enumerate(x):
+                walk(v, f"{path}[{i}]")
         elif isinstance(x, float):
             fl.append(x)
+            if names is not None:
+                names[0].append(path)
         else:
             it.append(int(x))
-    walk(d, False)
+            if names is not None:
+                names[1].append(path)
+    walk(d, "st")
     return np.array(fl), np.array(it)
 
 
 def assert_state_close(so, sg, what=""):
-    fo, io = flat_state(so)
+    names = ([], [])
+    fo, io = flat_state(so, names)
     fg, ig = flat_state(sg)
-    np.testing.assert_array_equal(io, ig, err_msg=f"integer state differs {what}")
-    np.testing.assert_allclose(fg, fo, rtol=RTOL, atol=ATOL, err_msg=f"float state differs {what}")
+    bad_i = [f"{names[1][k]}: oracle {io[k]} hip {ig[k]}" for k in np.nonzero(io != ig)[0][:12]]
+    assert not bad_i, f"integer state differs {what}: {bad_i}"
+    bad = np.nonzero(~np.isclose(fg, fo, rtol=RTOL, atol=ATOL))[0]
+    bad_f = [f"{names[0][k]}: oracle {fo[k]!r} hip {fg[k]!r}" for k in bad[:12]]
+    assert not bad_f, f"float state differs {what}: {bad_f}"
