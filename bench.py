@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""bench.py — env (policy) steps/sec of the batched ReachHuman stepper, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Workload (BASELINE.json metric): ReachHuman, sara-shield SSM, 4096 envs per GPU, control_freq 10 (25 shield
+cycles of 4 ms per policy step), synthetic random actions U(-1,1)^7, synthetic human clips, auto-reset on.
+One "step" = one `hrg_batch_step` launch over the rank's 4096 envs (+ one RCCL all-gather of the packed
+outputs when N > 1).  Envs shard embarrassingly: rank r owns global env ids [r*4096, (r+1)*4096).
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     — HBM roofline of the step kernel: ALGORITHMIC bytes per launch / average kernel time measured
+                 live with HIP events on the launch stream (hrg_batch_kernel_time).
+  cpu_baseline — the CPU oracle (oracle/hrg_oracle.c, kind "port") timed on the host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ENVS_PER_GPU = 4096
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
+    """state block read + written once, one animation frame per cycle, action in, outputs out."""
+    frame = C["HRG_FRAME_DIM"] * 8
+    out = 2 * C["HRG_OBS_DIM"] * 4 + 4 + 1 + C["HRG_INFO_DIM"] * 4
+    return 2 * state_bytes + n_cycles * frame + C["HRG_ACT_DIM"] * 8 + out
+
+
+def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0):
+    """Oracle on the host cores: P threads (ctypes releases the GIL) x n/P envs each, barrier per vec-step —
+    the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per step)."""
+    import numpy as np
+    import human_robot_gym_amd as hrg
+    from oracle.oracle import OracleBatch
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    n = ENVS_PER_GPU
+    clips = hrg.synthetic_clips(13, seed=clips_seed)
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    B = OracleBatch(desc, clips, n, 0)
+    B.reset()
+    rng = np.random.RandomState(1234)
+    bounds = [(n * i // cores, n * (i + 1) // cores) for i in range(cores)]
+
+    def vec_step(a):
+        ts = [threading.Thread(target=B.step_range, args=(lo, hi, a)) for lo, hi in bounds]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+
+    vec_step(rng.uniform(-1, 1, (n, 7)))  # warm-up
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        vec_step(rng.uniform(-1, 1, (n, 7)))
+        k += 1
+        el = time.perf_counter() - t0
+        if el >= budget_s and k >= 2:
+            break
+    B.close()
+    return {"value": n * k / el, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} host threads"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
+    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd._cstruct import CONST as C
+    from human_robot_gym_amd._lib import HipBatch, load_library
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    # ReachHuman training configuration: training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
+    env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
+                      reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
+    n = args.envs_per_gpu
+    clips = hrg.synthetic_clips(13, seed=0)
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
+    dev = G.device
+    G.reset()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    pool = [torch.rand((n, C["HRG_ACT_DIM"]), generator=gen, device=dev, dtype=torch.float64) * 2 - 1 for _ in range(32)]
+    gathered = torch.empty(world * G.packed.numel(), dtype=torch.uint8, device=dev) if world > 1 else None
+
+    def one_step(k):
+        G.step(pool[k % len(pool)])
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, G.packed)  # one fused RCCL all-gather of obs/reward/done/info
+
+    for k in range(args.warmup):
+        one_step(k)
+    G.kernel_time()  # arm + clear the HIP-event kernel timer
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kernel_ms, n_launch = G.kernel_time()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        state_bytes = load_library().hrg_state_bytes()
+        per_env = algorithmic_bytes_per_env_step(C, state_bytes, desc.n_cycles)
+        achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic = None
+        try:
+            with open(args.traffic_json) as f:
+                traffic = json.load(f).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+        out = {
+            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs",
+            "value": world * n * args.steps / elapsed,
+            "unit": "env steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"ReachHuman, {n} envs/GPU, sara-shield {args.shield}, control_freq 10 (25 x 4 ms shield cycles per step), "
+                                   "random actions U(-1,1)^7, 13 synthetic human clips, auto-reset",
+                       "envs_per_gpu": n, "shield_type": args.shield, "horizon": 100, "substeps_per_step": int(desc.n_cycles),
+                       "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" if world > 1 else "")},
+            "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "kernel": "hrg_step_kernel", "kernel_ms": kernel_ms, "launches": n_launch,
+                         "algorithmic_bytes_per_launch": per_env * n},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0)
+        print(json.dumps(out), flush=True)
+    G.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -96,11 +96,21 @@ class HipBatch:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.hrg_batch_create(ctypes.byref(desc), ctypes.byref(table), self.n, int(env_id0), device, ctypes.byref(self.h)))
             C = CONST
-            self.obs = torch.zeros((self.n, C["HRG_OBS_DIM"]), dtype=torch.float32, device=self.device)
-            self.term_obs = torch.zeros((self.n, C["HRG_OBS_DIM"]), dtype=torch.float32, device=self.device)
-            self.reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
-            self.done = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
-            self.info = torch.zeros((self.n, C["HRG_INFO_DIM"]), dtype=torch.int32, device=self.device)
+            # one contiguous SoA output block so that multi-GPU runs need ONE all-gather per step:
+            # [obs f32 n*18 | term_obs f32 n*18 | reward f32 n | info i32 n*12 | done u8 n (padded)]
+            n, od, idim = self.n, C["HRG_OBS_DIM"], C["HRG_INFO_DIM"]
+            sizes = [4 * n * od, 4 * n * od, 4 * n, 4 * n * idim, n]
+            offs, tot = [], 0
+            for sz in sizes:
+                offs.append(tot)
+                tot += (sz + 255) // 256 * 256
+            self.packed = torch.zeros(tot, dtype=torch.uint8, device=self.device)
+            self.packed_layout = dict(offsets=offs, sizes=sizes)
+            self.obs = self.packed[offs[0]:offs[0] + sizes[0]].view(torch.float32).view(n, od)
+            self.term_obs = self.packed[offs[1]:offs[1] + sizes[1]].view(torch.float32).view(n, od)
+            self.reward = self.packed[offs[2]:offs[2] + sizes[2]].view(torch.float32)
+            self.info = self.packed[offs[3]:offs[3] + sizes[3]].view(torch.int32).view(n, idim)
+            self.done = self.packed[offs[4]:offs[4] + sizes[4]]
 
     def _stream(self):
         return ctypes.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
