@@ -16,7 +16,7 @@ SRC = os.path.join(_HERE, "csrc", "hrgym_hip.hip")
 EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
-    "hrg_batch_kernel_time",
+    "hrg_batch_kernel_time", "hrg_batch_enable_taps",
 ]
 
 
@@ -58,6 +58,7 @@ def load_library():
     lib.hrg_batch_capsules.argtypes = [vp, vp, vp, vp]
     lib.hrg_batch_get_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_batch_enable_taps.argtypes = [vp, i32]
     lib.hrg_batch_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     if lib.hrg_state_bytes() != ctypes.sizeof(EnvState):
         raise RuntimeError("hrg_env_state layout mismatch between header mirror and library: rebuild")
@@ -153,6 +154,9 @@ class HipBatch:
         ncon = np.zeros(self.n, np.int32)
         _check(self.lib, self.lib.hrg_batch_contacts(self.h, pairs.ctypes.data_as(ctypes.c_void_p), ncon.ctypes.data_as(ctypes.c_void_p)))
         return pairs, ncon
+
+    def enable_taps(self, on=True):
+        _check(self.lib, self.lib.hrg_batch_enable_taps(self.h, int(bool(on))))
 
     def capsules(self):
         import numpy as np

@@ -35,6 +35,7 @@ struct DevModel {
   double Rq[NV][9];          // body_quat as matrices
   int32_t anc_mask[NV];      // bit i set: body i is an ancestor-or-self of body j
   int32_t hb_maxdepth;
+  int32_t phase_mask;        // timing experiments (HRG_PHASE_MASK); 0xff = everything on
   // human reach capsule table (one entry per lane): kind 0 ACC, 1 VEL, 2 POS ball, 3 POS part
   int32_t hc_n;
   int32_t hc_kind[HRG_NHCAP_MAX], hc_j1[HRG_NHCAP_MAX], hc_j2[HRG_NHCAP_MAX];

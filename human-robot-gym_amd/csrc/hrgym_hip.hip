@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -43,7 +44,7 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
 }
 
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
-DI int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
+__device__ __noinline__ int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const double h = m.timestep;
@@ -286,7 +287,7 @@ DI void eef_update(const DevModel* __restrict__ dm, Lds& L) {
 
 // HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
 // + FailsafeController.reset (failsafe_controller.py:204-250)
-DI void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
+__device__ __noinline__ void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const int episode = s.episode + 1;
@@ -343,8 +344,9 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
       wave_sync();
     }
     // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
-    shield_step(dm, L, lane, e, dbg_r, dbg_h, dbg_nh);
-    robot_dynamics_terms(dm, L, lane);
+    const int pm = dm->phase_mask;
+    if (pm & 1) shield_step(dm, L, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm, L, lane, false);
+    if (pm & 2) robot_dynamics_terms(dm, L, lane);
     if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
       if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
       wave_sync();
@@ -368,9 +370,9 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
     }
     if (!failsafe_intervention && !s.is_safe) { failsafe_intervention = 1; s.failsafe_interventions = s.failsafe_interventions + 1; }
     wave_sync();
-    human_control(dm, L, lane, gid); // _control_human + kinematics of sim.forward() #2
-    int ncon;
-    collide(dm, L, lane, &ncon);
+    if (pm & 4) human_control(dm, L, lane, gid); // _control_human + kinematics of sim.forward() #2
+    int ncon = 0;
+    if (pm & 8) collide(dm, L, lane, &ncon);
     classify(dm, L, ncon, &has_collision, &collision_type);
     s.ncon = ncon;
     if (lane < HRG_NCON_MAX) {
@@ -378,7 +380,7 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
       s.con_pairs[lane][1] = lane < ncon ? L.con[lane].g2 : -1;
     }
     wave_sync();
-    crash = dynamics_step(dm, L, lane, ncon);
+    if (pm & 16) crash = dynamics_step(dm, L, lane, ncon);
     if (crash) break;
     s.time = s.time + m.timestep;
     eef_update(dm, L);
@@ -489,6 +491,7 @@ struct hrg_batch {
   int32_t* d_nh = nullptr;
   float* d_scratch_obs = nullptr;
   bool timing = false;
+  bool taps = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
@@ -552,6 +555,8 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     for (int j = i + 1; j < HRG_NRCAP; j++)
       if ((desc->rcap_selfmask[i] >> j) & 1u) { hm->self_i[ns] = i; hm->self_j[ns] = j; ns++; }
   hm->n_self = ns;
+  hm->phase_mask = 0xff;
+  if (const char* pm = getenv("HRG_PHASE_MASK")) hm->phase_mask = atoi(pm); // timing experiments only: results are invalid
   // clips
   const size_t fbytes = sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames;
   int64_t tot = 0;
@@ -611,7 +616,7 @@ int hrg_batch_step(hrg_batch* b, const double* actions_dev, float* obs_dev, floa
     HIPCHK(hipEventRecord(ev.first, st));
   }
   hipLaunchKernelGGL(hrg_step_kernel, dim3(b->n_envs), dim3(64), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                     b->d_rcaps, b->d_hcaps, b->d_nh, b->env_id0, b->d_scratch_obs);
+                     b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(ev.second, st)); b->events.push_back(ev); }
   return HRG_OK;
@@ -649,6 +654,12 @@ int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t 
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_env_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(b->d_states + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
+int hrg_batch_enable_taps(hrg_batch* b, int32_t on) {
+  if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  b->taps = on != 0;
   return HRG_OK;
 }
 

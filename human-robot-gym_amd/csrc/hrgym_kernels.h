@@ -7,7 +7,7 @@
 // Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
 // 1 = configuration at the end of the fail-safe brake (both feed RobotReach), 2 = simulation state
 // (mj_kinematics of sim.forward(), environments/manipulation/human_env.py:504).
-DI void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
+__device__ __noinline__ void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
   if (lane < 3 && (lane == 2 || shield_on)) {
     const hrg_model_desc& m = dm->m;
     const int cfg = lane;
@@ -57,7 +57,7 @@ DI void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool s
 // mj_comPos / mj_crb / mj_rne(flg_acc=0) for the robot tree: joint subspaces, world inertias, composite
 // inertia -> dense 8x8 M (lanes = matrix entries), bias forces (serial recursion wave-uniform, per-body
 // force terms on lanes = bodies).  SURVEY.md Appendix B.1 position+velocity stages.
-DI void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
+__device__ __noinline__ void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
   const hrg_model_desc& m = dm->m;
   if (lane < NV) {
     const int i = lane;
@@ -158,7 +158,7 @@ DI int clip_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int an
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
 }
 
-DI void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+__device__ __noinline__ void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
   const hrg_model_desc& m = dm->m;
   const int b = lane < HRG_NHB ? lane : 0;
   double R[9], p[3], Rloc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, anchor[3];
@@ -217,7 +217,7 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const 
   wave_sync();
 }
 
-DI void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
+__device__ __noinline__ void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   // human_env.py:1719-1731 (wave-uniform)
@@ -251,7 +251,7 @@ DI void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t
 // SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
 // restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
 // human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
-DI void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+__device__ __noinline__ void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const double dt = m.timestep, t = s.time;
@@ -397,7 +397,7 @@ DI void shield_reset(const DevModel* __restrict__ dm, Lds& L, int lane) {
 
 // ================================================================================================ contacts
 // Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
-DI void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
+__device__ __noinline__ void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
   const hrg_model_desc& m = dm->m;
   if (lane < HRG_NRCAP) {
     const int c = lane, b = m.rcap_body[c];
@@ -479,7 +479,7 @@ DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TAB
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
-DI void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
+__device__ __noinline__ void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   int cur[HRG_NPREV_MAX], ncur = 0;

@@ -1,0 +1,63 @@
+"""Multi-GPU sharding: one process per GPU, envs split by global id, ONE all-gather of the packed outputs per step.
+
+Envs never interact (one OS process each in the reference, utils/training_utils_SB3.py:71), so there is no data-path
+collective inside a step; the only exchange is publishing every rank's (obs, term_obs, reward, info, done) block to
+all ranks — RCCL `all_gather` over xGMI on GPUs ("nccl" backend), gloo on CPU for tests.
+"""
+import numpy as np
+
+from ._cstruct import CONST
+
+
+def shard_range(n_global, rank, world):
+    """Global env ids [lo, hi) owned by `rank`; remainders go to the lowest ranks."""
+    base, rem = divmod(n_global, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def packed_layout(n):
+    """Byte layout of one rank's output block (mirrors HipBatch.packed)."""
+    od, idim = CONST["HRG_OBS_DIM"], CONST["HRG_INFO_DIM"]
+    sizes = [4 * n * od, 4 * n * od, 4 * n, 4 * n * idim, n]
+    offs, tot = [], 0
+    for sz in sizes:
+        offs.append(tot)
+        tot += (sz + 255) // 256 * 256
+    return dict(offsets=offs, sizes=sizes, total=tot)
+
+
+def unpack(block, n):
+    """uint8 numpy block of one rank -> dict of typed views."""
+    lay = packed_layout(n)
+    o, s = lay["offsets"], lay["sizes"]
+    od, idim = CONST["HRG_OBS_DIM"], CONST["HRG_INFO_DIM"]
+    return dict(
+        obs=block[o[0]:o[0] + s[0]].view(np.float32).reshape(n, od),
+        term_obs=block[o[1]:o[1] + s[1]].view(np.float32).reshape(n, od),
+        reward=block[o[2]:o[2] + s[2]].view(np.float32),
+        info=block[o[3]:o[3] + s[3]].view(np.int32).reshape(n, idim),
+        done=block[o[4]:o[4] + s[4]],
+    )
+
+
+def all_gather_packed(packed, group=None):
+    """All-gather equal-sized packed blocks (torch uint8 tensors). Returns a [world, total] tensor on every rank."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    out = torch.empty((world, packed.numel()), dtype=torch.uint8, device=packed.device)
+    if dist.get_backend(group) == "gloo":
+        parts = list(out.unbind(0))
+        dist.all_gather(parts, packed.contiguous(), group=group)
+        out = torch.stack(parts, 0)
+    else:
+        dist.all_gather_into_tensor(out.view(-1), packed.contiguous(), group=group)
+    return out
+
+
+def gather_global(packed, n_local, group=None):
+    """Global (obs, term_obs, reward, info, done) numpy arrays in global env-id order (equal shards)."""
+    g = all_gather_packed(packed, group).cpu().numpy()
+    parts = [unpack(g[r], n_local) for r in range(g.shape[0])]
+    return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}

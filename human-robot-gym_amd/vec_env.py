@@ -1,0 +1,255 @@
+"""Drop-in vectorised / single-env facades over the HIP stepper.
+
+`HipVecEnv` keeps the stable-baselines3 `VecEnv` contract that the reference's training utilities consume
+(`make_vec_env(..., vec_env_cls=SubprocVecEnv)`: utils/env_util_SB3.py:75-87, utils/training_utils_SB3.py:60-75):
+`reset() -> obs[N,18]`, `step_async(actions)`, `step_wait() -> (obs, rewards, dones, infos)`, auto-reset with
+`infos[i]["terminal_observation"]`, Monitor-style `infos[i]["episode"] = {"r","l","t"}`, `TimeLimit.truncated`
+(wrappers/time_limit.py:40-43) and the `log_info_keys` of training/config/run/default_training.yaml:18-29.
+The wrapper stack of the reference (Monitor -> TimeLimit -> GymWrapper -> ReachHuman) is folded into the batch:
+flattening to `[object-state, goal_difference]` (human_reach_ppo_parallel.yaml:14-16) happens in the kernel.
+
+`HipGymEnv` is the single-env gym-0.21 facade (4-tuple step) for config 1 (demos/demo_reach_human_environment.py).
+
+If stable-baselines3 / gym are installed the classes subclass their ABCs; otherwise light stand-ins with the same
+attributes are used (neither package is available in the build image).
+"""
+import time
+from collections import OrderedDict
+
+import numpy as np
+
+from ._cstruct import CONST
+from .animation import synthetic_clips
+from .model import build_model_desc, DEFAULT_ENV_KWARGS
+
+try:  # pragma: no cover - not installed in the build image
+    from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
+except Exception:  # noqa: BLE001
+    class _VecEnvBase:  # minimal stand-in with the attributes SB3 algorithms read
+        def __init__(self, num_envs, observation_space, action_space):
+            self.num_envs = num_envs
+            self.observation_space = observation_space
+            self.action_space = action_space
+
+        def step(self, actions):
+            self.step_async(actions)
+            return self.step_wait()
+
+try:  # pragma: no cover
+    from gym import spaces as _spaces
+    _Box = _spaces.Box
+except Exception:  # noqa: BLE001
+    class _Box:
+        def __init__(self, low, high, shape=None, dtype=np.float32):
+            self.shape = tuple(shape if shape is not None else np.shape(low))
+            self.low = np.broadcast_to(np.asarray(low, dtype), self.shape).copy()
+            self.high = np.broadcast_to(np.asarray(high, dtype), self.shape).copy()
+            self.dtype = np.dtype(dtype)
+
+        def sample(self):
+            lo = np.where(np.isfinite(self.low), self.low, -1.0)
+            hi = np.where(np.isfinite(self.high), self.high, 1.0)
+            return np.random.uniform(lo, hi).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
+    "collision", "collision_type", "n_collisions", "n_collisions_static", "n_collisions_robot", "n_collisions_human",
+    "n_collisions_critical", "timeout", "failsafe_interventions", "n_goal_reached", "TimeLimit.truncated", "sim_crash",
+]
+_BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
+OBS_KEYS = ["object-state", "goal_difference"]
+
+
+class _TorchBackend:
+    """numpy <-> HipBatch adapter: one H2D copy of the actions, one D2H copy of the packed output block per step."""
+
+    def __init__(self, desc, clips, n_envs, env_id0, device):
+        import torch
+        from ._lib import HipBatch
+        self.torch = torch
+        self.batch = HipBatch(desc, clips, n_envs, env_id0=env_id0, device=device)
+        self.n = n_envs
+        lay = self.batch.packed_layout
+        self._host = torch.empty(self.batch.packed.numel(), dtype=torch.uint8, pin_memory=True)
+        o, s = lay["offsets"], lay["sizes"]
+        hb = self._host.numpy()
+        od, idim = CONST["HRG_OBS_DIM"], CONST["HRG_INFO_DIM"]
+        self.obs = hb[o[0]:o[0] + s[0]].view(np.float32).reshape(n_envs, od)
+        self.term_obs = hb[o[1]:o[1] + s[1]].view(np.float32).reshape(n_envs, od)
+        self.reward = hb[o[2]:o[2] + s[2]].view(np.float32)
+        self.info = hb[o[3]:o[3] + s[3]].view(np.int32).reshape(n_envs, idim)
+        self.done = hb[o[4]:o[4] + s[4]]
+
+    def _fetch(self):
+        self._host.copy_(self.batch.packed, non_blocking=False)
+
+    def reset(self):
+        self.batch.reset()
+        self._fetch()
+        return self.obs
+
+    def step_async(self, actions):
+        a = self.torch.from_numpy(np.ascontiguousarray(actions, np.float64)).to(self.batch.device, non_blocking=True)
+        self.batch.step(a)
+
+    def step_wait(self):
+        self._fetch()
+        return self.obs, self.term_obs, self.reward, self.done, self.info
+
+    def close(self):
+        self.batch.close()
+
+
+class HipVecEnv(_VecEnvBase):
+    """Batched ReachHuman environments stepped by the HIP library (one wavefront per env).
+
+    Args mirror the reference factory (`utils/env_util_SB3.py:19-87`): `env_kwargs` is the dict composed at
+    `utils/training_utils.py:71-88`; `seed` plays the role of `seed + rank` (per-env streams are keyed by the
+    global env id, so sharding does not change results)."""
+
+    def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
+                 device=0, env_id0=0, backend=None, info_dicts=True):
+        if env_id != "ReachHuman":
+            raise NotImplementedError(f"env_id {env_id!r}: only ReachHuman is built in this round (DESIGN.md §6)")
+        if obs_keys is not None and list(obs_keys) != OBS_KEYS:
+            raise NotImplementedError(f"obs_keys {obs_keys!r}: the compiled observation layout is {OBS_KEYS}")
+        kw = dict(env_kwargs or {})
+        if seed is not None:
+            kw["seed"] = int(seed)
+        self.env_kwargs = kw
+        self._clips = clips if clips is not None else synthetic_clips()
+        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips)
+        self._device, self._env_id0 = device, env_id0
+        self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
+        obs_space = _Box(-np.inf, np.inf, shape=(CONST["HRG_OBS_DIM"],), dtype=np.float32)
+        act_space = _Box(-1.0, 1.0, shape=(CONST["HRG_ACT_DIM"],), dtype=np.float32)
+        super().__init__(n_envs, obs_space, act_space)
+        self.info_dicts = info_dicts
+        self._ep_ret = np.zeros(n_envs, np.float64)
+        self._ep_len = np.zeros(n_envs, np.int64)
+        self._t_start = time.time()
+        self._actions = None
+        self.horizon = int(self._desc.horizon)
+
+    # ---- VecEnv API -------------------------------------------------------------------------------------
+    def reset(self):
+        self._ep_ret[:] = 0
+        self._ep_len[:] = 0
+        return np.array(self._backend.reset(), copy=True)
+
+    def step_async(self, actions):
+        actions = np.asarray(actions, np.float64).reshape(self.num_envs, CONST["HRG_ACT_DIM"])
+        self._actions = actions
+        self._backend.step_async(actions)
+
+    def step_wait(self):
+        obs, term_obs, reward, done, info = self._backend.step_wait()
+        obs, reward = np.array(obs, copy=True), np.array(reward, copy=True)
+        dones = np.asarray(done).astype(bool)
+        self._ep_ret += reward
+        self._ep_len += 1
+        infos = self._make_infos(info, dones, term_obs) if self.info_dicts else [{} for _ in range(self.num_envs)]
+        self._ep_ret[dones] = 0
+        self._ep_len[dones] = 0
+        return obs, reward, dones, infos
+
+    def _make_infos(self, info, dones, term_obs):
+        infos = []
+        now = time.time() - self._t_start
+        for i in range(self.num_envs):
+            d = {k: (bool(info[i, j]) if k in _BOOL_KEYS else int(info[i, j])) for j, k in enumerate(INFO_KEYS)}
+            d["action"] = self._actions[i]
+            d["action_resamples"] = 0  # CollisionPreventionWrapper is not part of this round
+            if dones[i]:
+                d["terminal_observation"] = np.array(term_obs[i], copy=True)
+                d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
+            else:
+                d.pop("TimeLimit.truncated")
+            infos.append(d)
+        return infos
+
+    def close(self):
+        self._backend.close()
+
+    def seed(self, seed=None):
+        """Re-key the per-env random streams (takes effect at the next reset by rebuilding the batch)."""
+        if seed is None:
+            return [None] * self.num_envs
+        self.env_kwargs["seed"] = int(seed)
+        self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips)
+        if isinstance(self._backend, _TorchBackend):
+            self._backend.close()
+            self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)
+        else:
+            self._backend.reseed(self._desc)
+        return [int(seed) + i for i in range(self.num_envs)]
+
+    def get_attr(self, attr_name, indices=None):
+        idx = self._indices(indices)
+        if attr_name in ("horizon", "env_kwargs"):
+            return [getattr(self, attr_name)] * len(idx)
+        raise AttributeError(f"HipVecEnv has no per-env attribute {attr_name!r}")
+
+    def set_attr(self, attr_name, value, indices=None):
+        raise NotImplementedError("per-env attributes are fixed at construction (hrg_model_desc)")
+
+    def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        raise NotImplementedError(f"env_method({method_name!r}) is not available on the batched stepper")
+
+    def env_is_wrapped(self, wrapper_class, indices=None):
+        return [False] * len(self._indices(indices))
+
+    def get_images(self):
+        raise NotImplementedError("rendering is out of scope")
+
+    def render(self, mode="human"):
+        raise NotImplementedError("rendering is out of scope")
+
+    def _indices(self, indices):
+        if indices is None:
+            return list(range(self.num_envs))
+        if isinstance(indices, int):
+            return [indices]
+        return list(indices)
+
+
+class HipGymEnv:
+    """Single ReachHuman env with the gym-0.21 API: `reset() -> obs`, `step(a) -> (obs, reward, done, info)`.
+
+    Stepping a finished episode raises ValueError like HumanEnv.step (human_env.py:487-488)."""
+
+    def __init__(self, env_kwargs=None, seed=None, clips=None, device=0, backend=None):
+        self._vec = HipVecEnv(1, env_kwargs=env_kwargs, seed=seed, clips=clips, device=device, backend=backend)
+        self.observation_space = self._vec.observation_space
+        self.action_space = self._vec.action_space
+        self._done = True
+        self._next_obs = None
+
+    def reset(self):
+        if self._next_obs is not None:  # the kernel already reset the env when the episode ended
+            obs, self._next_obs = self._next_obs, None
+        else:
+            obs = self._vec.reset()[0]
+        self._done = False
+        return obs
+
+    def step(self, action):
+        if self._done:
+            raise ValueError("executing action in terminated episode")
+        obs, rew, done, infos = self._vec.step(np.asarray(action, np.float64)[None])
+        info = infos[0]
+        if done[0]:
+            self._done = True
+            self._next_obs = obs[0]
+            return info["terminal_observation"], float(rew[0]), True, info
+        return obs[0], float(rew[0]), False, info
+
+    def observation_dict(self, obs):
+        """Split a flat observation back into the reference's modality keys."""
+        return OrderedDict([("object-state", obs[:12]), ("goal_difference", obs[12:])])
+
+    def close(self):
+        self._vec.close()

@@ -248,6 +248,8 @@ int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host);
 /* reach capsules of the last shield cycle: robot double[n_envs][HRG_NSHIELD_RCAP][7],
  * human double[n_envs][HRG_NHCAP_MAX][7] (p1,p2,r), n_human int32[n_envs] */
 int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int32_t* n_human_host);
+/* the capsule taps cost ~4 KB of HBM writes per env per shield cycle, so they are off unless enabled here */
+int hrg_batch_enable_taps(hrg_batch* b, int32_t on);
 int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 

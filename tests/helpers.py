@@ -54,3 +54,24 @@ def assert_state_close(so, sg, what=""):
     bad = np.nonzero(~np.isclose(fg, fo, rtol=RTOL, atol=ATOL))[0]
     bad_f = [f"{names[0][k]}: oracle {fo[k]!r} hip {fg[k]!r}" for k in bad[:12]]
     assert not bad_f, f"float state differs {what}: {bad_f}"
+
+
+class OracleBackend:
+    """HipVecEnv backend interface served by the CPU oracle (host-logic tests without a GPU)."""
+
+    def __init__(self, desc, clips, n_envs, env_id0=0):
+        from oracle.oracle import OracleBatch
+        self.B = OracleBatch(desc, clips, n_envs, env_id0)
+
+    def reset(self):
+        return self.B.reset()
+
+    def step_async(self, actions):
+        self._out = self.B.step(actions)
+
+    def step_wait(self):
+        obs, rew, done, info = self._out
+        return obs, self.B.term_obs.copy(), rew, done, info
+
+    def close(self):
+        self.B.close()

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Mint the golden rollouts under tests/golden/ with the CPU oracle.
+
+The reference holds no golden vectors for this path and cannot run here, so these fixtures pin
+ORACLE <-> HIP agreement (and guard the oracle against silent drift) — not agreement with MuJoCo/sara-shield.
+    python tools/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import human_robot_gym_amd as hrg  # noqa: E402
+from oracle.oracle import OracleBatch  # noqa: E402
+
+CASES = {
+    "reach_off": dict(shield_type="OFF", reward_shaping=True, horizon=25),
+    "reach_ssm": dict(shield_type="SSM", reward_shaping=True, horizon=25),
+    "reach_ssm_freq5": dict(shield_type="SSM", control_freq=5, horizon=1000, human_rand=[1.0, 0.5, 0.2], base_human_pos_offset=[0.0, 0.0, 0.0]),
+}
+
+
+def run(kw, n_envs=8, n_steps=40, seed=11):
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+    d = hrg.build_model_desc(kw, n_clips=clips.n_clips)
+    B = OracleBatch(d, clips, n_envs)
+    out = dict(obs0=B.reset())
+    rng = np.random.RandomState(seed)
+    acts, obs, rew, done, info, qpos, qvel, ncon, pairs = [], [], [], [], [], [], [], [], []
+    for _ in range(n_steps):
+        a = rng.uniform(-1, 1, (n_envs, 7))
+        o, r, dn, i = B.step(a)
+        acts.append(a); obs.append(o); rew.append(r); done.append(dn); info.append(i)
+        st = [B.get_state(e) for e in range(n_envs)]
+        qpos.append([list(s.qpos) for s in st]); qvel.append([list(s.qvel) for s in st])
+        p, n = B.contacts()
+        ncon.append(n); pairs.append(p)
+    out.update(actions=np.array(acts), obs=np.array(obs), reward=np.array(rew), done=np.array(done), info=np.array(info),
+               qpos=np.array(qpos), qvel=np.array(qvel), ncon=np.array(ncon), pairs=np.array(pairs).astype(np.int8))
+    return out
+
+
+if __name__ == "__main__":
+    for name, kw in CASES.items():
+        out = run(kw)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"{name}.npz"), **out)
+        print(name, {k: v.shape for k, v in out.items()}, "dones", int(out["done"].sum()), "failsafe", int(out["info"][-1, :, 8].sum()))
