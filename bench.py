@@ -36,13 +36,14 @@ def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
     return 2 * state_bytes + n_cycles * frame + C["HRG_ACT_DIM"] * 8 + out
 
 
-def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0):
+def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16):
     """Oracle on the host cores: P threads (ctypes releases the GIL) x n/P envs each, barrier per vec-step —
     the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per step)."""
     import numpy as np
     import human_robot_gym_amd as hrg
     from oracle.oracle import OracleBatch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(avail, max_threads)  # a 1-GPU box is given a 16-core CPU share
     n = ENVS_PER_GPU
     clips = hrg.synthetic_clips(13, seed=clips_seed)
     desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
@@ -69,7 +70,7 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0):
             break
     B.close()
     return {"value": n * k / el, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} host threads"}
+            "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} of {avail} host threads"}
 
 
 def main():
@@ -80,6 +81,7 @@ def main():
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
     args = ap.parse_args()
 
@@ -170,7 +172,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_env * n},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0)
+            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads)
         print(json.dumps(out), flush=True)
     G.close()
     if world > 1:

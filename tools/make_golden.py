@@ -18,12 +18,19 @@ from oracle.oracle import OracleBatch  # noqa: E402
 CASES = {
     "reach_off": dict(shield_type="OFF", reward_shaping=True, horizon=25),
     "reach_ssm": dict(shield_type="SSM", reward_shaping=True, horizon=25),
-    "reach_ssm_freq5": dict(shield_type="SSM", control_freq=5, horizon=1000, human_rand=[1.0, 0.5, 0.2], base_human_pos_offset=[0.0, 0.0, 0.0]),
+    "reach_ssm_freq5": dict(shield_type="SSM", control_freq=5, horizon=1000, human_rand=[0.2, 0.2, 0.2]),  # config 1 shape: 50 cycles/step
+    "contact_static": dict(shield_type="OFF", horizon=60, done_at_collision=False, collision_reward=-10),
 }
 
 
-def run(kw, n_envs=8, n_steps=40, seed=11):
-    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+def clips_for(name):
+    if name == "contact_static":  # T-pose human whose left hand is 0.3 m from the upright arm (collision scenario)
+        return hrg.static_clip(600, pelvis=(-0.8, 1.0, 0.3))
+    return hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+
+
+def run(name, kw, n_envs=8, n_steps=40, seed=11):
+    clips = clips_for(name)
     d = hrg.build_model_desc(kw, n_clips=clips.n_clips)
     B = OracleBatch(d, clips, n_envs)
     out = dict(obs0=B.reset())
@@ -31,6 +38,9 @@ def run(kw, n_envs=8, n_steps=40, seed=11):
     acts, obs, rew, done, info, qpos, qvel, ncon, pairs = [], [], [], [], [], [], [], [], []
     for _ in range(n_steps):
         a = rng.uniform(-1, 1, (n_envs, 7))
+        if name == "contact_static":  # tilt the arm towards / away from the hand
+            a[:, 1] = np.where(np.arange(n_envs) % 2 == 0, 1.0, -1.0)
+            a[:, [0, 2, 3, 4, 5]] *= 0.2
         o, r, dn, i = B.step(a)
         acts.append(a); obs.append(o); rew.append(r); done.append(dn); info.append(i)
         st = [B.get_state(e) for e in range(n_envs)]
@@ -44,6 +54,6 @@ def run(kw, n_envs=8, n_steps=40, seed=11):
 
 if __name__ == "__main__":
     for name, kw in CASES.items():
-        out = run(kw)
+        out = run(name, kw, n_steps=24 if name == "contact_static" else 40)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"{name}.npz"), **out)
         print(name, {k: v.shape for k, v in out.items()}, "dones", int(out["done"].sum()), "failsafe", int(out["info"][-1, :, 8].sum()))
