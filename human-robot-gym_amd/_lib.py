@@ -10,7 +10,7 @@ import subprocess
 from ._cstruct import CONST, EnvState, ModelDesc, ClipTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhrgym_hip.so")
+LIB_PATH = os.environ.get("HRG_LIB_PATH") or os.path.join(_HERE, "libhrgym_hip.so")  # override: tuning experiments only
 SRC = os.path.join(_HERE, "csrc", "hrgym_hip.hip")
 
 EXPORTS = [

@@ -22,6 +22,19 @@
 #define NV HRG_NV
 #define NARM HRG_NARM
 #define DI __device__ __forceinline__
+// tuning knobs (measured on MI355X, profiles/README.md): phases as real functions + a 128-VGPR cap give 4 waves/SIMD,
+// i.e. all 4096 envs of a batch resident at once (16 single-wave workgroups per CU)
+#ifndef HRG_NOINLINE
+#define HRG_NOINLINE 1
+#endif
+#ifndef HRG_MIN_WAVES
+#define HRG_MIN_WAVES 4
+#endif
+#if HRG_NOINLINE
+#define HRG_PHASE __device__ __noinline__
+#else
+#define HRG_PHASE __device__ __forceinline__
+#endif
 #define HRG_PI 3.14159265358979323846
 
 #define GEOM_HUMAN0 HRG_NRCAP
@@ -52,28 +65,37 @@ struct Contact {
   double dist, n[3], pos[3];
 };
 
-// per-workgroup (= per-env) LDS image
+// constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
+#define ROW_CON0 24
+#define NROW (ROW_CON0 + 4 * HRG_NCON_DYN)
+
+// per-workgroup (= per-env) LDS image.  Sized to <= 10 KB so that 16 envs (4 waves/SIMD) are resident per CU:
+// 4096 envs on 256 CUs then run in one round.  Phase-local scratch shares one union.
 struct Lds {
   hrg_env_state st;
-  // robot tree at the simulation state
-  double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], com[NV][3], Iw[NV][6], vw[NV][3], vv[NV][3];
-  double cI[NV][10], F[NV][6];
-  double aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
-  double M[NV * NV], LM[NV * NV], H[NV * NV];
+  // robot tree at the simulation state (live across the whole cycle)
+  double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], vw[NV][3], vv[NV][3];
+  double M[NV * NV], H[NV * NV], Hinv[NV];
   double bias[NV], a0[NV], Ma0[NV], ctrl[NV], qacc[NV], g[NV], d[NV], Md[NV];
-  // shield
-  double cq[NARM], cv[NARM], ca[NARM], qe[NARM];
-  double scap[2][HRG_NSHIELD_RCAP][6];
-  double rc[HRG_NSHIELD_RCAP][7];
-  union U {
-    hrg_ltt cand;                       // live inside shield_step only
-    struct { double J[64][NV], gg[64], hh[64]; } efc;  // live inside the constraint solve only
-  } u;
-  // contacts
-  double hcap[HRG_NHB][6];
-  double rcapw[HRG_NRCAP][6];
   double rcen[HRG_NRCAP][3];
-  Contact con[HRG_NCON_MAX];
+  Contact con[HRG_NCON_DYN];
+  union {
+    struct {  // shield_step
+      double cq[NARM], cv[NARM], ca[NARM], qe[NARM];
+      double scap[2][HRG_NSHIELD_RCAP][6];
+      double rc[HRG_NSHIELD_RCAP][7];
+      hrg_ltt cand;
+    };
+    struct {  // robot_dynamics_terms
+      double com[NV][3], Iw[NV][6], cI[NV][10], F[NV][6], aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
+    };
+    struct {  // human_control + collide
+      double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
+    };
+    struct {  // dynamics_step: contact rows of J (padded to 9: conflict-free ds_read_b64), per-row gradient / curvature
+      double Jc[4 * HRG_NCON_DYN][NV + 1], rg[NROW], rh[NROW];
+    };
+  };
 };
 
 // ------------------------------------------------------------------------------------------------ math
@@ -117,9 +139,24 @@ DI void quatmul(double* r, const double* a, const double* b) {
   double z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0];
   r[0] = w; r[1] = x; r[2] = y; r[3] = z;
 }
+// sin/cos for bounded arguments (joint angles, |x| < ~100): Cody-Waite reduction by pi/2 in two pieces and the
+// fdlibm kernel polynomials on [-pi/4, pi/4]; ~1 ulp, a fraction of the registers/instructions of the generic ocml path.
+DI void sincos_small(double x, double* sn, double* cs) {
+  const double k = rint(x * 6.36619772367581382433e-01);
+  const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double ps = r + r * z * (-1.66666666666666324348e-01 + z * (8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 +
+                    z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)))));
+  const double pc = 1.0 - 0.5 * z + z * z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 +
+                    z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  const int q = ((int)k) & 3;
+  const double s0 = (q & 1) ? pc : ps, c0 = (q & 1) ? ps : pc;
+  *sn = (q & 2) ? -s0 : s0;
+  *cs = ((q + 1) & 2) ? -c0 : c0;
+}
 DI void axisangle2mat(double* M, const double* ax, double ang) {
   double s, c;
-  sincos(ang, &s, &c);
+  sincos_small(ang, &s, &c);
   double t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
   M[0] = t * x * x + c; M[1] = t * x * y - s * z; M[2] = t * x * z + s * y;
   M[3] = t * x * y + s * z; M[4] = t * y * y + c; M[5] = t * y * z - s * x;
@@ -333,31 +370,44 @@ DI void sinertia_mul(double* n, double* f, const double* s, const double* w, con
   f[2] = s[0] * v[2] - hw[2];
 }
 
-// wave-uniform 8x8 Cholesky / solve on LDS arrays
-DI int chol8(double* A) {
-  for (int j = 0; j < NV; j++) {
-    double d = A[j * NV + j];
-    for (int k = 0; k < j; k++) d -= A[j * NV + k] * A[j * NV + k];
-    if (!(d > 0)) return 0;
-    d = sqrt(d);
-    A[j * NV + j] = d;
-    for (int i = j + 1; i < NV; i++) {
-      double s = A[i * NV + j];
-      for (int k = 0; k < j; k++) s -= A[i * NV + k] * A[j * NV + k];
-      A[i * NV + j] = s / d;
-    }
+// 8x8 Cholesky across the wave: lane (i,j) = (lane>>3, lane&7) owns A_ij in a register; right-looking
+// elimination with three shuffles per pivot, no LDS round trips.  Returns L_ij in lanes i >= j.
+// The subtraction order per entry (k ascending) is the one of the oracle's left-looking loop.
+DI double chol_lanes(double a, int lane, bool* ok) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const double akk = __shfl(a, k * 9, 64);
+    if (!(akk > 0)) good = false;
+    const double d = sqrt(akk), inv = 1.0 / d;
+    const double lik = __shfl(a, i * 8 + k, 64) * inv;
+    const double ljk = __shfl(a, j * 8 + k, 64) * inv;
+    if (j == k) { if (i == k) a = d; else if (i > k) a = lik; }
+    else if (i > k && j > k) a -= lik * ljk;
   }
-  return 1;
+  *ok = good;
+  return a;
 }
-DI void chol8_solve(const double* L, double* x) {
+// publish the factor for the wave-uniform solves: lower triangle + reciprocal diagonal
+DI void chol_store(double l, int lane, double* Lm, double* invd) {
+  Lm[lane] = l;
+  if ((lane >> 3) == (lane & 7)) invd[lane & 7] = 1.0 / l;
+}
+// wave-uniform solve L L' x = b with x in registers (factor read from LDS, reads are broadcast)
+DI void chol_solve_reg(const double* Lm, const double* invd, double* x) {
+#pragma unroll
   for (int i = 0; i < NV; i++) {
     double s = x[i];
-    for (int k = 0; k < i; k++) s -= L[i * NV + k] * x[k];
-    x[i] = s / L[i * NV + i];
+#pragma unroll
+    for (int k = 0; k < i; k++) s -= Lm[i * NV + k] * x[k];
+    x[i] = s * invd[i];
   }
+#pragma unroll
   for (int i = NV - 1; i >= 0; i--) {
     double s = x[i];
-    for (int k = i + 1; k < NV; k++) s -= L[k * NV + i] * x[k];
-    x[i] = s / L[i * NV + i];
+#pragma unroll
+    for (int k = i + 1; k < NV; k++) s -= Lm[k * NV + i] * x[k];
+    x[i] = s * invd[i];
   }
 }

@@ -43,176 +43,185 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
   }
 }
 
+DI double pick8(const double* x, int k) {  // x[k] for a register-resident array without dynamic indexing
+  double v = x[0];
+#pragma unroll
+  for (int i = 1; i < NV; i++) v = (k == i) ? x[i] : v;
+  return v;
+}
+
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
-__device__ __noinline__ int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
+HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const double h = m.timestep;
-  L.LM[lane] = L.M[lane];
+  const int mi = lane >> 3, mj = lane & 7;
+  // ---- factor M across the wave; unconstrained acceleration a0 = M^-1 (actuation + passive - bias) ----
+  bool ok;
+  const double Mij = L.M[lane];
+  {
+    const double lm = chol_lanes(Mij, lane, &ok);
+    if (!ok) return 1;
+    chol_store(lm, lane, L.H, L.Hinv);
+  }
   if (lane < NV) {
-    const int i = lane;
-    double act = L.ctrl[i];
-    if (i >= NARM) act = clampd(m.finger_kp * (L.ctrl[i] - s.qpos[i]), m.finger_forcerange[0], m.finger_forcerange[1]);
-    L.a0[i] = act - m.jnt_damping[i] * s.qvel[i] - L.bias[i];
-    L.qacc[i] = s.qacc_warmstart[i];
+    double act = L.ctrl[lane];
+    if (lane >= NARM) act = clampd(m.finger_kp * (act - s.qpos[lane]), m.finger_forcerange[0], m.finger_forcerange[1]);
+    L.Ma0[lane] = act - m.jnt_damping[lane] * s.qvel[lane] - L.bias[lane];  // M a0 (exactly the solve's right-hand side)
+    L.qacc[lane] = s.qacc_warmstart[lane];
   }
   wave_sync();
-  if (!chol8(L.LM)) return 1;
-  chol8_solve(L.LM, L.a0);
-  // ---- build this lane's row ----
-  double J[NV];
+  {
+    double x[NV];
 #pragma unroll
-  for (int i = 0; i < NV; i++) J[i] = 0;
-  int type = 1;
-  bool cand = false;
-  double pos = 0, margin = 0, floss = 0, diag = 0;
+    for (int i = 0; i < NV; i++) x[i] = L.Ma0[i];
+    chol_solve_reg(L.H, L.Hinv, x);
+    if (lane < NV) L.a0[lane] = pick8(x, lane);
+  }
+  // ---- this lane's constraint row (fixed slot) ----
   const int r = lane;
+  int type = 1, rdof = 0;
+  bool cand = false;
+  double rsgn = 0, pos = 0, margin = 0, floss = 0, diag = 0, vel = 0;
   if (r < NV) {
     if (m.jnt_frictionloss[r] > 0) {
       cand = true; type = 0; floss = m.jnt_frictionloss[r]; diag = m.dof_invweight0[r];
-#pragma unroll
-      for (int i = 0; i < NV; i++) J[i] = (i == r) ? 1.0 : 0.0;
+      rdof = r; rsgn = 1.0; vel = s.qvel[r];
     }
-  } else if (r < 24) {
-    const int k = r - 8, dof = k >> 1, side = k & 1;
+  } else if (r < ROW_CON0) {
+    const int k = r - NV, dof = k >> 1, side = k & 1;
     const double dist = side ? m.jnt_range[dof][1] - s.qpos[dof] : s.qpos[dof] - m.jnt_range[dof][0];
     if (dist < 0) {
       cand = true; pos = dist; diag = m.dof_invweight0[dof];
-#pragma unroll
-      for (int i = 0; i < NV; i++) J[i] = (i == dof) ? (side ? -1.0 : 1.0) : 0.0;
+      rdof = dof; rsgn = side ? -1.0 : 1.0; vel = rsgn * s.qvel[dof];
     }
-  } else {
-    const int c = (r - 24) >> 2, d = (r - 24) & 3;
+  } else if (r < NROW) {
+    const int c = (r - ROW_CON0) >> 2, d = (r - ROW_CON0) & 3;
     if (c < ncon && c < HRG_NCON_DYN) {
-      cand = true;
       const Contact& cc = L.con[c];
-      const double n[3] = {cc.n[0], cc.n[1], cc.n[2]};
-      double t1[3], t2[3];
+      const double n[3] = {cc.n[0], cc.n[1], cc.n[2]}, cp[3] = {cc.pos[0], cc.pos[1], cc.pos[2]};
+      double t1[3], t2[3], dir[3];
       const double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
       v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
       v3scl(t1, t1, 1.0 / v3norm(t1));
       v3cross(t2, n, t1);
-      const double* tt = d < 2 ? t1 : t2;
       const double sg = (d & 1) ? -1.0 : 1.0;
-      double dir[3];
-      for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * tt[a];
+      for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
       pos = cc.dist;
       margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
       diag = ((cc.b1 >= 0 ? m.body_invweight0[cc.b1] : 0.0) + (cc.b2 >= 0 ? m.body_invweight0[cc.b2] : 0.0)) * (1.0 + m.friction_static * m.friction_static);
       const int am1 = cc.b1 >= 0 ? dm->anc_mask[cc.b1] : 0, am2 = cc.b2 >= 0 ? dm->anc_mask[cc.b2] : 0;
-#pragma unroll
+      double nz = 0;
+#pragma unroll 1
       for (int i = 0; i < NV; i++) {
         double t[3], v[3];
-        v3cross(t, L.Sw[i], cc.pos);
+        v3cross(t, L.Sw[i], cp);
         v3add(v, L.Sv[i], t);
         const double jv = v3dot(dir, v);
         double acc = 0;
         if ((am1 >> i) & 1) acc += -1.0 * jv;
         if ((am2 >> i) & 1) acc += jv;
-        J[i] = acc;
+        L.Jc[r - ROW_CON0][i] = acc;
+        vel += acc * s.qvel[i];
+        nz += fabs(acc);
       }
+      cand = nz > 0;
     }
   }
+  const bool active = cand && diag > 0;
+  const bool is_con = r >= ROW_CON0;
   double aref = 0, D = 0;
-  bool active = false;
-  {
-    double vel = 0, nz = 0;
-#pragma unroll
-    for (int i = 0; i < NV; i++) { vel += J[i] * s.qvel[i]; nz += fabs(J[i]); }
-    active = cand && nz > 0 && diag > 0;
-    if (active) {
-      double imp, K, Bd;
-      impedance(m, pos - margin, &imp, &K, &Bd);
-      aref = -Bd * vel - K * imp * (pos - margin);
-      D = 1.0 / ((1 - imp) / imp * diag);
-    }
+  if (active) {
+    double imp, K, Bd;
+    impedance(m, pos - margin, &imp, &K, &Bd);
+    aref = -Bd * vel - K * imp * (pos - margin);
+    D = 1.0 / ((1 - imp) / imp * diag);
   }
-#pragma unroll
-  for (int i = 0; i < NV; i++) L.u.efc.J[r][i] = active ? J[i] : 0.0;
   const uint64_t mask = __ballot(active);
-  if (lane < NV) {
-    double t = 0;
-    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.a0[j];
-    L.Ma0[lane] = t;
-  }
+  const uint64_t cmask = mask >> ROW_CON0;  // active contact rows
   wave_sync();
+  // J_r . x for a wave-shared vector x (LDS)
+  auto rowdot = [&](const double* x) -> double {
+    if (!active) return 0.0;
+    if (!is_con) return rsgn * x[rdof];
+    const double* Jr = L.Jc[r - ROW_CON0];
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < NV; i++) t += Jr[i] * x[i];
+    return t;
+  };
   if (mask == 0) {
     if (lane < NV) L.qacc[lane] = L.a0[lane];
     wave_sync();
   } else {
-    // warm start vs unconstrained acceleration: keep the cheaper point
-    double cost[2];
-    for (int pass = 0; pass < 2; pass++) {
-      const double* x = pass ? L.a0 : L.qacc;
-      double c = 0;
-      for (int i = 0; i < NV; i++) {
-        double t = 0;
-        for (int j = 0; j < NV; j++) t += L.M[i * NV + j] * (x[j] - L.a0[j]);
-        c += 0.5 * (x[i] - L.a0[i]) * t;
-      }
-      double y = -aref, cc = 0, gg, hh;
-#pragma unroll
-      for (int i = 0; i < NV; i++) y += J[i] * x[i];
-      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
-      cost[pass] = c + wave_sum(cc);
-    }
-    wave_sync();
-    if (!(cost[0] < cost[1])) { if (lane < NV) L.qacc[lane] = L.a0[lane]; }
-    wave_sync();
-    for (int it = 0; it < m.solver_iters; it++) {
-      double y = -aref, cc = 0, gg = 0, hh = 0;
-#pragma unroll
-      for (int i = 0; i < NV; i++) y += J[i] * L.qacc[i];
-      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
-      L.u.efc.gg[r] = gg;
-      L.u.efc.hh[r] = hh;
+    { // warm start vs unconstrained acceleration: keep the cheaper point
+      const double ei = L.qacc[mi] - L.a0[mi], ej = L.qacc[mj] - L.a0[mj];
+      double c0 = 0, c1 = 0, g_, h_;
+      if (active) { row_cost(type, D, floss, rowdot(L.qacc) - aref, &c0, &g_, &h_); row_cost(type, D, floss, rowdot(L.a0) - aref, &c1, &g_, &h_); }
+      const double cost_ws = wave_sum(0.5 * Mij * ei * ej + c0), cost_a0 = wave_sum(c1);
       wave_sync();
-      if (lane < NV) {
+      if (!(cost_ws < cost_a0)) { if (lane < NV) L.qacc[lane] = L.a0[lane]; }
+      wave_sync();
+    }
+#pragma unroll 1
+    for (int it = 0; it < m.solver_iters; it++) {
+      const double y = rowdot(L.qacc) - aref;
+      double cc = 0, gg = 0, hh = 0;
+      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
+      if (r < NROW) { L.rg[r] = gg; L.rh[r] = hh; }
+      wave_sync();
+      double gm = 0;
+      if (lane < NV) { // gradient, rows accumulated in slot order (the oracle's row order)
         double t = -L.Ma0[lane];
+#pragma unroll
         for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
-        for (uint64_t mm = mask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.u.efc.J[q][lane] * L.u.efc.gg[q]; }
+        gm = t;
+        t += L.rg[lane];
+        t += L.rg[NV + 2 * lane];
+        t -= L.rg[NV + 2 * lane + 1];
+        for (uint64_t mm = cmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
         L.g[lane] = t;
       }
-      {
-        const int i = lane >> 3, j = lane & 7;
-        double t = L.M[lane];
-        for (uint64_t mm = mask; mm;) {
-          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
-          const double hq = L.u.efc.hh[q];
-          if (hq != 0) t += hq * L.u.efc.J[q][i] * L.u.efc.J[q][j];
-        }
-        L.H[lane] = t;
+      double hval = Mij;
+      if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
+      for (uint64_t mm = cmask; mm;) {
+        const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+        const double hq = L.rh[ROW_CON0 + q];
+        if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
       }
       wave_sync();
       double gn = 0, sc = 0;
+#pragma unroll
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
       if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
-      for (int i = 0; i < NV; i++) L.d[i] = -L.g[i];
-      if (!chol8(L.H)) break;
-      chol8_solve(L.H, L.d);
-      if (lane < NV) {
-        double t = 0;
-        for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.d[j];
-        L.Md[lane] = t;
-      }
-      double p = 0;
-#pragma unroll
-      for (int i = 0; i < NV; i++) p += J[i] * L.d[i];
+      const double hl = chol_lanes(hval, lane, &ok);
+      if (!ok) break;
+      chol_store(hl, lane, L.H, L.Hinv);
       wave_sync();
-      double dMd = 0, gd0 = 0;
-      for (int i = 0; i < NV; i++) {
-        dMd += L.d[i] * L.Md[i];
-        double t = -L.Ma0[i];
-        for (int j = 0; j < NV; j++) t += L.M[i * NV + j] * L.qacc[j];
-        gd0 += L.d[i] * t;
+      {
+        double x[NV];
+#pragma unroll
+        for (int i = 0; i < NV; i++) x[i] = -L.g[i];
+        chol_solve_reg(L.H, L.Hinv, x);
+        if (lane < NV) L.d[lane] = pick8(x, lane);
       }
-      double al = 1.0, lo = 0, hi = -1, d1_0 = 0;
+      wave_sync();
+      const double p = rowdot(L.d);
+      double dd = 0, Mdi = 0;
+      if (lane < NV) {
+        dd = L.d[lane];
+#pragma unroll
+        for (int j = 0; j < NV; j++) Mdi += L.M[lane * NV + j] * L.d[j];
+      }
+      const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
+      double al = 1.0, lo = 0, hi = -1;
+      const double d1_0 = gd0 + wave_sum(gg * p);
+#pragma unroll 1
       for (int ls = 0; ls < 40; ls++) {
         double c2, g2 = 0, h2 = 0;
         if (active) row_cost(type, D, floss, y + al * p, &c2, &g2, &h2);
         const double d1 = gd0 + al * dMd + wave_sum(g2 * p);
         const double d2 = dMd + wave_sum(h2 * p * p);
-        if (ls == 0) d1_0 = gd0 + wave_sum(gg * p);
         if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
         if (d1 < 0) lo = al; else hi = al;
         double nx = al - d1 / d2;
@@ -220,8 +229,7 @@ __device__ __noinline__ int dynamics_step(const DevModel* __restrict__ dm, Lds& 
         else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
         al = nx;
       }
-      wave_sync();
-      if (lane < NV) L.qacc[lane] += al * L.d[lane];
+      if (lane < NV) L.qacc[lane] += al * dd;
       wave_sync();
     }
   }
@@ -230,22 +238,28 @@ __device__ __noinline__ int dynamics_step(const DevModel* __restrict__ dm, Lds& 
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
   {
-    const int i = lane >> 3, j = lane & 7;
-    L.H[lane] = L.M[lane] + (i == j ? h * m.jnt_damping[i] : 0.0);
+    const double hl = chol_lanes(Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok);
+    if (!ok) return 1;
+    chol_store(hl, lane, L.H, L.Hinv);
   }
   if (lane < NV) {
     s.qacc_warmstart[lane] = L.qacc[lane];
     double t = 0;
+#pragma unroll
     for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
     L.d[lane] = t;
   }
   wave_sync();
-  if (!chol8(L.H)) return 1;
-  chol8_solve(L.H, L.d);
-  if (lane < NV) {
-    const double v = s.qvel[lane] + h * L.d[lane];
-    s.qvel[lane] = v;
-    s.qpos[lane] = s.qpos[lane] + h * v;
+  {
+    double x[NV];
+#pragma unroll
+    for (int i = 0; i < NV; i++) x[i] = L.d[i];
+    chol_solve_reg(L.H, L.Hinv, x);
+    if (lane < NV) {
+      const double v = s.qvel[lane] + h * pick8(x, lane);
+      s.qvel[lane] = v;
+      s.qpos[lane] = s.qpos[lane] + h * v;
+    }
   }
   wave_sync();
   return 0;
@@ -287,7 +301,7 @@ DI void eef_update(const DevModel* __restrict__ dm, Lds& L) {
 
 // HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
 // + FailsafeController.reset (failsafe_controller.py:204-250)
-__device__ __noinline__ void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
+HRG_PHASE void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const int episode = s.episode + 1;
@@ -355,7 +369,6 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
       double t = 0;
       for (int j = 0; j < NARM; j++) t += s.mass_matrix[lane * NARM + j] * (m.kp * (s.des_q[j] - s.qpos[j]) + m.kd * (s.des_v[j] - s.qvel[j]) + s.des_a[j]);
       const double tq = clampd(t + L.bias[lane], m.arm_ctrlrange[lane][0], m.arm_ctrlrange[lane][1]);
-      s.torque[lane] = tq;
       L.ctrl[lane] = tq;
     }
     { // gripper: RethinkGripper.format_action + ctrl-range mapping
@@ -374,12 +387,6 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
     int ncon = 0;
     if (pm & 8) collide(dm, L, lane, &ncon);
     classify(dm, L, ncon, &has_collision, &collision_type);
-    s.ncon = ncon;
-    if (lane < HRG_NCON_MAX) {
-      s.con_pairs[lane][0] = lane < ncon ? L.con[lane].g1 : -1;
-      s.con_pairs[lane][1] = lane < ncon ? L.con[lane].g2 : -1;
-    }
-    wave_sync();
     if (pm & 16) crash = dynamics_step(dm, L, lane, ncon);
     if (crash) break;
     s.time = s.time + m.timestep;
@@ -436,7 +443,7 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
 }
 
 // ================================================================================================ kernels
-__global__ __launch_bounds__(64) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const double* __restrict__ actions,
+__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs) {
   __shared__ Lds L;
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(64) void hrg_step_kernel(const DevModel* __restrict
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
 }
 
-__global__ __launch_bounds__(64) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
+__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
                                                       float* __restrict__ obs, int64_t env_id0) {
   __shared__ Lds L;
   const int e = blockIdx.x, lane = threadIdx.x;

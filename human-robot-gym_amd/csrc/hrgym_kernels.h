@@ -7,7 +7,7 @@
 // Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
 // 1 = configuration at the end of the fail-safe brake (both feed RobotReach), 2 = simulation state
 // (mj_kinematics of sim.forward(), environments/manipulation/human_env.py:504).
-__device__ __noinline__ void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
+HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
   if (lane < 3 && (lane == 2 || shield_on)) {
     const hrg_model_desc& m = dm->m;
     const int cfg = lane;
@@ -15,6 +15,7 @@ __device__ __noinline__ void robot_chain_fk(const DevModel* __restrict__ dm, Lds
 #pragma unroll
     for (int k = 0; k < 9; k++) R[k] = dm->Rbase[k];
     v3cpy(p, m.base_pos);
+#pragma unroll 1
     for (int i = 0; i < NARM; i++) {
       double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
       double Rl[9], Rj[9], t[3];
@@ -37,6 +38,7 @@ __device__ __noinline__ void robot_chain_fk(const DevModel* __restrict__ dm, Lds
       }
     }
     if (cfg == 2) {
+#pragma unroll 1
       for (int f = 0; f < HRG_NFINGER; f++) {
         const int i = NARM + f;
         double Rl[9], t[3], pf[3], axw[3];
@@ -57,7 +59,7 @@ __device__ __noinline__ void robot_chain_fk(const DevModel* __restrict__ dm, Lds
 // mj_comPos / mj_crb / mj_rne(flg_acc=0) for the robot tree: joint subspaces, world inertias, composite
 // inertia -> dense 8x8 M (lanes = matrix entries), bias forces (serial recursion wave-uniform, per-body
 // force terms on lanes = bodies).  SURVEY.md Appendix B.1 position+velocity stages.
-__device__ __noinline__ void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
+HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
   const hrg_model_desc& m = dm->m;
   if (lane < NV) {
     const int i = lane;
@@ -85,10 +87,12 @@ __device__ __noinline__ void robot_dynamics_terms(const DevModel* __restrict__ d
   }
   wave_sync();
   // ---- velocity recursion + composite inertia (wave-uniform serial passes) ----
+#pragma unroll 1
   for (int i = NV - 1; i >= 1; i--) {
     int par = m.body_parent[i];
     for (int a = 0; a < 10; a++) L.cI[par][a] += L.cI[i][a];
   }
+#pragma unroll 1
   for (int i = 0; i < NV; i++) {
     int par = m.body_parent[i];
     double pw[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, paw[3] = {0, 0, 0}, pav[3];
@@ -135,6 +139,7 @@ __device__ __noinline__ void robot_dynamics_terms(const DevModel* __restrict__ d
     L.M[lane] = v;
   }
   // bias: backward accumulation (wave-uniform)
+#pragma unroll 1
   for (int i = NV - 1; i >= 0; i--) {
     L.bias[i] = v3dot(L.Sw[i], L.fn[i]) + v3dot(L.Sv[i], L.ff[i]);
     int par = m.body_parent[i];
@@ -158,7 +163,7 @@ DI int clip_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int an
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
 }
 
-__device__ __noinline__ void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
   const hrg_model_desc& m = dm->m;
   const int b = lane < HRG_NHB ? lane : 0;
   double R[9], p[3], Rloc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, anchor[3];
@@ -179,6 +184,7 @@ __device__ __noinline__ void human_fk_lanes(const DevModel* __restrict__ dm, Lds
   }
   const int par = lane >= 1 && lane < HRG_NHB ? m.hb_parent[b] : 0;
   const int depth = lane < HRG_NHB ? m.hb_depth[b] : -1;
+#pragma unroll 1
   for (int level = 1; level <= dm->hb_maxdepth; level++) {
     double Rp[9], pp[3];
 #pragma unroll
@@ -217,7 +223,7 @@ __device__ __noinline__ void human_fk_lanes(const DevModel* __restrict__ dm, Lds
   wave_sync();
 }
 
-__device__ __noinline__ void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
+HRG_PHASE void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   // human_env.py:1719-1731 (wave-uniform)
@@ -251,7 +257,7 @@ __device__ __noinline__ void human_control(const DevModel* __restrict__ dm, Lds&
 // SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
 // restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
 // human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
-__device__ __noinline__ void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   const double dt = m.timestep, t = s.time;
@@ -270,14 +276,14 @@ __device__ __noinline__ void shield_step(const DevModel* __restrict__ dm, Lds& L
       use_cand = 1;
       double tj = 0;
       if (lane < NARM) {
-        ltt_plan_joint(&L.u.cand, lane, L.cq[lane], L.cv[lane], L.ca[lane], s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
-        for (int i = 0; i < HRG_LTT_NSEG; i++) tj += L.u.cand.dur[lane][i];
+        ltt_plan_joint(&L.cand, lane, L.cq[lane], L.cv[lane], L.ca[lane], s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
+        for (int i = 0; i < HRG_LTT_NSEG; i++) tj += L.cand.dur[lane][i];
       }
-      L.u.cand.T = wave_max(tj);
+      L.cand.T = wave_max(tj);
     }
     wave_sync();
   }
-  const hrg_ltt* Lp = use_cand ? &L.u.cand : &s.ltt;
+  const hrg_ltt* Lp = use_cand ? &L.cand : &s.ltt;
   const double ps = use_cand ? 0.0 : s.path_s, pv = use_cand ? 1.0 : s.path_v, pa = use_cand ? 0.0 : s.path_a;
   hrg_path rec, fs2;
   double s1, v1, a1, se, ve_, ae;
@@ -337,6 +343,7 @@ __device__ __noinline__ void shield_step(const DevModel* __restrict__ dm, Lds& L
         r = dm->hc_th[lane] + m.meas_err_pos + dm->hc_v[lane] * Td;
         mdl = kind == 1 ? 1 : 2;
       }
+#pragma unroll 1
       for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
         double x1[3], x2[3];
         const double rr = L.rc[c][6] + r;
@@ -361,7 +368,7 @@ __device__ __noinline__ void shield_step(const DevModel* __restrict__ dm, Lds& L
   if (safe) {
     if (use_cand) {
       double* dst = (double*)&s.ltt;
-      const double* src = (const double*)&L.u.cand;
+      const double* src = (const double*)&L.cand;
       for (int k = lane; k < (int)(sizeof(hrg_ltt) / sizeof(double)); k += 64) dst[k] = src[k];
       s.new_goal = 0;
     }
@@ -397,7 +404,7 @@ DI void shield_reset(const DevModel* __restrict__ dm, Lds& L, int lane) {
 
 // ================================================================================================ contacts
 // Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
-__device__ __noinline__ void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
+HRG_PHASE void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
   const hrg_model_desc& m = dm->m;
   if (lane < HRG_NRCAP) {
     const int c = lane, b = m.rcap_body[c];
@@ -414,6 +421,7 @@ __device__ __noinline__ void collide(const DevModel* __restrict__ dm, Lds& L, in
   int base = 0;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   // rounds: 0 = robot-robot, 1..4 = robot-human (240 pairs), 5 = planes
+#pragma unroll 1
   for (int round = 0; round < 6; round++) {
     bool hit = false;
     Contact c;
@@ -467,11 +475,15 @@ __device__ __noinline__ void collide(const DevModel* __restrict__ dm, Lds& L, in
     const uint64_t mask = __ballot(hit);
     if (hit) {
       const int idx = base + __popcll(mask & lt);
-      if (idx < HRG_NCON_MAX) L.con[idx] = c;
+      if (idx < HRG_NCON_DYN) L.con[idx] = c;  // full geometry only for the contacts that enter the solve
+      if (idx < HRG_NCON_MAX) { L.st.con_pairs[idx][0] = c.g1; L.st.con_pairs[idx][1] = c.g2; }
     }
     base += __popcll(mask);
   }
-  *ncon_out = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
+  const int ncon = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
+  if (lane < HRG_NCON_MAX && lane >= ncon) { L.st.con_pairs[lane][0] = -1; L.st.con_pairs[lane][1] = -1; }
+  L.st.ncon = ncon;
+  *ncon_out = ncon;
   wave_sync();
 }
 
@@ -479,7 +491,7 @@ DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TAB
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
-__device__ __noinline__ void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
+HRG_PHASE void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
   const hrg_model_desc& m = dm->m;
   hrg_env_state& s = L.st;
   int cur[HRG_NPREV_MAX], ncur = 0;
@@ -487,7 +499,7 @@ __device__ __noinline__ void classify(const DevModel* __restrict__ dm, Lds& L, i
   double deb = tm > 0 ? tm : 0;
   const int n_prev = s.n_prev;
   for (int c = 0; c < ncon; c++) {
-    const int g1 = L.con[c].g1, g2 = L.con[c].g2;
+    const int g1 = s.con_pairs[c][0], g2 = s.con_pairs[c][1];
     const int t1 = geom_class(g1), t2 = geom_class(g2);
     if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
     const int h12 = cantor(g1, g2), h21 = cantor(g2, g1);

@@ -60,9 +60,9 @@ extern "C" {
 #define HRG_OBS_DIM 18    /* object-state(12) + goal_difference(6): human_reach_ppo_parallel.yaml:14-16 */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
 #define HRG_INFO_DIM 12
-#define HRG_NCON_MAX 32   /* contacts reported per env per substep */
-#define HRG_NCON_DYN 10   /* contacts that enter the constraint solve (4 pyramid rows each) */
-#define HRG_NPREV_MAX 32  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
+#define HRG_NCON_MAX 24   /* contacts reported per env per substep */
+#define HRG_NCON_DYN 6    /* contacts that enter the constraint solve (4 pyramid rows each) */
+#define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
 
 /* info columns (human_env.py:752-763 + TimeLimit + sim crash) */

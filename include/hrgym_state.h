@@ -40,7 +40,6 @@ typedef struct hrg_env_state {
   double goal_qpos[HRG_NARM];
   double mass_matrix[HRG_NARM * HRG_NARM]; /* stale 6x6 block, refreshed on policy steps only */
   double grip_action;                      /* RethinkGripper.current_action */
-  double torque[HRG_NARM];                 /* last applied arm torques */
   /* ---- shield ---- */
   hrg_ltt ltt;
   hrg_path safe_path;       /* last verified fail-safe profile */

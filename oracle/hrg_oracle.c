@@ -1031,8 +1031,7 @@ static void env_step(hrgo_batch* B, int e, const double* action, float* obs, flo
     for (int i = 0; i < NARM; i++) { /* failsafe_controller.py:356-369 */
       double t = 0;
       for (int j = 0; j < NARM; j++) t += s->mass_matrix[i * NARM + j] * (m->kp * (s->des_q[j] - s->qpos[j]) + m->kd * (s->des_v[j] - s->qvel[j]) + s->des_a[j]);
-      s->torque[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
-      ctrl[i] = s->torque[i];
+      ctrl[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
     }
     { /* RethinkGripper.format_action + actuator ctrl range mapping */
       double a = action[NARM], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
