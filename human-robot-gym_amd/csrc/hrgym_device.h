@@ -49,6 +49,8 @@ struct DevModel {
   int32_t anc_mask[NV];      // bit i set: body i is an ancestor-or-self of body j
   int32_t hb_maxdepth;
   int32_t phase_mask;        // timing experiments (HRG_PHASE_MASK); 0xff = everything on
+  hrg_path brake_full;       // fail-safe profile from the steady state (s'=1, s''=0): constant per model
+  double brake_T, brake_ds;
   // human reach capsule table (one entry per lane): kind 0 ACC, 1 VEL, 2 POS ball, 3 POS part
   int32_t hc_n;
   int32_t hc_kind[HRG_NHCAP_MAX], hc_j1[HRG_NHCAP_MAX], hc_j2[HRG_NHCAP_MAX];
@@ -165,10 +167,27 @@ DI void axisangle2mat(double* M, const double* ax, double ang) {
 DI double clampd(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 
 // wave-wide helpers (wave = 64 lanes on gfx950)
+// one DPP step of a 64-bit value: lanes outside row_mask receive 0.0
+template <int CTRL, int ROW_MASK>
+DI double dpp_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(b & 0xffffffffLL), CTRL, ROW_MASK, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+// wave-wide sum on the DPP network (no LDS crossbar): quad swaps, row half-mirror / mirror, then the gfx9 row
+// broadcasts 15 and 31; the total lands in lane 63 and is read back as a scalar.
 DI double wave_sum(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_f64<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xf>(v);  // row_half_mirror
+  v += dpp_f64<0x140, 0xf>(v);  // row_mirror
+  v += dpp_f64<0x142, 0xa>(v);  // row_bcast15 -> rows 1,3
+  v += dpp_f64<0x143, 0xc>(v);  // row_bcast31 -> rows 2,3
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 DI double wave_max(double v) {
 #pragma unroll
@@ -307,7 +326,7 @@ DI void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double
   *q = L->qT[j]; *v = 0; *a = 0;
 }
 
-DI void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, double amax, double jmax) {
+__host__ DI void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, double amax, double jmax) {
   P->s0 = s0; P->v0 = v0; P->a0 = a0; P->k = 0;
   for (int i = 0; i < 3; i++) { P->dur[i] = 0; P->jerk[i] = 0; }
   if (fabs(v0 - ve) < 1e-12 && fabs(a0) < 1e-12) { P->v0 = ve; P->a0 = 0; return; }
@@ -327,8 +346,8 @@ DI void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, doubl
   P->dur[0] = t1; P->dur[1] = t2; P->dur[2] = t3;
   P->jerk[0] = dir * jmax; P->jerk[1] = 0; P->jerk[2] = -dir * jmax;
 }
-DI double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
-DI void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
+__host__ DI double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
+__host__ DI void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
   double ss = P->s0, vv = P->v0, aa = P->a0;
   for (int i = 0; i < 3; i++) {
     double d = P->dur[i], jj = P->jerk[i];
@@ -394,20 +413,22 @@ DI void chol_store(double l, int lane, double* Lm, double* invd) {
   Lm[lane] = l;
   if ((lane >> 3) == (lane & 7)) invd[lane & 7] = 1.0 / l;
 }
-// wave-uniform solve L L' x = b with x in registers (factor read from LDS, reads are broadcast)
-DI void chol_solve_reg(const double* Lm, const double* invd, double* x) {
+// solve L L' x = b with x_i living in lane i (< 8): column-oriented substitution, the pivot value is broadcast
+// with a scalar readlane, the column of the factor comes from LDS.  Register footprint: one double.
+DI double chol_solve_lanes(const double* Lm, const double* invd, double b, int lane) {
+  double x = b;
+  const int i = lane & 7;
 #pragma unroll
-  for (int i = 0; i < NV; i++) {
-    double s = x[i];
-#pragma unroll
-    for (int k = 0; k < i; k++) s -= Lm[i * NV + k] * x[k];
-    x[i] = s * invd[i];
+  for (int k = 0; k < NV; k++) {
+    const double xk = __shfl(x, k, 64) * invd[k];
+    if (lane == k) x = xk;
+    else if (lane > k && lane < NV) x -= Lm[i * NV + k] * xk;
   }
 #pragma unroll
-  for (int i = NV - 1; i >= 0; i--) {
-    double s = x[i];
-#pragma unroll
-    for (int k = i + 1; k < NV; k++) s -= Lm[k * NV + i] * x[k];
-    x[i] = s * invd[i];
+  for (int k = NV - 1; k >= 0; k--) {
+    const double xk = __shfl(x, k, 64) * invd[k];
+    if (lane == k) x = xk;
+    else if (lane < k) x -= Lm[k * NV + i] * xk;
   }
+  return x;
 }

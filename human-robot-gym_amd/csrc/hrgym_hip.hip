@@ -43,13 +43,6 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
   }
 }
 
-DI double pick8(const double* x, int k) {  // x[k] for a register-resident array without dynamic indexing
-  double v = x[0];
-#pragma unroll
-  for (int i = 1; i < NV; i++) v = (k == i) ? x[i] : v;
-  return v;
-}
-
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
 HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
   const hrg_model_desc& m = dm->m;
@@ -72,11 +65,8 @@ HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, i
   }
   wave_sync();
   {
-    double x[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) x[i] = L.Ma0[i];
-    chol_solve_reg(L.H, L.Hinv, x);
-    if (lane < NV) L.a0[lane] = pick8(x, lane);
+    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
+    if (lane < NV) L.a0[lane] = x;
   }
   // ---- this lane's constraint row (fixed slot) ----
   const int r = lane;
@@ -163,6 +153,7 @@ HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, i
       if (!(cost_ws < cost_a0)) { if (lane < NV) L.qacc[lane] = L.a0[lane]; }
       wave_sync();
     }
+    bool h_is_m = true;
 #pragma unroll 1
     for (int it = 0; it < m.solver_iters; it++) {
       const double y = rowdot(L.qacc) - aref;
@@ -194,16 +185,16 @@ HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, i
 #pragma unroll
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
       if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
-      const double hl = chol_lanes(hval, lane, &ok);
-      if (!ok) break;
-      chol_store(hl, lane, L.H, L.Hinv);
-      wave_sync();
+      if (__any(hh != 0) || !h_is_m) {  // no row with curvature: H == M and its factor is still in LDS
+        const double hl = chol_lanes(hval, lane, &ok);
+        if (!ok) break;
+        chol_store(hl, lane, L.H, L.Hinv);
+        h_is_m = false;
+        wave_sync();
+      }
       {
-        double x[NV];
-#pragma unroll
-        for (int i = 0; i < NV; i++) x[i] = -L.g[i];
-        chol_solve_reg(L.H, L.Hinv, x);
-        if (lane < NV) L.d[lane] = pick8(x, lane);
+        const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
+        if (lane < NV) L.d[lane] = x;
       }
       wave_sync();
       const double p = rowdot(L.d);
@@ -251,12 +242,9 @@ HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, i
   }
   wave_sync();
   {
-    double x[NV];
-#pragma unroll
-    for (int i = 0; i < NV; i++) x[i] = L.d[i];
-    chol_solve_reg(L.H, L.Hinv, x);
+    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.d[lane] : 0.0, lane);
     if (lane < NV) {
-      const double v = s.qvel[lane] + h * pick8(x, lane);
+      const double v = s.qvel[lane] + h * x;
       s.qvel[lane] = v;
       s.qpos[lane] = s.qpos[lane] + h * v;
     }
@@ -563,6 +551,13 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
       if ((desc->rcap_selfmask[i] >> j) & 1u) { hm->self_i[ns] = i; hm->self_j[ns] = j; ns++; }
   hm->n_self = ns;
   hm->phase_mask = 0xff;
+  {
+    double se, ve, ae;
+    path_plan(&hm->brake_full, 0.0, 1.0, 0.0, 0.0, desc->path_amax, desc->path_jmax);
+    hm->brake_T = path_total(&hm->brake_full);
+    path_eval(&hm->brake_full, hm->brake_T, 0.0, &se, &ve, &ae);
+    hm->brake_ds = se;
+  }
   if (const char* pm = getenv("HRG_PHASE_MASK")) hm->phase_mask = atoi(pm); // timing experiments only: results are invalid
   // clips
   const size_t fbytes = sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames;

@@ -56,22 +56,25 @@ HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane,
   wave_sync();
 }
 
-// mj_comPos / mj_crb / mj_rne(flg_acc=0) for the robot tree: joint subspaces, world inertias, composite
-// inertia -> dense 8x8 M (lanes = matrix entries), bias forces (serial recursion wave-uniform, per-body
-// force terms on lanes = bodies).  SURVEY.md Appendix B.1 position+velocity stages.
+// mj_comPos / mj_crb / mj_rne(flg_acc=0) for the robot tree (SURVEY.md Appendix B.1 position+velocity stages).
+// All spatial quantities are world-frame about the world origin, so nothing has to be transformed between bodies and
+// the tree recursions collapse into independent per-lane sums:
+//   lane = body i : velocity/acceleration = walk over the (<= 7) ancestors in registers; force of body i
+//   lane = body k : composite inertia and joint force = sums over the descendants of k
+//   lane = (i,j)  : M_ij = S_i . (Ic_j S_j)
+// -> three hand-offs through LDS, no serial LDS read-modify-write chains.
 HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
   const hrg_model_desc& m = dm->m;
+  double bI[10];  // this body's spatial inertia about the world origin (m, h, I)
   if (lane < NV) {
     const int i = lane;
     const double* R = L.kR[i];
-    double axw[3], t[3];
+    double axw[3], t[3], c[3];
     m3mulv(axw, R, m.jnt_axis[i]);
     if (i < NARM) { v3cpy(L.Sw[i], axw); v3cross(L.Sv[i], L.kp[i], axw); }
     else { v3set(L.Sw[i], 0, 0, 0); v3cpy(L.Sv[i], axw); }
     m3mulv(t, R, m.body_com[i]);
-    double c[3];
     v3add(c, L.kp[i], t);
-    v3cpy(L.com[i], c);
     const double* I = m.body_inertia[i];
     double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Rt[9], W[9];
 #pragma unroll
@@ -80,54 +83,58 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int
       for (int b = 0; b < 3; b++) Rt[3 * a + b] = R[3 * b + a];
     m3mul(T, R, Ib);
     m3mul(W, T, Rt);
-    double Iw[6] = {W[0], W[4], W[8], W[1], W[2], W[5]};
+    const double Iw[6] = {W[0], W[4], W[8], W[1], W[2], W[5]};
+    sinertia_body(bI, m.body_mass[i], c, Iw);
 #pragma unroll
-    for (int a = 0; a < 6; a++) L.Iw[i][a] = Iw[a];
-    sinertia_body(L.cI[i], m.body_mass[i], c, Iw);
+    for (int a = 0; a < 10; a++) L.cI[i][a] = bI[a];
   }
   wave_sync();
-  // ---- velocity recursion + composite inertia (wave-uniform serial passes) ----
-#pragma unroll 1
-  for (int i = NV - 1; i >= 1; i--) {
-    int par = m.body_parent[i];
-    for (int a = 0; a < 10; a++) L.cI[par][a] += L.cI[i][a];
-  }
-#pragma unroll 1
-  for (int i = 0; i < NV; i++) {
-    int par = m.body_parent[i];
-    double pw[3] = {0, 0, 0}, pv[3] = {0, 0, 0}, paw[3] = {0, 0, 0}, pav[3];
-    v3scl(pav, m.gravity, -1.0);
-    if (par >= 0) { v3cpy(pw, L.vw[par]); v3cpy(pv, L.vv[par]); v3cpy(paw, L.aw[par]); v3cpy(pav, L.av[par]); }
-    double jw[3], jv[3], vw[3], vv[3], t1[3], t2[3], t3[3], aw[3], av[3];
-    const double qd = L.st.qvel[i];
-    v3scl(jw, L.Sw[i], qd);
-    v3scl(jv, L.Sv[i], qd);
-    v3add(vw, pw, jw);
-    v3add(vv, pv, jv);
-    v3cross(t1, vw, jw);
-    v3cross(t2, vw, jv);
-    v3cross(t3, vv, jw);
-    v3add(aw, paw, t1);
-    v3add(av, pav, t2);
-    v3add(av, av, t3);
-    v3cpy(L.vw[i], vw); v3cpy(L.vv[i], vv); v3cpy(L.aw[i], aw); v3cpy(L.av[i], av);
-  }
-  // ---- per-body terms on lanes = bodies ----
   if (lane < NV) {
-    const int i = lane;
-    double n[3], f[3];
-    sinertia_mul(n, f, L.cI[i], L.Sw[i], L.Sv[i]);
-#pragma unroll
-    for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
-    double s[10], n1[3], f1[3], n2[3], f2[3], t1[3], t2[3], t3[3];
-    sinertia_body(s, m.body_mass[i], L.com[i], L.Iw[i]);
-    sinertia_mul(n1, f1, s, L.aw[i], L.av[i]);
-    sinertia_mul(n2, f2, s, L.vw[i], L.vv[i]);
-    v3cross(t1, L.vw[i], n2);
-    v3cross(t2, L.vv[i], f2);
-    v3cross(t3, L.vw[i], f2);
+    const int i = lane, anc = dm->anc_mask[i];
+    // ---- velocity / acceleration of body i: accumulate along the ancestor path (ancestors have smaller indices) ----
+    double vw[3] = {0, 0, 0}, vv[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, av[3];
+    v3scl(av, m.gravity, -1.0);
+#pragma unroll 1
+    for (int k = 0; k < NV; k++) {
+      if (!((anc >> k) & 1)) continue;
+      const double qd = L.st.qvel[k];
+      double jw[3], jv[3], t1[3], t2[3], t3[3];
+      v3scl(jw, L.Sw[k], qd);
+      v3scl(jv, L.Sv[k], qd);
+      v3add(vw, vw, jw);
+      v3add(vv, vv, jv);
+      v3cross(t1, vw, jw);
+      v3cross(t2, vw, jv);
+      v3cross(t3, vv, jw);
+      v3add(aw, aw, t1);
+      v3add(av, av, t2);
+      v3add(av, av, t3);
+    }
+    v3cpy(L.vw[i], vw);
+    v3cpy(L.vv[i], vv);
+    // ---- force of body i: f = I a + v x* (I v) ----
+    double n1[3], f1[3], n2[3], f2[3], t1[3], t2[3], t3[3];
+    sinertia_mul(n1, f1, bI, aw, av);
+    sinertia_mul(n2, f2, bI, vw, vv);
+    v3cross(t1, vw, n2);
+    v3cross(t2, vv, f2);
+    v3cross(t3, vw, f2);
 #pragma unroll
     for (int a = 0; a < 3; a++) { L.fn[i][a] = n1[a] + t1[a] + t2[a]; L.ff[i][a] = f1[a] + t3[a]; }
+    // ---- composite inertia of the subtree rooted at i, applied to the joint axis ----
+    double cc[10];
+#pragma unroll
+    for (int a = 0; a < 10; a++) cc[a] = bI[a];
+#pragma unroll 1
+    for (int k = i + 1; k < NV; k++) {
+      if (!((dm->anc_mask[k] >> i) & 1)) continue;
+#pragma unroll
+      for (int a = 0; a < 10; a++) cc[a] += L.cI[k][a];
+    }
+    double n[3], f[3];
+    sinertia_mul(n, f, cc, L.Sw[i], L.Sv[i]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
   }
   wave_sync();
   { // mass matrix: lane (i,j)
@@ -138,12 +145,18 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int
     if (i == j) v += m.jnt_armature[i];
     L.M[lane] = v;
   }
-  // bias: backward accumulation (wave-uniform)
+  if (lane < NV) { // bias force of joint k = S_k . (sum of the forces of the bodies in its subtree)
+    const int k = lane;
+    double sn[3], sf[3];
+    v3cpy(sn, L.fn[k]);
+    v3cpy(sf, L.ff[k]);
 #pragma unroll 1
-  for (int i = NV - 1; i >= 0; i--) {
-    L.bias[i] = v3dot(L.Sw[i], L.fn[i]) + v3dot(L.Sv[i], L.ff[i]);
-    int par = m.body_parent[i];
-    if (par >= 0) for (int a = 0; a < 3; a++) { L.fn[par][a] += L.fn[i][a]; L.ff[par][a] += L.ff[i][a]; }
+    for (int i = k + 1; i < NV; i++) {
+      if (!((dm->anc_mask[i] >> k) & 1)) continue;
+      v3add(sn, sn, L.fn[i]);
+      v3add(sf, sf, L.ff[i]);
+    }
+    L.bias[k] = v3dot(L.Sw[k], sn) + v3dot(L.Sv[k], sf);
   }
   wave_sync();
 }
@@ -263,11 +276,8 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, in
   const double dt = m.timestep, t = s.time;
   const bool shield_on = m.shield_type != HRG_SHIELD_OFF;
   const bool have_vel = s.n_meas >= 1 && t > s.meas_prev_t;
-  if (lane < NARM) {
-    double qq, q1, q2;
-    ltt_eval(&s.ltt, lane, s.path_s, &qq, &q1, &q2);
-    L.cq[lane] = qq; L.cv[lane] = q1 * s.path_v; L.ca[lane] = q1 * s.path_a + q2 * s.path_v * s.path_v;
-  }
+  // current motion = the Motion returned last cycle (same trajectory, same path state -> bitwise the same evaluation)
+  if (lane < NARM) { L.cq[lane] = s.des_q[lane]; L.cv[lane] = s.des_v[lane]; L.ca[lane] = s.des_a[lane]; }
   wave_sync();
   int use_cand = 0;
   if (s.new_goal) {
@@ -285,13 +295,25 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, in
   }
   const hrg_ltt* Lp = use_cand ? &L.cand : &s.ltt;
   const double ps = use_cand ? 0.0 : s.path_s, pv = use_cand ? 1.0 : s.path_v, pa = use_cand ? 0.0 : s.path_a;
-  hrg_path rec, fs2;
-  double s1, v1, a1, se, ve_, ae;
-  path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
-  path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
-  path_plan(&fs2, s1, v1, a1, 0.0, m.path_amax, m.path_jmax);
-  const double Tb = path_total(&fs2);
-  path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+  hrg_path fs2;
+  double s1, v1, a1, se, Tb;
+  if (pv == 1.0 && pa == 0.0) {
+    // steady state on the trajectory (the common case): the recovery step is s += dt and the fail-safe profile is the
+    // model constant "brake from full path speed" shifted to s1
+    s1 = ps + dt; v1 = 1.0; a1 = 0.0;
+    fs2 = dm->brake_full;
+    fs2.s0 = s1;
+    Tb = dm->brake_T;
+    se = s1 + dm->brake_ds;
+  } else {
+    hrg_path rec;
+    double ve_, ae;
+    path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
+    path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
+    path_plan(&fs2, s1, v1, a1, 0.0, m.path_amax, m.path_jmax);
+    Tb = path_total(&fs2);
+    path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+  }
   if (shield_on && lane < NARM) {
     double d1, d2, qv;
     ltt_eval(Lp, lane, se, &qv, &d1, &d2);
