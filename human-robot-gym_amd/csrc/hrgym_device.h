@@ -100,26 +100,51 @@ struct Lds {
   };
 };
 
+// The per-env LDS image is a file-scope __shared__ object: every device function addresses it directly (ds_* instructions),
+// nothing is passed around as a generic pointer.
+__shared__ Lds g_L;
+
+// Model constants are read through the CONSTANT address space from a wave-uniform base held in SGPRs, so that every
+// uniform-index access becomes a scalar load (s_load_*, scalar cache, SGPR destination) instead of a per-lane flat load.
+typedef const DevModel __attribute__((address_space(4)))* ModelPtr;
+DI ModelPtr uniform_model(const DevModel* dm) {
+  const unsigned long long a = (unsigned long long)dm;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(a & 0xffffffffull));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  return (ModelPtr)(((unsigned long long)hi << 32) | lo);
+}
+
 // ------------------------------------------------------------------------------------------------ math
+// read-only operands are templated on the pointer type so that LDS / constant / private operands keep their address space
 DI void v3set(double* r, double a, double b, double c) { r[0] = a; r[1] = b; r[2] = c; }
-DI void v3cpy(double* r, const double* a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
-DI void v3add(double* r, const double* a, const double* b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
-DI void v3sub(double* r, const double* a, const double* b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
-DI void v3scl(double* r, const double* a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
-DI void v3madd(double* r, const double* a, const double* b, double s) { r[0] = a[0] + b[0] * s; r[1] = a[1] + b[1] * s; r[2] = a[2] + b[2] * s; }
-DI double v3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
-DI double v3norm(const double* a) { return sqrt(v3dot(a, a)); }
-DI void v3cross(double* r, const double* a, const double* b) {
+template <class PA>
+DI void v3cpy(double* r, PA a) { r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; }
+template <class PA, class PB>
+DI void v3add(double* r, PA a, PB b) { r[0] = a[0] + b[0]; r[1] = a[1] + b[1]; r[2] = a[2] + b[2]; }
+template <class PA, class PB>
+DI void v3sub(double* r, PA a, PB b) { r[0] = a[0] - b[0]; r[1] = a[1] - b[1]; r[2] = a[2] - b[2]; }
+template <class PA>
+DI void v3scl(double* r, PA a, double s) { r[0] = a[0] * s; r[1] = a[1] * s; r[2] = a[2] * s; }
+template <class PA, class PB>
+DI void v3madd(double* r, PA a, PB b, double s) { r[0] = a[0] + b[0] * s; r[1] = a[1] + b[1] * s; r[2] = a[2] + b[2] * s; }
+template <class PA, class PB>
+DI double v3dot(PA a, PB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class PA>
+DI double v3norm(PA a) { return sqrt(v3dot(a, a)); }
+template <class PA, class PB>
+DI void v3cross(double* r, PA a, PB b) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
   r[0] = x; r[1] = y; r[2] = z;
 }
-DI void m3mulv(double* r, const double* M, const double* v) {
+template <class PA, class PB>
+DI void m3mulv(double* r, PA M, PB v) {
   double x = M[0] * v[0] + M[1] * v[1] + M[2] * v[2];
   double y = M[3] * v[0] + M[4] * v[1] + M[5] * v[2];
   double z = M[6] * v[0] + M[7] * v[1] + M[8] * v[2];
   r[0] = x; r[1] = y; r[2] = z;
 }
-DI void m3mul(double* R, const double* A, const double* B) {
+template <class PA, class PB>
+DI void m3mul(double* R, PA A, PB B) {
   double T[9];
 #pragma unroll
   for (int i = 0; i < 3; i++)
@@ -128,13 +153,15 @@ DI void m3mul(double* R, const double* A, const double* B) {
 #pragma unroll
   for (int i = 0; i < 9; i++) R[i] = T[i];
 }
-DI void quat2mat(double* M, const double* q) {
+template <class PA>
+DI void quat2mat(double* M, PA q) {
   double w = q[0], x = q[1], y = q[2], z = q[3];
   M[0] = 1 - 2 * (y * y + z * z); M[1] = 2 * (x * y - w * z); M[2] = 2 * (x * z + w * y);
   M[3] = 2 * (x * y + w * z); M[4] = 1 - 2 * (x * x + z * z); M[5] = 2 * (y * z - w * x);
   M[6] = 2 * (x * z - w * y); M[7] = 2 * (y * z + w * x); M[8] = 1 - 2 * (x * x + y * y);
 }
-DI void quatmul(double* r, const double* a, const double* b) {
+template <class PA, class PB>
+DI void quatmul(double* r, PA a, PB b) {
   double w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3];
   double x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2];
   double y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1];
@@ -156,7 +183,8 @@ DI void sincos_small(double x, double* sn, double* cs) {
   *sn = (q & 2) ? -s0 : s0;
   *cs = ((q + 1) & 2) ? -c0 : c0;
 }
-DI void axisangle2mat(double* M, const double* ax, double ang) {
+template <class PA>
+DI void axisangle2mat(double* M, PA ax, double ang) {
   double s, c;
   sincos_small(ang, &s, &c);
   double t = 1 - c, x = ax[0], y = ax[1], z = ax[2];
@@ -218,7 +246,8 @@ DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, u
 
 // ------------------------------------------------------------------------------------------------ segments
 // closest points of two segments; returns squared distance (Ericson 5.1.9)
-DI double seg_seg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) {
+template <class PA, class PB, class PC, class PD>
+DI double seg_seg(PA p1, PB q1, PC p2, PD q2, double* c1, double* c2) {
   double d1[3], d2[3], r[3];
   v3sub(d1, q1, p1);
   v3sub(d2, q2, p2);
@@ -366,7 +395,8 @@ __host__ DI void path_eval(const hrg_path* P, double t, double ve, double* s, do
 }
 
 // ------------------------------------------------------------------------------------------------ spatial inertia
-DI void sinertia_body(double* s /*10*/, double m, const double* c, const double* Ic) {
+template <class PA, class PB>
+DI void sinertia_body(double* s /*10*/, double m, PA c, PB Ic) {
   s[0] = m;
   s[1] = c[0] * m; s[2] = c[1] * m; s[3] = c[2] * m;
   double cc = v3dot(c, c);
@@ -377,7 +407,8 @@ DI void sinertia_body(double* s /*10*/, double m, const double* c, const double*
   s[8] = Ic[4] - m * c[0] * c[2];
   s[9] = Ic[5] - m * c[1] * c[2];
 }
-DI void sinertia_mul(double* n, double* f, const double* s, const double* w, const double* v) {
+template <class PA, class PB, class PC>
+DI void sinertia_mul(double* n, double* f, PA s, PB w, PC v) {
   double hv[3], hw[3];
   v3cross(hv, s + 1, v);
   v3cross(hw, s + 1, w);

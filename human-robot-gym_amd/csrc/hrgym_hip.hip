@@ -16,7 +16,8 @@
 // constraints (friction loss, joint limits, pyramidal contacts) by primal Newton + exact line search,
 // semi-implicit Euler with implicit joint damping.  Lanes = constraint rows in fixed slots:
 //   0..7 friction loss of dof r | 8..23 joint limit (dof, lo/hi) | 24..63 contact c, pyramid edge d.
-DI void impedance(const hrg_model_desc& m, double x0, double* imp, double* K, double* Bd) {
+template <class MD>
+DI void impedance(const MD& m, double x0, double* imp, double* K, double* Bd) {
   const double d0 = m.solimp[0], dmax = m.solimp[1], width = m.solimp[2], mid = m.solimp[3], power = m.solimp[4];
   const double x = fabs(x0) / width;
   double y;
@@ -44,8 +45,10 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
 }
 
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
-HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, int ncon) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   const double h = m.timestep;
   const int mi = lane >> 3, mj = lane & 7;
@@ -254,8 +257,8 @@ HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm, Lds& L, int lane, i
 }
 
 // ================================================================================================ env
-DI void goal_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int idx, double* g) {
-  const hrg_model_desc& m = dm->m;
+DI void goal_of(ModelPtr dm, int64_t gid, int episode, int idx, double* g) {
+  const auto& m = dm->m;
   for (int j = 0; j < NARM; j++) {
     const double u = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_GOAL, (uint64_t)(idx * NARM + j));
     g[j] = m.qpos_limits[0][j] + (m.qpos_limits[1][j] - m.qpos_limits[0][j]) * u;
@@ -264,8 +267,10 @@ DI void goal_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int i
 
 // observation: object-state (vec/dist eef -> L hand, R hand, head; human_env.py:1536-1590) + goal_difference
 // (environments/manipulation/reach_human_env.py:649-651); lanes = observation entries
-DI void write_obs(const DevModel* __restrict__ dm, const Lds& L, int lane, const double* goal, float* out) {
-  const hrg_model_desc& m = dm->m;
+DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal, float* out) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   const hrg_env_state& s = L.st;
   if (lane < HRG_OBS_DIM) {
     double v;
@@ -280,7 +285,9 @@ DI void write_obs(const DevModel* __restrict__ dm, const Lds& L, int lane, const
   }
 }
 
-DI void eef_update(const DevModel* __restrict__ dm, Lds& L) {
+DI void eef_update(const DevModel* __restrict__ dm_) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
   double t[3], e[3];
   m3mulv(t, L.kR[NARM - 1], dm->m.eef_pos);
   v3add(e, L.kp[NARM - 1], t);
@@ -289,8 +296,10 @@ DI void eef_update(const DevModel* __restrict__ dm, Lds& L) {
 
 // HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
 // + FailsafeController.reset (failsafe_controller.py:204-250)
-HRG_PHASE void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid, float* obs_out) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid, float* obs_out) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   const int episode = s.episode + 1;
   wave_sync();
@@ -309,24 +318,26 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm, Lds& L, int lane, int6
   s.animation_time = -1;
   wave_sync();
   const double p0[3] = {0, 0, 0}, q0[4] = {1, 0, 0, 0};
-  human_fk_lanes(dm, L, lane, p0, q0, nullptr);
-  robot_chain_fk(dm, L, lane, false);
-  eef_update(dm, L);
-  shield_reset(dm, L, lane);
+  human_fk_lanes(dm_, lane, p0, q0, nullptr);
+  robot_chain_fk(dm_, lane, false);
+  eef_update(dm_);
+  shield_reset(dm_, lane);
   wave_sync();
   if (obs_out) {
     double g[NARM];
     goal_of(dm, gid, episode, 0, g);
-    write_obs(dm, L, lane, g, obs_out);
+    write_obs(dm_, lane, g, obs_out);
   }
   wave_sync();
 }
 
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
-DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64_t gid, const double* __restrict__ action, float* obs, float* term_obs,
+DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, const double* __restrict__ action, float* obs, float* term_obs,
                  float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
-  const hrg_model_desc& m = dm->m;
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   s.timestep = s.timestep + 1;
   int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
@@ -347,8 +358,8 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
     }
     // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
     const int pm = dm->phase_mask;
-    if (pm & 1) shield_step(dm, L, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm, L, lane, false);
-    if (pm & 2) robot_dynamics_terms(dm, L, lane);
+    if (pm & 1) shield_step(dm_, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm_, lane, false);
+    if (pm & 2) robot_dynamics_terms(dm_, lane);
     if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
       if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
       wave_sync();
@@ -371,21 +382,21 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
     }
     if (!failsafe_intervention && !s.is_safe) { failsafe_intervention = 1; s.failsafe_interventions = s.failsafe_interventions + 1; }
     wave_sync();
-    if (pm & 4) human_control(dm, L, lane, gid); // _control_human + kinematics of sim.forward() #2
+    if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
     int ncon = 0;
-    if (pm & 8) collide(dm, L, lane, &ncon);
-    classify(dm, L, ncon, &has_collision, &collision_type);
-    if (pm & 16) crash = dynamics_step(dm, L, lane, ncon);
+    if (pm & 8) collide(dm_, lane, &ncon);
+    classify(dm_, ncon, &has_collision, &collision_type);
+    if (pm & 16) crash = dynamics_step(dm_, lane, ncon);
     if (crash) break;
     s.time = s.time + m.timestep;
-    eef_update(dm, L);
+    eef_update(dm_);
     s.low_level_time = s.low_level_time + 1;
     wave_sync();
   }
   // ---- observation / success / info / reward / done ----
   double goal[NARM];
   goal_of(dm, gid, s.episode, s.goal_index, goal);
-  write_obs(dm, L, lane, goal, term_obs);
+  write_obs(dm_, lane, goal, term_obs);
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
   const double dist = sqrt(dist2);
@@ -426,15 +437,15 @@ DI void env_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, int64
   }
   if (lane == 0) { *reward = (float)r; *done = (uint8_t)d; }
   wave_sync();
-  if (d) env_reset(dm, L, lane, gid, obs);
-  else write_obs(dm, L, lane, goal, obs);
+  if (d) env_reset(dm_, lane, gid, obs);
+  else write_obs(dm_, lane, goal, obs);
 }
 
 // ================================================================================================ kernels
 __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs) {
-  __shared__ Lds L;
+  Lds& L = g_L;
   const int e = blockIdx.x, lane = threadIdx.x;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
@@ -442,7 +453,7 @@ __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevMo
   for (int k = lane; k < NW; k += 64) dst[k] = src[k];
   wave_sync();
   float* tobs = term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : scratch_obs + (size_t)e * HRG_OBS_DIM;
-  env_step(dm, L, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
+  env_step(dm, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
            info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh);
   wave_sync();
   double* out = (double*)(states + e);
@@ -451,7 +462,7 @@ __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevMo
 
 __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
                                                       float* __restrict__ obs, int64_t env_id0) {
-  __shared__ Lds L;
+  Lds& L = g_L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[e]) return;
   const double* src = (const double*)(states + e);
@@ -459,7 +470,7 @@ __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_reset_kernel(const DevM
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
   for (int k = lane; k < NW; k += 64) dst[k] = src[k];
   wave_sync();
-  env_reset(dm, L, lane, env_id0 + e, obs ? obs + (size_t)e * HRG_OBS_DIM : nullptr);
+  env_reset(dm, lane, env_id0 + e, obs ? obs + (size_t)e * HRG_OBS_DIM : nullptr);
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];

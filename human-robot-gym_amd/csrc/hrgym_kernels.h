@@ -7,9 +7,11 @@
 // Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
 // 1 = configuration at the end of the fail-safe brake (both feed RobotReach), 2 = simulation state
 // (mj_kinematics of sim.forward(), environments/manipulation/human_env.py:504).
-HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane, bool shield_on) {
+HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_on) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
   if (lane < 3 && (lane == 2 || shield_on)) {
-    const hrg_model_desc& m = dm->m;
+    const auto& m = dm->m;
     const int cfg = lane;
     double R[9], p[3];
 #pragma unroll
@@ -63,8 +65,10 @@ HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm, Lds& L, int lane,
 //   lane = body k : composite inertia and joint force = sums over the descendants of k
 //   lane = (i,j)  : M_ij = S_i . (Ic_j S_j)
 // -> three hand-offs through LDS, no serial LDS read-modify-write chains.
-HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int lane) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   double bI[10];  // this body's spatial inertia about the world origin (m, h, I)
   if (lane < NV) {
     const int i = lane;
@@ -75,7 +79,7 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int
     else { v3set(L.Sw[i], 0, 0, 0); v3cpy(L.Sv[i], axw); }
     m3mulv(t, R, m.body_com[i]);
     v3add(c, L.kp[i], t);
-    const double* I = m.body_inertia[i];
+    const auto* I = m.body_inertia[i];
     double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Rt[9], W[9];
 #pragma unroll
     for (int a = 0; a < 3; a++)
@@ -161,7 +165,8 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm, Lds& L, int
   wave_sync();
 }
 
-DI void robot_point_vel(const Lds& L, int b, const double* r, double* v) {
+DI void robot_point_vel(int b, const double* r, double* v) {
+  Lds& L = g_L;
   if (b < 0) { v3set(v, 0, 0, 0); return; }
   double t[3];
   v3cross(t, L.vw[b], r);
@@ -170,14 +175,16 @@ DI void robot_point_vel(const Lds& L, int b, const double* r, double* v) {
 
 // ================================================================================================ human
 // HumanEnv._control_human (human_env.py:1710-1767) + kinematics of the 24-body tree on lanes = bodies.
-DI int clip_of(const DevModel* __restrict__ dm, int64_t gid, int episode, int anim_index) {
+DI int clip_of(ModelPtr dm, int64_t gid, int episode, int anim_index) {
   double u = rng_u01(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_ANIM, (uint64_t)anim_index);
   int c = (int)(u * dm->m.n_clips);
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
 }
 
-HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   const int b = lane < HRG_NHB ? lane : 0;
   double R[9], p[3], Rloc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, anchor[3];
   v3cpy(anchor, m.hb_anchor[b]);
@@ -236,8 +243,10 @@ HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm, Lds& L, int lane,
   wave_sync();
 }
 
-HRG_PHASE void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, int64_t gid) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   // human_env.py:1719-1731 (wave-uniform)
   int control_time = (int)floor((double)s.low_level_time / m.anim_step_length);
@@ -263,15 +272,17 @@ HRG_PHASE void human_control(const DevModel* __restrict__ dm, Lds& L, int lane, 
   double qa[4] = {fr[6], fr[3], fr[4], fr[5]};
   quatmul(q1, s.human_rot_offset, qbi);
   quatmul(mq, q1, qa);
-  human_fk_lanes(dm, L, lane, mp, mq, fr + 7);
+  human_fk_lanes(dm_, lane, mp, mq, fr + 7);
 }
 
 // ================================================================================================ shield
 // SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
 // restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
 // human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
-HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   const double dt = m.timestep, t = s.time;
   const bool shield_on = m.shield_type != HRG_SHIELD_OFF;
@@ -301,8 +312,8 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, in
     // steady state on the trajectory (the common case): the recovery step is s += dt and the fail-safe profile is the
     // model constant "brake from full path speed" shifted to s1
     s1 = ps + dt; v1 = 1.0; a1 = 0.0;
-    fs2 = dm->brake_full;
-    fs2.s0 = s1;
+    fs2.s0 = s1; fs2.v0 = 1.0; fs2.a0 = 0.0; fs2.k = 0.0;
+    for (int a = 0; a < 3; a++) { fs2.dur[a] = dm->brake_full.dur[a]; fs2.jerk[a] = dm->brake_full.jerk[a]; }
     Tb = dm->brake_T;
     se = s1 + dm->brake_ds;
   } else {
@@ -320,7 +331,7 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, in
     L.qe[lane] = qv;
   }
   wave_sync();
-  robot_chain_fk(dm, L, lane, shield_on);
+  robot_chain_fk(dm_, lane, shield_on);
   int safe = 1;
   if (shield_on) {
     const double sdiff = se - ps;
@@ -413,7 +424,9 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm, Lds& L, int lane, in
   wave_sync();
 }
 
-DI void shield_reset(const DevModel* __restrict__ dm, Lds& L, int lane) {
+DI void shield_reset(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
   hrg_env_state& s = L.st;
   // ltt_const + zero paths: the state block was zeroed by the caller
   if (lane < NARM) {
@@ -426,13 +439,15 @@ DI void shield_reset(const DevModel* __restrict__ dm, Lds& L, int lane) {
 
 // ================================================================================================ contacts
 // Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
-HRG_PHASE void collide(const DevModel* __restrict__ dm, Lds& L, int lane, int* ncon_out) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   if (lane < HRG_NRCAP) {
     const int c = lane, b = m.rcap_body[c];
-    const double* R = b < 0 ? dm->Rbase : L.kR[b];
-    const double* p = b < 0 ? m.base_pos : L.kp[b];
-    double t[3], mid[3];
+    double R[9], p[3], t[3], mid[3];
+    if (b < 0) { for (int a = 0; a < 9; a++) R[a] = dm->Rbase[a]; v3cpy(p, m.base_pos); }
+    else { for (int a = 0; a < 9; a++) R[a] = L.kR[b][a]; v3cpy(p, L.kp[b]); }
     m3mulv(t, R, m.rcap_p1[c]); v3add(&L.rcapw[c][0], p, t);
     m3mulv(t, R, m.rcap_p2[c]); v3add(&L.rcapw[c][3], p, t);
     for (int a = 0; a < 3; a++) mid[a] = 0.5 * (m.rcap_p1[c][a] + m.rcap_p2[c][a]);
@@ -513,8 +528,10 @@ DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TAB
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
-HRG_PHASE void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* has_collision, int* collision_type) {
-  const hrg_model_desc& m = dm->m;
+HRG_PHASE void classify(const DevModel* __restrict__ dm_, int ncon, int* has_collision, int* collision_type) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
   hrg_env_state& s = L.st;
   int cur[HRG_NPREV_MAX], ncur = 0;
   const double tm = s.debounce_timer - m.timestep;
@@ -537,7 +554,7 @@ HRG_PHASE void classify(const DevModel* __restrict__ dm, Lds& L, int ncon, int* 
       if (deb > 0) continue;
       deb = m.collision_debounce_delay;
       double v[3];
-      robot_point_vel(L, m.rcap_body[rg], L.rcen[rg], v);
+      robot_point_vel(m.rcap_body[rg], L.rcen[rg], v);
       if (v3norm(v) <= m.safe_vel) { *collision_type |= HRG_COL_HUMAN; s.n_collisions_human = s.n_collisions_human + 1; }
       else { *collision_type |= HRG_COL_HUMAN_CRIT; s.n_collisions_critical = s.n_collisions_critical + 1; }
     } else { *collision_type |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + 1; }
