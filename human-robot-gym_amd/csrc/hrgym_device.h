@@ -35,11 +35,37 @@
 #else
 #define HRG_PHASE __device__ __forceinline__
 #endif
+// phases that need more than the ~78 caller-saved VGPRs would save/restore callee-saved registers on every call
+// (scratch traffic): HRG_BIGINLINE=1 inlines those into the kernel instead
+// HRG_CYCLEFN=1: one real function per shield cycle (all phases inlined inside it) instead of one per phase
+#ifndef HRG_CYCLEFN
+#define HRG_CYCLEFN 0
+#endif
+#ifndef HRG_BIGINLINE
+#define HRG_BIGINLINE 0
+#endif
+#if HRG_BIGINLINE
+#define HRG_BIGPHASE __device__ __forceinline__
+#else
+#define HRG_BIGPHASE HRG_PHASE
+#endif
 #define HRG_PI 3.14159265358979323846
 
 #define GEOM_HUMAN0 HRG_NRCAP
 #define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
 #define GEOM_FLOOR (GEOM_TABLE + 1)
+
+// ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
+#ifdef HRG_STAMPS
+__device__ unsigned long long g_stamps[32];
+#define STAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(), _t1, _acc[20] = {0}
+#define STAMP(k) do { _t1 = __builtin_amdgcn_s_memtime(); _acc[k] += _t1 - _t0; _t0 = _t1; } while (0)
+#define STAMP_FLUSH(lane) do { if ((lane) == 0) for (int _k = 0; _k < 20; _k++) atomicAdd(&g_stamps[_k], _acc[_k]); } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(k)
+#define STAMP_FLUSH(lane)
+#endif
 
 // ------------------------------------------------------------------------------------------------ model
 struct DevModel {
@@ -78,7 +104,9 @@ struct Lds {
   // robot tree at the simulation state (live across the whole cycle)
   double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], vw[NV][3], vv[NV][3];
   double M[NV * NV], H[NV * NV], Hinv[NV];
-  double bias[NV], a0[NV], Ma0[NV], ctrl[NV], qacc[NV], g[NV], d[NV], Md[NV];
+  double bias[NV], a0[NV], Ma0[NV], ctrl[NV], qacc[NV], g[NV], d[NV];
+  double act[NV];                        // this step's action (7 used)
+  int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators
   double rcen[HRG_NRCAP][3];
   Contact con[HRG_NCON_DYN];
   union {
@@ -93,6 +121,7 @@ struct Lds {
     };
     struct {  // human_control + collide
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
+      int cur[HRG_NPREV_MAX];
     };
     struct {  // dynamics_step: contact rows of J (padded to 9: conflict-free ds_read_b64), per-row gradient / curvature
       double Jc[4 * HRG_NCON_DYN][NV + 1], rg[NROW], rh[NROW];
@@ -323,12 +352,24 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
     w = w_hi;
     tc = w > 0 ? (Dm - dist_nocruise(vm, w, amax, jmax)) / w : 0;
   } else {
+    /* root of the increasing function f(w) = dist_nocruise(vm, w) - Dm on [w_lo, w_hi]: Newton with the analytic
+     * derivative, safeguarded by the bracket (falls back to bisection when a step leaves it) */
     double lo = w_lo, hi = w_hi;
-    for (int it = 0; it < 64; it++) {
-      double mid = 0.5 * (lo + hi);
-      if (dist_nocruise(vm, mid, amax, jmax) <= Dm) lo = mid; else hi = mid;
+    const double vtri = amax * amax / jmax;
+    w = 0.5 * (lo + hi);
+    for (int it = 0; it < 80; it++) {
+      const double d1 = w - vm, T1 = scurve_time(d1, amax, jmax), T2 = scurve_time(w, amax, jmax);
+      const double f = 0.5 * (vm + w) * T1 + 0.5 * w * T2 - Dm;
+      if (f <= 0) lo = w; else hi = w;
+      const double T1p = fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / sqrt(jmax * fabs(d1)) : 0.0);
+      const double T2p = fabs(w) >= vtri ? 1.0 / amax : (fabs(w) > 0 ? 1.0 / sqrt(jmax * fabs(w)) : 0.0);
+      const double fp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
+      double nw = fp > 0 ? w - f / fp : 0.5 * (lo + hi);
+      if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);
+      const double step = fabs(nw - w);
+      w = nw;
+      if (step <= 4e-16 * (1.0 + fabs(w)) || hi - lo <= 4e-16 * (1.0 + hi)) break;
     }
-    w = lo;
   }
   scurve(v, sg * w, amax, jmax, dur + n, jerk + n);
   n += 3;

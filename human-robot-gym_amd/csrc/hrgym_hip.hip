@@ -45,7 +45,7 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
 }
 
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
-HRG_PHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
+HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -331,6 +331,83 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   wave_sync();
 }
 
+// one shield cycle (human_env.py:503-526): controller goal on policy steps, shield, dynamics terms, PD+ torque,
+// human playback, contacts, integration.  Returns 1 when the simulation diverged.
+#if HRG_CYCLEFN
+__device__ __noinline__
+#else
+DI
+#endif
+int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  STAMP_DECL;
+  if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
+    if (lane < NARM) {
+      const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
+      const double otr = 0.5 * (m.act_out_max + m.act_out_min), itr = 0.5 * (m.act_in_max + m.act_in_min);
+      const double a = clampd(L.act[lane], m.act_in_min, m.act_in_max);
+      const double g = clampd(s.qpos[lane] + ((a - itr) * scale + otr), m.qpos_limits[0][lane], m.qpos_limits[1][lane]);
+      s.goal_qpos[lane] = g;
+      s.new_goal_q[lane] = g;
+    }
+    s.new_goal = 1;
+    wave_sync();
+  }
+  // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
+  const int pm = dm->phase_mask;
+  if (pm & 1) shield_step(dm_, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm_, lane, false);
+  STAMP(1);
+  if (pm & 2) robot_dynamics_terms(dm_, lane);
+  STAMP(2);
+  if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
+    if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
+    wave_sync();
+  }
+  if (lane < NARM) { // run_controller, failsafe_controller.py:356-369
+    double t = 0;
+    for (int j = 0; j < NARM; j++) t += s.mass_matrix[lane * NARM + j] * (m.kp * (s.des_q[j] - s.qpos[j]) + m.kd * (s.des_v[j] - s.qvel[j]) + s.des_a[j]);
+    const double tq = clampd(t + L.bias[lane], m.arm_ctrlrange[lane][0], m.arm_ctrlrange[lane][1]);
+    L.ctrl[lane] = tq;
+  }
+  { // gripper: RethinkGripper.format_action + ctrl-range mapping
+    const double grip_a = L.act[NARM];
+    const double sg = grip_a > 0 ? 1.0 : (grip_a < 0 ? -1.0 : 0.0);
+    const double ga = clampd(s.grip_action + m.gripper_speed * sg, -1.0, 1.0);
+    wave_sync();
+    s.grip_action = ga;
+    if (lane < HRG_NFINGER) {
+      const double lo = m.finger_ctrlrange[lane][0], hi = m.finger_ctrlrange[lane][1];
+      L.ctrl[NARM + lane] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (lane == 0 ? ga : -ga);
+    }
+  }
+  if (!L.acc_failsafe && !s.is_safe) { L.acc_failsafe = 1; s.failsafe_interventions = s.failsafe_interventions + 1; }
+  wave_sync();
+  STAMP(3);
+  if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
+  STAMP(4);
+  int ncon = 0;
+  if (pm & 8) collide(dm_, lane, &ncon);
+  STAMP(5);
+  int hc = L.acc_has_collision, ct = L.acc_collision_type;
+  classify(dm_, ncon, &hc, &ct);
+  L.acc_has_collision = hc; L.acc_collision_type = ct;
+  STAMP(6);
+  int crash = 0;
+  if (pm & 16) crash = dynamics_step(dm_, lane, ncon);
+  STAMP(7);
+  if (!crash) {
+    s.time = s.time + m.timestep;
+    eef_update(dm_);
+    s.low_level_time = s.low_level_time + 1;
+  }
+  wave_sync();
+  STAMP_FLUSH(lane);
+  return crash;
+}
+
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
 DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, const double* __restrict__ action, float* obs, float* term_obs,
@@ -340,59 +417,13 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
   s.timestep = s.timestep + 1;
-  int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
-  double act = lane < HRG_ACT_DIM ? action[lane] : 0.0;
-  const double grip_a = __shfl(act, NARM, 64);
-  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) {
-    if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
-      if (lane < NARM) {
-        const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
-        const double otr = 0.5 * (m.act_out_max + m.act_out_min), itr = 0.5 * (m.act_in_max + m.act_in_min);
-        const double a = clampd(act, m.act_in_min, m.act_in_max);
-        const double g = clampd(s.qpos[lane] + ((a - itr) * scale + otr), m.qpos_limits[0][lane], m.qpos_limits[1][lane]);
-        s.goal_qpos[lane] = g;
-        s.new_goal_q[lane] = g;
-      }
-      s.new_goal = 1;
-      wave_sync();
-    }
-    // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
-    const int pm = dm->phase_mask;
-    if (pm & 1) shield_step(dm_, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm_, lane, false);
-    if (pm & 2) robot_dynamics_terms(dm_, lane);
-    if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
-      if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
-      wave_sync();
-    }
-    if (lane < NARM) { // run_controller, failsafe_controller.py:356-369
-      double t = 0;
-      for (int j = 0; j < NARM; j++) t += s.mass_matrix[lane * NARM + j] * (m.kp * (s.des_q[j] - s.qpos[j]) + m.kd * (s.des_v[j] - s.qvel[j]) + s.des_a[j]);
-      const double tq = clampd(t + L.bias[lane], m.arm_ctrlrange[lane][0], m.arm_ctrlrange[lane][1]);
-      L.ctrl[lane] = tq;
-    }
-    { // gripper: RethinkGripper.format_action + ctrl-range mapping
-      const double sg = grip_a > 0 ? 1.0 : (grip_a < 0 ? -1.0 : 0.0);
-      const double ga = clampd(s.grip_action + m.gripper_speed * sg, -1.0, 1.0);
-      wave_sync();
-      s.grip_action = ga;
-      if (lane < HRG_NFINGER) {
-        const double lo = m.finger_ctrlrange[lane][0], hi = m.finger_ctrlrange[lane][1];
-        L.ctrl[NARM + lane] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (lane == 0 ? ga : -ga);
-      }
-    }
-    if (!failsafe_intervention && !s.is_safe) { failsafe_intervention = 1; s.failsafe_interventions = s.failsafe_interventions + 1; }
-    wave_sync();
-    if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
-    int ncon = 0;
-    if (pm & 8) collide(dm_, lane, &ncon);
-    classify(dm_, ncon, &has_collision, &collision_type);
-    if (pm & 16) crash = dynamics_step(dm_, lane, ncon);
-    if (crash) break;
-    s.time = s.time + m.timestep;
-    eef_update(dm_);
-    s.low_level_time = s.low_level_time + 1;
-    wave_sync();
-  }
+  int has_collision = 0, collision_type = HRG_COL_NULL, crash = 0;
+  if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
+  L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
+  wave_sync();
+#pragma unroll 1
+  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) crash = cycle_body(dm_, lane, e, gid, cyc, dbg_r, dbg_h, dbg_nh);
+  has_collision = L.acc_has_collision; collision_type = L.acc_collision_type;
   // ---- observation / success / info / reward / done ----
   double goal[NARM];
   goal_of(dm, gid, s.episode, s.goal_index, goal);
@@ -675,6 +706,16 @@ int hrg_batch_enable_taps(hrg_batch* b, int32_t on) {
   b->taps = on != 0;
   return HRG_OK;
 }
+
+#ifdef HRG_STAMPS
+int hrg_debug_stamps(double* out, int reset) {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < 32; i++) out[i] = (double)h[i];
+  if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
+  return 0;
+}
+#endif
 
 int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");

@@ -7,7 +7,7 @@
 // Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
 // 1 = configuration at the end of the fail-safe brake (both feed RobotReach), 2 = simulation state
 // (mj_kinematics of sim.forward(), environments/manipulation/human_env.py:504).
-HRG_PHASE void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_on) {
+DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_on) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   if (lane < 3 && (lane == 2 || shield_on)) {
@@ -181,7 +181,7 @@ DI int clip_of(ModelPtr dm, int64_t gid, int episode, int anim_index) {
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
 }
 
-HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -243,7 +243,7 @@ HRG_PHASE void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const 
   wave_sync();
 }
 
-HRG_PHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -279,7 +279,7 @@ HRG_PHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t
 // SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
 // restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
 // human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
-HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -287,6 +287,7 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
   const double dt = m.timestep, t = s.time;
   const bool shield_on = m.shield_type != HRG_SHIELD_OFF;
   const bool have_vel = s.n_meas >= 1 && t > s.meas_prev_t;
+  STAMP_DECL;
   // current motion = the Motion returned last cycle (same trajectory, same path state -> bitwise the same evaluation)
   if (lane < NARM) { L.cq[lane] = s.des_q[lane]; L.cv[lane] = s.des_v[lane]; L.ca[lane] = s.des_a[lane]; }
   wave_sync();
@@ -304,6 +305,7 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     }
     wave_sync();
   }
+  STAMP(10);
   const hrg_ltt* Lp = use_cand ? &L.cand : &s.ltt;
   const double ps = use_cand ? 0.0 : s.path_s, pv = use_cand ? 1.0 : s.path_v, pa = use_cand ? 0.0 : s.path_a;
   hrg_path fs2;
@@ -325,13 +327,16 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     Tb = path_total(&fs2);
     path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
   }
+  STAMP(11);
   if (shield_on && lane < NARM) {
     double d1, d2, qv;
     ltt_eval(Lp, lane, se, &qv, &d1, &d2);
     L.qe[lane] = qv;
   }
   wave_sync();
+  STAMP(12);
   robot_chain_fk(dm_, lane, shield_on);
+  STAMP(13);
   int safe = 1;
   if (shield_on) {
     const double sdiff = se - ps;
@@ -394,6 +399,7 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     safe = !(hitA && hitV && hitP);
   }
   wave_sync();
+  STAMP(14);
   // humanMeasurement bookkeeping: previous measurement <- current sites
   for (int k = lane; k < HRG_NHJ * 3; k += 64) (&s.meas_prev[0][0])[k] = (&s.human_site[0][0])[k];
   s.meas_prev_t = t;
@@ -422,6 +428,8 @@ HRG_PHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     s.des_q[lane] = qq; s.des_v[lane] = q1 * s.path_v; s.des_a[lane] = q1 * s.path_a + q2 * s.path_v * s.path_v;
   }
   wave_sync();
+  STAMP(15);
+  STAMP_FLUSH(lane);
 }
 
 DI void shield_reset(const DevModel* __restrict__ dm_, int lane) {
@@ -533,7 +541,8 @@ HRG_PHASE void classify(const DevModel* __restrict__ dm_, int ncon, int* has_col
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
-  int cur[HRG_NPREV_MAX], ncur = 0;
+  int* cur = L.cur;  // scratch in the (dead) collide area of the LDS union
+  int ncur = 0;
   const double tm = s.debounce_timer - m.timestep;
   double deb = tm > 0 ? tm : 0;
   const int n_prev = s.n_prev;

@@ -1,0 +1,23 @@
+"""Diagnostic: per-phase share of wave cycles from the -DHRG_STAMPS build (human-robot-gym_amd/variant_stamps.so)."""
+import os, sys, ctypes, numpy as np
+os.environ["HRG_LIB_PATH"] = os.path.abspath("human-robot-gym_amd/variant_stamps.so")
+sys.path.insert(0, '.')
+import torch
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd._lib import HipBatch, load_library
+lib = load_library()
+clips = hrg.synthetic_clips(13, seed=0)
+kw = dict(shield_type=sys.argv[1] if len(sys.argv) > 1 else "SSM", control_freq=10, horizon=100, done_at_success=True, reward_shaping=True, seed=1234)
+G = HipBatch(hrg.build_model_desc(kw, n_clips=13), clips, 4096); G.reset()
+gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+acts = [torch.rand((4096, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(16)]
+out = np.zeros(32)
+for k in range(150): G.step(acts[k % 16])
+torch.cuda.synchronize(); lib.hrg_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
+for k in range(50): G.step(acts[k % 16])
+torch.cuda.synchronize(); lib.hrg_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
+names = {0: "loop/ctrl prev", 1: "shield_step (total)", 2: "robot_dynamics_terms", 3: "controller", 4: "human_control", 5: "collide", 6: "classify", 7: "dynamics_step", 8: "epilogue", 9: "reset/obs",
+         10: " shield: cur+plan", 11: " shield: paths", 12: " shield: qe eval", 13: " shield: chain fk", 14: " shield: reach+verify", 15: " shield: update+des"}
+tot = out[:10].sum()
+for k in range(16):
+    print("%-26s %6.2f %%  (%.0f cycles/env-step)" % (names.get(k, k), 100 * out[k] / tot, out[k] / (50 * 4096)))
