@@ -138,8 +138,11 @@ __shared__ Lds g_L;
 typedef const DevModel __attribute__((address_space(4)))* ModelPtr;
 DI ModelPtr uniform_model(const DevModel* dm) {
   const unsigned long long a = (unsigned long long)dm;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(a & 0xffffffffull));
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(a & 0xffffffffull));
+  unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  // opaque to the optimiser: model loads are re-issued where they are used (cheap scalar-cache hits) instead of being
+  // hoisted out of the 25-cycle loop and kept live in SGPRs, which would spill
+  asm volatile("" : "+s"(lo), "+s"(hi));
   return (ModelPtr)(((unsigned long long)hi << 32) | lo);
 }
 

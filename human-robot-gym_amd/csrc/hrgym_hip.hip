@@ -339,6 +339,8 @@ __device__ __noinline__
 DI
 #endif
 int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+  // opaque per cycle: nothing derived from the lane id is hoisted out of the 25-cycle loop and kept live (spilled)
+  asm volatile("" : "+v"(lane));
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
