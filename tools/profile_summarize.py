@@ -6,7 +6,7 @@ root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
 lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps N --warmup W --no-cpu-baseline` (1 x MI355X, 4096 envs, SSM)", ""]
-f = glob.glob(f"{go}/{tag}_trace/*/*_kernel_stats.csv")
+f = sorted(glob.glob(f"{go}/{tag}_trace/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
 if f:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | total ns | average ns | % | min ns | max ns |", "|---|---|---|---|---|---|---|"]
     for r in csv.DictReader(open(f[0])):
@@ -16,7 +16,7 @@ if f:
 pmc = {}
 meta = {}
 for sub in ["fetch", "write", "sq", "sq2"]:
-    f = glob.glob(f"{go}/{tag}_{sub}/*/*_counter_collection.csv")
+    f = sorted(glob.glob(f"{go}/{tag}_{sub}/*/*_counter_collection.csv"), key=os.path.getmtime, reverse=True)
     if not f:
         continue
     acc = collections.defaultdict(list)
