@@ -87,6 +87,9 @@ struct DevModel {
   // robot self-collision candidate pairs in enumeration order
   int32_t n_self;
   int32_t self_i[64], self_j[64];
+  // pre-check model pairs (capsules 0..6 + gripper cylinder)
+  int32_t n_chk;
+  int32_t chk_i[32], chk_j[32];
   // animation clips (frames in device memory)
   hrg_clip_table clips;
 };
@@ -273,7 +276,7 @@ DI double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4 };
 DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);

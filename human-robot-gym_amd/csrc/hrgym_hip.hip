@@ -257,12 +257,127 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
 }
 
 // ================================================================================================ env
-DI void goal_of(ModelPtr dm, int64_t gid, int episode, int idx, double* g) {
+// HumanEnv._check_action_safety (human_env.py:931-946) for the configuration in L.cq: static collision objects (table
+// volume, mount pedestal: human_env.py:1301-1348) and self collision (pinocchio_manipulator_model.py:168-236) on the
+// capsule model.  Lane 0 runs the chain kinematics, then lanes = capsule end points / capsule pairs, verdict by __any.
+#define NCAP_CHECK 8
+DI bool config_collides(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
   const auto& m = dm->m;
-  for (int j = 0; j < NARM; j++) {
-    const double u = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_GOAL, (uint64_t)(idx * NARM + j));
-    g[j] = m.qpos_limits[0][j] + (m.qpos_limits[1][j] - m.qpos_limits[0][j]) * u;
+  double* cc = &L.scap[0][0][0];  // 8 capsules x (p1, p2), shield scratch is free here
+  if (lane == 0) {
+    double R[9], p[3], t[3];
+    for (int k = 0; k < 9; k++) R[k] = dm->Rbase[k];
+    v3cpy(p, m.base_pos);
+    m3mulv(t, R, m.rcap_p1[0]); v3add(cc, p, t);
+    m3mulv(t, R, m.rcap_p2[0]); v3add(cc + 3, p, t);
+#pragma unroll 1
+    for (int i = 0; i < NARM; i++) {
+      double Rl[9], Rj[9];
+      m3mul(Rl, R, dm->Rq[i]);
+      m3mulv(t, R, m.body_pos[i]);
+      v3add(p, p, t);
+      axisangle2mat(Rj, m.jnt_axis[i], L.cq[i]);
+      m3mul(R, Rl, Rj);
+      m3mulv(t, R, m.rcap_p1[i + 1]); v3add(cc + 6 * (i + 1), p, t);
+      m3mulv(t, R, m.rcap_p2[i + 1]); v3add(cc + 6 * (i + 1) + 3, p, t);
+    }
+    // capsule 7 = the gripper cylinder of the reference's URDF collision model = the shield's gripper capsule (on link 6)
+    m3mulv(t, R, m.scap_p1[HRG_NSHIELD_RCAP - 1]); v3add(cc + 6 * (NARM + 1), p, t);
+    m3mulv(t, R, m.scap_p2[HRG_NSHIELD_RCAP - 1]); v3add(cc + 6 * (NARM + 1) + 3, p, t);
   }
+  wave_sync();
+  bool hit = false;
+  if (lane < 2 * (NCAP_CHECK - 1)) {
+    const int c = 1 + (lane >> 1);
+    const double* p = cc + 6 * c + 3 * (lane & 1);
+    const double r = c == NCAP_CHECK - 1 ? m.scap_r[HRG_NSHIELD_RCAP - 1] : m.rcap_r[c], mg = m.obstacle_margin;
+    if (p[2] - r < m.table_top_z + mg && fabs(p[0]) <= m.table_half[0] + 0.5 * mg + r && fabs(p[1]) <= m.table_half[1] + 0.5 * mg + r) hit = true;
+    const double dx = p[0] - m.base_pos[0], dy = p[1] - m.base_pos[1];
+    if (p[2] - r < m.base_cyl_z && sqrt(dx * dx + dy * dy) < m.base_cyl_r + mg + r) hit = true;
+  } else if (lane >= 16 && lane - 16 < dm->n_chk) {
+    const int i = dm->chk_i[lane - 16], j = dm->chk_j[lane - 16];
+    double x1[3], x2[3];
+    const double rj = j == NCAP_CHECK - 1 ? m.scap_r[HRG_NSHIELD_RCAP - 1] : m.rcap_r[j];
+    if (sqrt(seg_seg(cc + 6 * i, cc + 6 * i + 3, cc + 6 * j, cc + 6 * j + 3, x1, x2)) - m.rcap_r[i] - rj < m.self_collision_safety) hit = true;
+  }
+  const bool any = __any(hit);
+  wave_sync();
+  return any;
+}
+
+// ReachHuman._sample_valid_pos (reach_human_env.py:525-548) -> L.st.cur_goal
+DI void goal_sample(const DevModel* __restrict__ dm_, int lane, int64_t gid, int idx) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+#pragma unroll 1
+  for (int t = 0; t < 20; t++) {
+    if (lane < NARM) {
+      const double u = rng_u01(m.seed, (uint64_t)gid, (uint64_t)s.episode, STREAM_GOAL, (uint64_t)((idx * 20 + t) * NARM + lane));
+      L.cq[lane] = m.qpos_limits[0][lane] + (m.qpos_limits[1][lane] - m.qpos_limits[0][lane]) * u;
+    }
+    wave_sync();
+    const bool bad = m.goal_check && config_collides(dm_, lane);
+    if (!bad) {
+      if (lane < NARM) s.cur_goal[lane] = L.cq[lane];
+      wave_sync();
+      return;
+    }
+  }
+  if (lane < NARM) s.cur_goal[lane] = 0.0;
+  wave_sync();
+}
+
+// goal configuration of an action -> L.cq (HumanEnv.check_collision_action, human_env.py:588-627)
+DI void action_goal(ModelPtr dm, int lane, const double* act) {
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  if (lane < NARM) {
+    const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
+    const double otr = 0.5 * (m.act_out_max + m.act_out_min), itr = 0.5 * (m.act_in_max + m.act_in_min);
+    const double a = clampd(act[lane], m.act_in_min, m.act_in_max);
+    L.cq[lane] = clampd(L.st.qpos[lane] + ((a - itr) * scale + otr), m.qpos_limits[0][lane], m.qpos_limits[1][lane]);
+  }
+  wave_sync();
+}
+
+// CollisionPreventionWrapper.action (wrappers/collision_prevention_wrapper.py:46-103) on L.act
+DI void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  if (!m.cp_enabled) return;
+  action_goal(dm, lane, L.act);
+  if (!config_collides(dm_, lane)) return;
+  s.action_resamples = s.action_resamples + 1;
+  double* cand = L.cv;              // 7 values in cv[6] + ca[0] (contiguous)
+  double* best = &L.rc[0][0];
+  double bestd = 1e300;
+  int found = 0;
+  if (m.cp_replace_type != 0) {
+#pragma unroll 1
+    for (int t = 0; t < m.cp_n_resamples; t++) {
+      double dd = 0;
+      if (lane < HRG_ACT_DIM) {
+        const double c = 2.0 * rng_u01(m.seed, (uint64_t)gid, (uint64_t)s.episode, STREAM_ACTION, (uint64_t)((s.timestep * 64 + t) * HRG_ACT_DIM + lane)) - 1.0;
+        cand[lane] = c;
+        dd = (L.act[lane] - c) * (L.act[lane] - c);
+      }
+      const double d = wave_sum(dd);
+      wave_sync();
+      action_goal(dm, lane, cand);
+      if (config_collides(dm_, lane)) continue;
+      if (m.cp_replace_type == 1) { if (lane < HRG_ACT_DIM) best[lane] = cand[lane]; found = 1; wave_sync(); break; }
+      if (d < bestd) { bestd = d; if (lane < HRG_ACT_DIM) best[lane] = cand[lane]; found = 1; }
+      wave_sync();
+    }
+  }
+  if (lane < HRG_ACT_DIM) L.act[lane] = found ? best[lane] : 0.0;
+  wave_sync();
 }
 
 // observation: object-state (vec/dist eef -> L hand, R hand, head; human_env.py:1536-1590) + goal_difference
@@ -323,11 +438,8 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   eef_update(dm_);
   shield_reset(dm_, lane);
   wave_sync();
-  if (obs_out) {
-    double g[NARM];
-    goal_of(dm, gid, episode, 0, g);
-    write_obs(dm_, lane, g, obs_out);
-  }
+  goal_sample(dm_, lane, gid, 0);
+  if (obs_out) write_obs(dm_, lane, s.cur_goal, obs_out);
   wave_sync();
 }
 
@@ -412,15 +524,18 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
-DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, const double* __restrict__ action, float* obs, float* term_obs,
+DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, double* __restrict__ action, float* obs, float* term_obs,
                  float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
-  s.timestep = s.timestep + 1;
   int has_collision = 0, collision_type = HRG_COL_NULL, crash = 0;
   if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
+  wave_sync();
+  screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
+  if (m.cp_enabled && lane < HRG_ACT_DIM) action[lane] = L.act[lane];
+  s.timestep = s.timestep + 1;
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
   wave_sync();
 #pragma unroll 1
@@ -428,7 +543,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   has_collision = L.acc_has_collision; collision_type = L.acc_collision_type;
   // ---- observation / success / info / reward / done ----
   double goal[NARM];
-  goal_of(dm, gid, s.episode, s.goal_index, goal);
+  for (int j = 0; j < NARM; j++) goal[j] = s.cur_goal[j];
   write_obs(dm_, lane, goal, term_obs);
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
@@ -448,7 +563,6 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   }
   const int ncoll = s.n_collisions_static + s.n_collisions_robot + s.n_collisions_human + s.n_collisions_critical;
   int truncated = 0;
-  if (goal_reached) s.goal_index = (s.goal_index + 1) % m.n_goals;
   if (s.timestep >= m.horizon) { truncated = !d; d = 1; }
   if (lane < HRG_INFO_DIM) {
     int v = 0;
@@ -465,17 +579,22 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
       case HRG_INFO_N_GOAL_REACHED: v = s.n_goal_reached; break;
       case HRG_INFO_TRUNCATED: v = truncated; break;
       case HRG_INFO_SIM_CRASH: v = crash; break;
+      case HRG_INFO_ACTION_RESAMPLES: v = s.action_resamples; break;
     }
     info[lane] = v;
   }
   if (lane == 0) { *reward = (float)r; *done = (uint8_t)d; }
   wave_sync();
+  if (goal_reached && !d) { // reach_human_env.py:399-407 (a finished episode resamples its goals at reset anyway)
+    s.goal_index = (s.goal_index + 1) % m.n_goals;
+    goal_sample(dm_, lane, gid, s.goal_index);
+  }
   if (d) env_reset(dm_, lane, gid, obs);
   else write_obs(dm_, lane, goal, obs);
 }
 
 // ================================================================================================ kernels
-__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const double* __restrict__ actions,
+__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs) {
   Lds& L = g_L;
@@ -594,6 +713,11 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     for (int j = i + 1; j < HRG_NRCAP; j++)
       if ((desc->rcap_selfmask[i] >> j) & 1u) { hm->self_i[ns] = i; hm->self_j[ns] = j; ns++; }
   hm->n_self = ns;
+  int nc = 0;
+  for (int i = 0; i < 8; i++)
+    for (int j = i + 1; j < 8; j++)
+      if (((desc->chk_selfmask[i] >> j) & 1u) && nc < 32) { hm->chk_i[nc] = i; hm->chk_j[nc] = j; nc++; }
+  hm->n_chk = nc;
   hm->phase_mask = 0xff;
   {
     double se, ve, ae;
@@ -652,7 +776,7 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
   return HRG_OK;
 }
 
-int hrg_batch_step(hrg_batch* b, const double* actions_dev, float* obs_dev, float* term_obs_dev, float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream) {
+int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* term_obs_dev, float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream) {
   if (!b || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return fail(HRG_ERR_INVALID, "null argument");
   hipStream_t st = (hipStream_t)stream;
   std::pair<hipEvent_t, hipEvent_t> ev;

@@ -32,7 +32,8 @@ def make_vec_env(
     if expert_obs_keys is not None:
         raise NotImplementedError("expert observation side channel is a 'next' row (SURVEY.md §8f-4)")
     if wrapper_class is not None:
-        raise NotImplementedError("per-env gym wrappers cannot wrap a batched env; CollisionPreventionWrapper is §8f-1")
+        raise NotImplementedError("per-env gym wrappers cannot wrap a batched env; pass vec_env_kwargs=dict(collision_prevention="
+                                  "dict(replace_type=0, n_resamples=20)) for the CollisionPreventionWrapper of config/wrappers/safe.yaml")
     if monitor_dir is not None:
         raise NotImplementedError("monitor csv files are not written; episode stats are in infos[i]['episode']")
     kw = dict(vec_env_kwargs or {})

@@ -51,6 +51,7 @@ DEFAULT_ENV_KWARGS = dict(
     n_goals_sampled_per_100_steps=20,
     goal_dist=0.1,
     safe_vel=0.01,
+    self_collision_safety=0.012,
     collision_debounce_delay=0.01,
     seed=0,
 )
@@ -150,11 +151,13 @@ def load_assets(name="reach_human_schunk.json"):
         return json.load(f)
 
 
-def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None):
+def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True):
     """Return a filled `ModelDesc` for ReachHuman/Schunk.
 
     `env_kwargs` takes the same keys as the reference's environment config
-    (training/config/environment/reach_human.yaml, default/human_env.yaml)."""
+    (training/config/environment/reach_human.yaml, default/human_env.yaml).
+    `collision_prevention` takes the keys of config/wrappers/collision_prevention/*.yaml (replace_type, n_resamples);
+    None = wrapper not in the stack.  `goal_check=False` takes the non-pinocchio branch of `_sample_valid_pos`."""
     kw = dict(DEFAULT_ENV_KWARGS)
     kw.update(env_kwargs or {})
     sp = dict(SHIELD_DEFAULTS)
@@ -253,6 +256,19 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     for c, (b, cap) in enumerate(caps):
         Rb, pb = (np.eye(3), np.asarray(d.base_pos[:])) if b < 0 else (R[b], p[b])
         wp.append((pb + Rb @ np.asarray(cap["p1"]), pb + Rb @ np.asarray(cap["p2"]), cap["r"]))
+    # pre-check model (HumanEnv.check_collision_action): capsules 0..6 + the URDF's gripper cylinder = shield gripper capsule
+    sc = GRIPPER["shield_capsule"]
+    chk = wp[:7] + [(p[NARM - 1] + R[NARM - 1] @ (p_hand + R_hand @ np.asarray(sc[0])), p[NARM - 1] + R[NARM - 1] @ (p_hand + R_hand @ np.asarray(sc[1])), sc[2])]
+    for i in range(8):
+        mask = 0
+        for j in range(i + 1, 8):
+            bi, bj = caps[i][0], caps[j][0]
+            if bi == bj or d.body_parent[bj] == bi or (bi >= 0 and d.body_parent[bi] == bj):
+                continue
+            if _seg_seg_dist(chk[i][0], chk[i][1], chk[j][0], chk[j][1]) - chk[i][2] - chk[j][2] < float(kw["self_collision_safety"]) + 0.005:
+                continue
+            mask |= 1 << j
+        d.chk_selfmask[i] = mask
     for i in range(len(caps)):
         mask = 0
         for j in range(i + 1, len(caps)):
@@ -261,8 +277,8 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
                 continue
             if bi >= NARM and bj >= NARM:  # finger-finger
                 continue
-            if _seg_seg_dist(wp[i][0], wp[i][1], wp[j][0], wp[j][1]) - wp[i][2] - wp[j][2] < 0.01:
-                continue
+            if _seg_seg_dist(wp[i][0], wp[i][1], wp[j][0], wp[j][1]) - wp[i][2] - wp[j][2] < float(kw["self_collision_safety"]) + 0.005:
+                continue  # (closer than the pre-check's safety distance in the home pose -> never a candidate)
             mask |= 1 << j
         d.rcap_selfmask[i] = mask
     # MuJoCo's constant inverse-weight approximations at qpos0 (mj_setM0 / set0): used for constraint regularisation
@@ -379,6 +395,17 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     d.done_at_success = int(bool(kw["done_at_success"]))
     d.safe_vel = float(kw["safe_vel"])
     d.collision_debounce_delay = float(kw["collision_debounce_delay"])
+    # static / self collision pre-check (human_env.py:588-627, 1301-1348; reach_human_env.py:589-593)
+    cp = collision_prevention
+    d.cp_enabled = int(cp is not None)
+    d.cp_replace_type = int((cp or {}).get("replace_type", 0))
+    d.cp_n_resamples = int((cp or {}).get("n_resamples", 20))
+    if not 0 <= d.cp_replace_type <= 2 or not 0 <= d.cp_n_resamples <= 64:
+        raise ValueError("collision_prevention: replace_type in {0,1,2}, n_resamples <= 64")
+    d.goal_check = int(bool(goal_check))
+    d.self_collision_safety = float(kw["self_collision_safety"])
+    d.obstacle_margin = 0.01
+    d.base_cyl_r, d.base_cyl_z = 0.2, 0.91
     d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
     return d
 

@@ -58,6 +58,7 @@ except Exception:  # noqa: BLE001
 INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "collision", "collision_type", "n_collisions", "n_collisions_static", "n_collisions_robot", "n_collisions_human",
     "n_collisions_critical", "timeout", "failsafe_interventions", "n_goal_reached", "TimeLimit.truncated", "sim_crash",
+    "action_resamples",
 ]
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
 OBS_KEYS = ["object-state", "goal_difference"]
@@ -92,12 +93,16 @@ class _TorchBackend:
         return self.obs
 
     def step_async(self, actions):
-        a = self.torch.from_numpy(np.ascontiguousarray(actions, np.float64)).to(self.batch.device, non_blocking=True)
-        self.batch.step(a)
+        self._act = self.torch.from_numpy(np.ascontiguousarray(actions, np.float64)).to(self.batch.device, non_blocking=True)
+        self.batch.step(self._act)
 
     def step_wait(self):
         self._fetch()
         return self.obs, self.term_obs, self.reward, self.done, self.info
+
+    def executed_actions(self):
+        """Actions after CollisionPreventionWrapper screening (the kernel rewrites the action rows in place)."""
+        return self._act.cpu().numpy()
 
     def close(self):
         self.batch.close()
@@ -111,7 +116,7 @@ class HipVecEnv(_VecEnvBase):
     global env id, so sharding does not change results)."""
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
-                 device=0, env_id0=0, backend=None, info_dicts=True):
+                 device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True):
         if env_id != "ReachHuman":
             raise NotImplementedError(f"env_id {env_id!r}: only ReachHuman is built in this round (DESIGN.md §6)")
         if obs_keys is not None and list(obs_keys) != OBS_KEYS:
@@ -121,7 +126,9 @@ class HipVecEnv(_VecEnvBase):
             kw["seed"] = int(seed)
         self.env_kwargs = kw
         self._clips = clips if clips is not None else synthetic_clips()
-        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips)
+        # collision_prevention: dict(replace_type=0|1|2, n_resamples=20) = config/wrappers/collision_prevention/*.yaml
+        self._cp, self._goal_check = collision_prevention, goal_check
+        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check)
         self._device, self._env_id0 = device, env_id0
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
         obs_space = _Box(-np.inf, np.inf, shape=(CONST["HRG_OBS_DIM"],), dtype=np.float32)
@@ -151,6 +158,8 @@ class HipVecEnv(_VecEnvBase):
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
         self._ep_len += 1
+        if self._cp is not None and self.info_dicts:
+            self._actions = np.array(self._backend.executed_actions(), copy=True)
         infos = self._make_infos(info, dones, term_obs) if self.info_dicts else [{} for _ in range(self.num_envs)]
         self._ep_ret[dones] = 0
         self._ep_len[dones] = 0
@@ -161,8 +170,7 @@ class HipVecEnv(_VecEnvBase):
         now = time.time() - self._t_start
         for i in range(self.num_envs):
             d = {k: (bool(info[i, j]) if k in _BOOL_KEYS else int(info[i, j])) for j, k in enumerate(INFO_KEYS)}
-            d["action"] = self._actions[i]
-            d["action_resamples"] = 0  # CollisionPreventionWrapper is not part of this round
+            d["action"] = self._actions[i]  # collision_prevention_wrapper.py:42-43: the executed action
             if dones[i]:
                 d["terminal_observation"] = np.array(term_obs[i], copy=True)
                 d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
@@ -179,7 +187,7 @@ class HipVecEnv(_VecEnvBase):
         if seed is None:
             return [None] * self.num_envs
         self.env_kwargs["seed"] = int(seed)
-        self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips)
+        self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check)
         if isinstance(self._backend, _TorchBackend):
             self._backend.close()
             self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)

@@ -59,7 +59,7 @@ extern "C" {
 #define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
 #define HRG_OBS_DIM 18    /* object-state(12) + goal_difference(6): human_reach_ppo_parallel.yaml:14-16 */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
-#define HRG_INFO_DIM 12
+#define HRG_INFO_DIM 13
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */
 #define HRG_NCON_DYN 6    /* contacts that enter the constraint solve (4 pyramid rows each) */
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
@@ -78,7 +78,8 @@ enum {
   HRG_INFO_FAILSAFE_INTERVENTIONS = 8,
   HRG_INFO_N_GOAL_REACHED = 9,
   HRG_INFO_TRUNCATED = 10, /* TimeLimit.truncated (time_limit.py:42) */
-  HRG_INFO_SIM_CRASH = 11
+  HRG_INFO_SIM_CRASH = 11,
+  HRG_INFO_ACTION_RESAMPLES = 12 /* CollisionPreventionWrapper.action_resamples */
 };
 
 /* COLLISION_TYPE flag values, human_env.py:55-77 */
@@ -195,6 +196,16 @@ typedef struct hrg_model_desc {
   double goal_dist, reward_scale, task_reward, collision_reward, sim_crash_reward;
   int32_t reward_shaping, done_at_collision, done_at_success;
   double safe_vel, collision_debounce_delay;
+  /* ---- static / self collision pre-check of a goal configuration (HumanEnv.check_collision_action, human_env.py:588-627;
+   *      collision objects of _setup_collision_objects, human_env.py:1301-1348; pinocchio_manipulator_model.py:168-236) ---- */
+  int32_t cp_enabled;           /* CollisionPreventionWrapper in the stack (config/wrappers/safe.yaml) */
+  int32_t cp_replace_type;      /* 0 zero action, 1 random safe action, 2 closest safe action (collision_prevention_wrapper.py:25-46) */
+  int32_t cp_n_resamples;
+  int32_t goal_check;           /* ReachHuman._sample_valid_pos rejects colliding goals (reach_human_env.py:525-548) */
+  double self_collision_safety; /* reach_human.yaml:25 */
+  double obstacle_margin;       /* safety_margin of the table / base obstacles (reach_human_env.py:589-593) */
+  double base_cyl_r, base_cyl_z; /* mount pedestal cylinder (human_env.py:1333-1339) */
+  uint32_t chk_selfmask[HRG_NRCAP]; /* self-collision candidates of the pre-check model: capsules 0..6 + gripper cylinder (7) */
   uint64_t seed;
 } hrg_model_desc;
 
@@ -234,12 +245,13 @@ void hrg_batch_destroy(hrg_batch* b);
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream);
 
 /* One policy step of every env: n_cycles shield cycles, observation, reward, done, info, auto-reset.
- *   actions_dev  const double[n_envs][HRG_ACT_DIM]
+ *   actions_dev  double[n_envs][HRG_ACT_DIM]  (with collision prevention on, rows are overwritten by the executed
+ *                action, the wrapper's info["action"])
  *   obs_dev      float[n_envs][HRG_OBS_DIM]   (observation AFTER auto-reset where done)
  *   term_obs_dev float[n_envs][HRG_OBS_DIM]   (observation BEFORE auto-reset; may be NULL)
  *   reward_dev   float[n_envs];  done_dev uint8_t[n_envs];  info_dev int32_t[n_envs][HRG_INFO_DIM]
  * Asynchronous with respect to the host. */
-int hrg_batch_step(hrg_batch* b, const double* actions_dev, float* obs_dev, float* term_obs_dev,
+int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* term_obs_dev,
                    float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream);
 
 /* Parity hooks (synchronous, host buffers). */

@@ -54,6 +54,7 @@ typedef struct hrg_env_state {
   double human_rot_offset[4];    /* (w,x,y,z) */
   double debounce_timer;
   double eef_pos[3];             /* grip-site position of the last forward pass (observable source) */
+  double cur_goal[HRG_NARM];     /* _desired_goals[_desired_goals_index] */
   /* ---- integers ---- */
   int32_t timestep;          /* policy steps in this episode */
   int32_t low_level_time;    /* human_env.py:526 */
@@ -68,11 +69,11 @@ typedef struct hrg_env_state {
   int32_t failsafe_interventions;
   int32_t n_collisions_static, n_collisions_robot, n_collisions_human, n_collisions_critical;
   int32_t n_goal_reached;
+  int32_t action_resamples;
   int32_t n_prev;                    /* previous_robot_collisions (cantor hashes of both orders) */
   int32_t prev_pairs[HRG_NPREV_MAX];
   int32_t ncon;                      /* contacts of the last substep (parity hook) */
   int32_t con_pairs[HRG_NCON_MAX][2];
-  int32_t pad_;
 } hrg_env_state;
 
 #ifdef __cplusplus

@@ -98,7 +98,7 @@ static double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t st
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4 };
 static double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * PI * u2);
@@ -961,13 +961,91 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const d
   for (int j = 0; j < NARM; j++) obs[12 + j] = (float)(goal[j] - s->qpos[j]);
 }
 
-static void goal_of(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, int idx, double* g) {
-  /* ReachHuman._sample_valid_pos without the pinocchio check (reach_human_env.py:525-548, else branch) */
-  const hrg_model_desc* m = &B->m;
-  for (int j = 0; j < NARM; j++) {
-    double u = rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_GOAL, (uint64_t)(idx * NARM + j));
-    g[j] = m->qpos_limits[0][j] + (m->qpos_limits[1][j] - m->qpos_limits[0][j]) * u;
+/* HumanEnv._check_action_safety (human_env.py:931-946): does the arm at configuration q6 hit the static collision objects
+ * (table volume, mount pedestal cylinder: _setup_collision_objects, human_env.py:1301-1348) or itself
+ * (pinocchio_manipulator_model.py:168-236)?  Restated on the capsule model: links 0..6 and the gripper body (no fingers,
+ * like the reference's URDF collision model). */
+#define NCAP_CHECK 8
+static int config_collides(const hrg_model_desc* m, const double* q6) {
+  double q[NV], c1[NCAP_CHECK][3], c2[NCAP_CHECK][3], Rb[9];
+  robot_kin k;
+  for (int i = 0; i < NARM; i++) q[i] = q6[i];
+  for (int i = NARM; i < NV; i++) q[i] = 0;
+  robot_fk(m, q, &k);
+  quat2mat(Rb, m->base_quat);
+  double rad[NCAP_CHECK];
+  for (int c = 0; c < NCAP_CHECK; c++) {
+    int b = m->rcap_body[c];
+    /* capsule 7 = the gripper cylinder of the reference's URDF collision model (r 0.07, l 0.11) = the shield's gripper capsule */
+    const double* q1 = c == NCAP_CHECK - 1 ? m->scap_p1[HRG_NSHIELD_RCAP - 1] : m->rcap_p1[c];
+    const double* q2 = c == NCAP_CHECK - 1 ? m->scap_p2[HRG_NSHIELD_RCAP - 1] : m->rcap_p2[c];
+    rad[c] = c == NCAP_CHECK - 1 ? m->scap_r[HRG_NSHIELD_RCAP - 1] : m->rcap_r[c];
+    double t[3];
+    m3mulv(t, b < 0 ? Rb : k.R[b], q1); v3add(c1[c], b < 0 ? m->base_pos : k.p[b], t);
+    m3mulv(t, b < 0 ? Rb : k.R[b], q2); v3add(c2[c], b < 0 ? m->base_pos : k.p[b], t);
   }
+  const double mg = m->obstacle_margin;
+  for (int c = 1; c < NCAP_CHECK; c++)
+    for (int e = 0; e < 2; e++) {
+      const double* p = e ? c2[c] : c1[c];
+      const double r = rad[c];
+      if (p[2] - r < m->table_top_z + mg && fabs(p[0]) <= m->table_half[0] + 0.5 * mg + r && fabs(p[1]) <= m->table_half[1] + 0.5 * mg + r) return 1 + 16 * c;
+      const double dx = p[0] - m->base_pos[0], dy = p[1] - m->base_pos[1];
+      if (p[2] - r < m->base_cyl_z && sqrt(dx * dx + dy * dy) < m->base_cyl_r + mg + r) return 2 + 16 * c;
+    }
+  for (int i = 0; i < NCAP_CHECK; i++)
+    for (int j = i + 1; j < NCAP_CHECK; j++) {
+      if (!((m->chk_selfmask[i] >> j) & 1u)) continue;
+      double x1[3], x2[3];
+      if (sqrt(seg_seg(c1[i], c2[i], c1[j], c2[j], x1, x2)) - rad[i] - rad[j] < m->self_collision_safety) return 3 + 16 * i + 256 * j;
+    }
+  return 0;
+}
+
+static void goal_of(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, int idx, double* g) {
+  /* ReachHuman._sample_valid_pos (reach_human_env.py:525-548): up to 20 uniform samples in the position limits, the first
+   * collision-free one wins, else the zero configuration */
+  const hrg_model_desc* m = &B->m;
+  for (int t = 0; t < 20; t++) {
+    for (int j = 0; j < NARM; j++) {
+      double u = rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_GOAL, (uint64_t)((idx * 20 + t) * NARM + j));
+      g[j] = m->qpos_limits[0][j] + (m->qpos_limits[1][j] - m->qpos_limits[0][j]) * u;
+    }
+    if (!m->goal_check || !config_collides(m, g)) return;
+    for (int j = 0; j < NARM; j++) g[j] = 0;
+  }
+}
+
+/* HumanEnv.check_collision_action (human_env.py:588-627): goal = clip(q + scale(action)), then the pre-check */
+static int action_collides(const hrg_model_desc* m, const hrg_env_state* s, const double* act) {
+  double scale = fabs(m->act_out_max - m->act_out_min) / fabs(m->act_in_max - m->act_in_min);
+  double otr = 0.5 * (m->act_out_max + m->act_out_min), itr = 0.5 * (m->act_in_max + m->act_in_min), g[NARM];
+  for (int j = 0; j < NARM; j++) {
+    double a = clampd(act[j], m->act_in_min, m->act_in_max);
+    g[j] = clampd(s->qpos[j] + ((a - itr) * scale + otr), m->qpos_limits[0][j], m->qpos_limits[1][j]);
+  }
+  return config_collides(m, g);
+}
+
+/* CollisionPreventionWrapper.action (wrappers/collision_prevention_wrapper.py:46-103) */
+static void screen_action(const hrgo_batch* B, int64_t gid, hrg_env_state* s, double* act) {
+  const hrg_model_desc* m = &B->m;
+  if (!m->cp_enabled || !action_collides(m, s, act)) return;
+  s->action_resamples++;
+  double best[HRG_ACT_DIM], bestd = 1e300;
+  int found = 0;
+  if (m->cp_replace_type != 0)
+    for (int t = 0; t < m->cp_n_resamples; t++) {
+      double c[HRG_ACT_DIM], d = 0;
+      for (int j = 0; j < HRG_ACT_DIM; j++) {
+        c[j] = 2.0 * rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_ACTION, (uint64_t)((s->timestep * 64 + t) * HRG_ACT_DIM + j)) - 1.0;
+        d += (act[j] - c[j]) * (act[j] - c[j]);
+      }
+      if (action_collides(m, s, c)) continue;
+      if (m->cp_replace_type == 1) { memcpy(best, c, sizeof best); found = 1; break; }
+      if (d < bestd) { bestd = d; memcpy(best, c, sizeof best); found = 1; }
+    }
+  for (int j = 0; j < HRG_ACT_DIM; j++) act[j] = found ? best[j] : 0.0;
 }
 
 static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
@@ -1007,14 +1085,16 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   eef_of(m, &k, s->eef_pos);
   shield_reset(m, s, s->qpos); /* FailsafeController.reset, failsafe_controller.py:204-250 */
   for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
-  if (obs) { double g[NARM]; goal_of(B, gid, s, 0, g); compute_obs(m, s, g, obs); }
+  goal_of(B, gid, s, 0, s->cur_goal);
+  if (obs) compute_obs(m, s, s->cur_goal, obs);
 }
 
-static void env_step(hrgo_batch* B, int e, const double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
   const hrg_model_desc* m = &B->m;
   hrg_env_state* s = &B->st[e];
   int64_t gid = B->env_id0 + e;
   const double h = m->timestep;
+  screen_action(B, gid, s, action); /* CollisionPreventionWrapper.step wraps env.step: uses the pre-step state */
   s->timestep += 1; /* human_env.py:490 */
   int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
   robot_kin k;
@@ -1139,7 +1219,7 @@ static void env_step(hrgo_batch* B, int e, const double* action, float* obs, flo
   }
   /* ---- observation, success, info, reward, done (human_env.py:561-581) ---- */
   double goal[NARM];
-  goal_of(B, gid, s, s->goal_index, goal);
+  memcpy(goal, s->cur_goal, sizeof goal);
   compute_obs(m, s, goal, term_obs);
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
@@ -1170,7 +1250,11 @@ static void env_step(hrgo_batch* B, int e, const double* action, float* obs, flo
   info[HRG_INFO_N_GOAL_REACHED] = s->n_goal_reached;
   info[HRG_INFO_SIM_CRASH] = crash;
   info[HRG_INFO_TRUNCATED] = 0;
-  if (goal_reached) s->goal_index = (s->goal_index + 1) % m->n_goals; /* reach_human_env.py:399-407 */
+  info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
+  if (goal_reached) { /* reach_human_env.py:399-407 */
+    s->goal_index = (s->goal_index + 1) % m->n_goals;
+    goal_of(B, gid, s, s->goal_index, s->cur_goal);
+  }
   if (s->timestep >= m->horizon) { info[HRG_INFO_TRUNCATED] = !d; d = 1; } /* time_limit.py:40-43 */
   *reward = (float)r;
   *done = (uint8_t)d;
@@ -1204,7 +1288,7 @@ int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
   for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
   return 0;
 }
-int hrgo_step(hrgo_batch* B, const double* actions, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+int hrgo_step(hrgo_batch* B, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
   for (int e = 0; e < B->n_envs; e++) {
     float tmp[HRG_OBS_DIM];
     env_step(B, e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : tmp,
@@ -1213,7 +1297,7 @@ int hrgo_step(hrgo_batch* B, const double* actions, float* obs, float* term_obs,
   return 0;
 }
 /* step a sub-range only (CPU baseline workers) */
-int hrgo_step_range(hrgo_batch* B, int e0, int e1, const double* actions, float* obs, float* reward, uint8_t* done, int32_t* info) {
+int hrgo_step_range(hrgo_batch* B, int e0, int e1, double* actions, float* obs, float* reward, uint8_t* done, int32_t* info) {
   for (int e = e0; e < e1; e++) {
     float tmp[HRG_OBS_DIM];
     env_step(B, e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tmp, reward + e, done + e, info + (size_t)e * HRG_INFO_DIM);
@@ -1268,4 +1352,5 @@ void hrgo_test_human_fk(const hrg_model_desc* m, const double* mp, const double*
   human_fk(m, mp, mq, qh, &h, (double(*)[3])sites);
   for (int b = 0; b < HRG_NHB; b++) { memcpy(caps + 6 * b, h.cap1[b], 24); memcpy(caps + 6 * b + 3, h.cap2[b], 24); }
 }
+int hrgo_test_config_collides(const hrg_model_desc* m, const double* q6) { return config_collides(m, q6); }
 double hrgo_test_u01(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) { return rng_u01(seed, env, ep, stream, idx); }

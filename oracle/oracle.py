@@ -66,6 +66,7 @@ class OracleBatch:
     def step(self, actions):
         a = np.ascontiguousarray(actions, np.float64)
         assert a.shape == (self.n, self.C["HRG_ACT_DIM"])
+        self.last_actions = a  # rewritten in place by the collision-prevention screening
         self.lib.hrgo_step(self.h, _p(a), _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.done), _p(self.info))
         return self.obs.copy(), self.reward.copy(), self.done.copy(), self.info.copy()
 

@@ -11,13 +11,13 @@ RTOL = 1e-5
 ATOL = 1e-7
 
 
-def make_pair(n_envs, env_kwargs=None, n_clips=3, clip_seed=0, env_id0=0, clips=None):
+def make_pair(n_envs, env_kwargs=None, n_clips=3, clip_seed=0, env_id0=0, clips=None, **desc_kw):
     """(OracleBatch, HipBatch) on identical model / clips / seeds."""
     from oracle.oracle import OracleBatch
     from human_robot_gym_amd._lib import HipBatch
     clips = clips or hrg.synthetic_clips(n_clips, seed=clip_seed, min_frames=300, max_frames=600)
-    d1 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
-    d2 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    d1 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, **desc_kw)
+    d2 = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, **desc_kw)
     return OracleBatch(d1, clips, n_envs, env_id0), HipBatch(d2, clips, n_envs, env_id0)
 
 
@@ -72,6 +72,9 @@ class OracleBackend:
     def step_wait(self):
         obs, rew, done, info = self._out
         return obs, self.B.term_obs.copy(), rew, done, info
+
+    def executed_actions(self):
+        return self.B.last_actions
 
     def close(self):
         self.B.close()
