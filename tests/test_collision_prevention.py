@@ -84,14 +84,14 @@ def test_wrapper_semantics_on_the_oracle_backend(oracle_lib, replace_type):
 @pytest.mark.parametrize("replace_type", [0, 1, 2])
 def test_hip_matches_oracle_with_collision_prevention(replace_type):
     import torch
-    kw = dict(shield_type="SSM", horizon=25)
+    kw = dict(shield_type="OFF", horizon=45)
     O, G = make_pair(16, kw, collision_prevention=dict(replace_type=replace_type, n_resamples=12))
     np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=1e-6)
     rng = np.random.RandomState(3)
     tot = 0
-    for k in range(40):
+    for k in range(45):
         a = rng.uniform(-1, 1, (16, 7))
-        a[:, 1] = np.where(np.arange(16) % 2 == 0, 1.0, a[:, 1])
+        a[:, 1] = np.where(np.arange(16) % 4 != 3, 1.0, a[:, 1])  # most envs keep folding the shoulder towards the table
         ag = torch.from_numpy(a.copy()).cuda()
         o_o, r_o, d_o, i_o = O.step(a)
         o_g, r_g, d_g, i_g = G.step(ag)
