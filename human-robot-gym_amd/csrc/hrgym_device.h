@@ -61,13 +61,20 @@
 // ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
 #ifdef HRG_STAMPS
 __device__ unsigned long long g_stamps[32];
-#define STAMP_DECL unsigned long long _t0 = __builtin_amdgcn_s_memtime(), _t1, _acc[20] = {0}
-#define STAMP(k) do { _t1 = __builtin_amdgcn_s_memtime(); _acc[k] += _t1 - _t0; _t0 = _t1; } while (0)
-#define STAMP_FLUSH(lane) do { if ((lane) == 0) for (int _k = 0; _k < 20; _k++) atomicAdd(&g_stamps[_k], _acc[_k]); } while (0)
+__shared__ unsigned long long g_acc[20];   // per-wave accumulators (diagnostic build only: costs one workgroup of occupancy)
+__shared__ unsigned long long g_t0;
+#define STAMP_NOW(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define STAMP_DECL
+#define STAMP_INIT(lane) do { if ((lane) < 20) g_acc[lane] = 0; unsigned long long _t; STAMP_NOW(_t); g_t0 = _t; __syncthreads(); } while (0)
+#define STAMP(k) do { unsigned long long _t; STAMP_NOW(_t); if (threadIdx.x == 0) { g_acc[k] += _t - g_t0; g_t0 = _t; } } while (0)
+#define STAMP_FLUSH(lane)
+#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 20) atomicAdd(&g_stamps[lane], g_acc[lane]); } while (0)
 #else
 #define STAMP_DECL
+#define STAMP_INIT(lane)
 #define STAMP(k)
 #define STAMP_FLUSH(lane)
+#define STAMP_FINAL(lane)
 #endif
 
 // ------------------------------------------------------------------------------------------------ model
@@ -480,7 +487,7 @@ DI double chol_lanes(double a, int lane, bool* ok) {
   for (int k = 0; k < NV; k++) {
     const double akk = __shfl(a, k * 9, 64);
     if (!(akk > 0)) good = false;
-    const double d = sqrt(akk), inv = 1.0 / d;
+    const double inv = rsqrt(akk), d = akk * inv;  // one transcendental per pivot
     const double lik = __shfl(a, i * 8 + k, 64) * inv;
     const double ljk = __shfl(a, j * 8 + k, 64) * inv;
     if (j == k) { if (i == k) a = d; else if (i > k) a = lik; }

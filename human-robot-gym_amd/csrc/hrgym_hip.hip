@@ -457,7 +457,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
-  STAMP_DECL;
+  STAMP(0);
   if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
     if (lane < NARM) {
       const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
@@ -531,6 +531,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
   int has_collision = 0, collision_type = HRG_COL_NULL, crash = 0;
+  STAMP_INIT(lane);
   if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
   wave_sync();
   screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
@@ -589,8 +590,11 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
     s.goal_index = (s.goal_index + 1) % m.n_goals;
     goal_sample(dm_, lane, gid, s.goal_index);
   }
+  STAMP(8);
   if (d) env_reset(dm_, lane, gid, obs);
   else write_obs(dm_, lane, goal, obs);
+  STAMP(9);
+  STAMP_FINAL(lane);
 }
 
 // ================================================================================================ kernels
@@ -674,6 +678,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int i = 0; i < NV; i++) {
     if ((i < NARM) != (desc->jnt_type[i] == 0)) return fail(HRG_ERR_INVALID, "expected 6 hinges followed by 2 slides");
     if (i < NARM && desc->body_parent[i] != i - 1) return fail(HRG_ERR_INVALID, "arm must be a serial chain");
+    if (i < NARM && !(desc->jnt_axis[i][0] == 0 && desc->jnt_axis[i][1] == 0 && desc->jnt_axis[i][2] == 1)) return fail(HRG_ERR_INVALID, "arm hinges must turn about the local z axis");
     if (i >= NARM && desc->body_parent[i] != NARM - 1) return fail(HRG_ERR_INVALID, "fingers must hang off the last link");
   }
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)

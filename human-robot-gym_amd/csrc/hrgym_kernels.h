@@ -20,12 +20,17 @@ DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_o
 #pragma unroll 1
     for (int i = 0; i < NARM; i++) {
       double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
-      double Rl[9], Rj[9], t[3];
-      m3mul(Rl, R, dm->Rq[i]);
+      double Rj[9], t[3], sn, cs;
       m3mulv(t, R, m.body_pos[i]);
       v3add(p, p, t);
-      axisangle2mat(Rj, m.jnt_axis[i], q);
-      m3mul(R, Rl, Rj);
+      // arm hinges turn about the local z axis (robot.xml:33-58, checked at create): Rq Rz(q) mixes the first two columns
+      sincos_small(q, &sn, &cs);
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double c0 = dm->Rq[i][3 * a], c1 = dm->Rq[i][3 * a + 1];
+        Rj[3 * a] = cs * c0 + sn * c1; Rj[3 * a + 1] = cs * c1 - sn * c0; Rj[3 * a + 2] = dm->Rq[i][3 * a + 2];
+      }
+      m3mul(R, R, Rj);
       if (cfg == 2) {
 #pragma unroll
         for (int k = 0; k < 9; k++) L.kR[i][k] = R[k];
@@ -287,7 +292,6 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   const double dt = m.timestep, t = s.time;
   const bool shield_on = m.shield_type != HRG_SHIELD_OFF;
   const bool have_vel = s.n_meas >= 1 && t > s.meas_prev_t;
-  STAMP_DECL;
   // current motion = the Motion returned last cycle (same trajectory, same path state -> bitwise the same evaluation)
   if (lane < NARM) { L.cq[lane] = s.des_q[lane]; L.cv[lane] = s.des_v[lane]; L.ca[lane] = s.des_a[lane]; }
   wave_sync();
@@ -381,10 +385,17 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
         r = dm->hc_th[lane] + m.meas_err_pos + dm->hc_v[lane] * Td;
         mdl = kind == 1 ? 1 : 2;
       }
+      double hc[3], hh[3];
+      for (int a = 0; a < 3; a++) { hc[a] = 0.5 * (c1[a] + c2[a]); hh[a] = 0.5 * (c2[a] - c1[a]); }
+      const double hl = sqrt(v3dot(hh, hh));
 #pragma unroll 1
       for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
-        double x1[3], x2[3];
+        double x1[3], x2[3], rcn[3], rh[3], dc[3];
         const double rr = L.rc[c][6] + r;
+        for (int a = 0; a < 3; a++) { rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]); rh[a] = 0.5 * (L.rc[c][3 + a] - L.rc[c][a]); }
+        v3sub(dc, rcn, hc);
+        const double reach = sqrt(v3dot(rh, rh)) + hl + rr + 1e-9;
+        if (v3dot(dc, dc) > reach * reach) continue;  // bounding spheres apart: cannot intersect
         if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true;
       }
       if (dbg_h) {
@@ -429,7 +440,6 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   }
   wave_sync();
   STAMP(15);
-  STAMP_FLUSH(lane);
 }
 
 DI void shield_reset(const DevModel* __restrict__ dm_, int lane) {
@@ -491,7 +501,18 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
         margin = m.contact_margin_human;
         c.b2 = -2;
       }
+      // broadphase: bounding spheres of the two capsules (conservative: a culled pair cannot be a contact); the whole
+      // wave skips the narrowphase when no lane survives, which is the common case
+      bool near = false;
       if (valid) {
+        double ca[3], cb[3], dc[3], h1[3], h2[3];
+        for (int a = 0; a < 3; a++) { ca[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]); h1[a] = 0.5 * (L.rcapw[i][3 + a] - L.rcapw[i][a]);
+                                      cb[a] = 0.5 * (a1[a] + a2[a]); h2[a] = 0.5 * (a2[a] - a1[a]); }
+        v3sub(dc, ca, cb);
+        const double reach = sqrt(v3dot(h1, h1)) + sqrt(v3dot(h2, h2)) + m.rcap_r[i] + r2 + margin + 1e-9;
+        near = v3dot(dc, dc) <= reach * reach;
+      }
+      if (__any(near) && valid && near) {
         double c1[3], c2[3], d[3];
         const double d2 = seg_seg(&L.rcapw[i][0], &L.rcapw[i][3], a1, a2, c1, c2), dd = sqrt(d2), dist = dd - m.rcap_r[i] - r2;
         if (dist < margin) {

@@ -16,8 +16,8 @@ for k in range(150): G.step(acts[k % 16])
 torch.cuda.synchronize(); lib.hrg_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
 for k in range(50): G.step(acts[k % 16])
 torch.cuda.synchronize(); lib.hrg_debug_stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
-names = {0: "loop/ctrl prev", 1: "shield_step (total)", 2: "robot_dynamics_terms", 3: "controller", 4: "human_control", 5: "collide", 6: "classify", 7: "dynamics_step", 8: "epilogue", 9: "reset/obs",
+names = {0: "cycle prologue (set_goal)", 1: "shield: tail (after des)", 2: "robot_dynamics_terms", 3: "controller", 4: "human_control", 5: "collide", 6: "classify", 7: "dynamics_step", 8: "epilogue", 9: "reset/obs",
          10: " shield: cur+plan", 11: " shield: paths", 12: " shield: qe eval", 13: " shield: chain fk", 14: " shield: reach+verify", 15: " shield: update+des"}
-tot = out[:10].sum()
+tot = out[:16].sum()
 for k in range(16):
     print("%-26s %6.2f %%  (%.0f cycles/env-step)" % (names.get(k, k), 100 * out[k] / tot, out[k] / (50 * 4096)))
