@@ -1,0 +1,105 @@
+"""C-ABI surface on the GPU: masked reset, state get/set round trip, capsule taps, kernel timer, HipVecEnv end to end."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import human_robot_gym_amd as hrg
+from helpers import RTOL, assert_state_close, make_pair
+
+pytestmark = pytest.mark.gpu
+
+
+def test_masked_reset_and_state_roundtrip():
+    import torch
+    O, G = make_pair(8, dict(shield_type="SSM", horizon=50))
+    O.reset(); G.reset()
+    rng = np.random.RandomState(0)
+    for _ in range(3):
+        a = rng.uniform(-1, 1, (8, 7))
+        O.step(a); G.step(torch.from_numpy(a).cuda())
+    mask = np.array([1, 0, 0, 1, 0, 1, 0, 0], np.uint8)
+    before = [G.get_state(e) for e in range(8)]
+    oo = O.reset(mask)
+    og = G.reset(torch.from_numpy(mask).cuda()).cpu().numpy()
+    np.testing.assert_allclose(og[mask == 1], oo[mask == 1], rtol=RTOL, atol=1e-6)
+    for e in range(8):
+        sg = G.get_state(e)
+        assert_state_close(O.get_state(e), sg, f"env {e}")
+        if not mask[e]:
+            assert bytes(sg) == bytes(before[e])          # untouched envs keep their block bit for bit
+        else:
+            assert sg.episode == before[e].episode + 1 and sg.timestep == 0
+    s = G.get_state(2)
+    s.qpos[0] = 0.123
+    G.set_state(5, s)
+    assert bytes(G.get_state(5)) == bytes(s)
+    O.close(); G.close()
+
+
+def test_reach_capsule_taps_match_oracle():
+    import torch
+    O, G = make_pair(8, dict(shield_type="SSM", horizon=50))
+    G.enable_taps(True)
+    O.reset(); G.reset()
+    rng = np.random.RandomState(1)
+    for _ in range(4):
+        a = rng.uniform(-1, 1, (8, 7))
+        O.step(a); G.step(torch.from_numpy(a).cuda())
+    ro, ho, no = O.capsules()
+    rg, hg, ng = G.capsules()
+    np.testing.assert_array_equal(ng, no)
+    np.testing.assert_allclose(rg, ro, rtol=RTOL, atol=1e-7)   # SafetyShield.getRobotReachCapsules (failsafe_controller.py:393)
+    for e in range(8):
+        np.testing.assert_allclose(hg[e, :no[e]], ho[e, :no[e]], rtol=RTOL, atol=1e-7)  # getHumanReachCapsules (:416)
+    assert (ro[:, :, 6] > 0).all() and no.min() > 30
+    O.close(); G.close()
+
+
+def test_kernel_timer_and_errors():
+    import torch
+    from human_robot_gym_amd._lib import HipBatch, HrgError
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=100, max_frames=120)
+    G = HipBatch(hrg.build_model_desc(dict(shield_type="OFF"), n_clips=2), clips, 64)
+    G.reset()
+    assert G.kernel_time() == (0.0, 0)
+    a = torch.zeros((64, 7), dtype=torch.float64, device="cuda")
+    for _ in range(3):
+        G.step(a)
+    ms, n = G.kernel_time()
+    assert n == 3 and 0 < ms < 1000
+    with pytest.raises(ValueError):
+        G.step(torch.zeros((63, 7), dtype=torch.float64, device="cuda"))
+    G.close()
+    with pytest.raises(HrgError, match="PFL"):
+        HipBatch(hrg.build_model_desc(dict(shield_type="PFL"), n_clips=2), clips, 4)
+
+
+def test_hip_vec_env_end_to_end_matches_oracle_backend():
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    from helpers import OracleBackend
+    kw = dict(shield_type="SSM", horizon=6, reward_shaping=True)
+    cp = dict(replace_type=0, n_resamples=20)
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    desc = hrg.build_model_desc(kw, n_clips=2, collision_prevention=cp)
+    e_gpu = HipVecEnv(8, env_kwargs=kw, clips=clips, collision_prevention=cp)
+    e_cpu = HipVecEnv(8, env_kwargs=kw, clips=clips, collision_prevention=cp, backend=OracleBackend(desc, clips, 8))
+    np.testing.assert_allclose(e_gpu.reset(), e_cpu.reset(), rtol=RTOL, atol=1e-6)
+    rng = np.random.RandomState(0)
+    for k in range(14):
+        a = rng.uniform(-1, 1, (8, 7))
+        og, rg, dg, ig = e_gpu.step(a)
+        oc, rc, dc, ic = e_cpu.step(a)
+        np.testing.assert_allclose(og, oc, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(rg, rc, rtol=RTOL, atol=1e-6)
+        np.testing.assert_array_equal(dg, dc)
+        for i in range(8):
+            assert set(ig[i]) == set(ic[i])
+            for key in ig[i]:
+                if key in ("terminal_observation", "action"):
+                    np.testing.assert_allclose(ig[i][key], ic[i][key], rtol=RTOL, atol=1e-6)
+                elif key == "episode":
+                    assert ig[i][key]["l"] == ic[i][key]["l"] and ig[i][key]["r"] == pytest.approx(ic[i][key]["r"], rel=1e-5)
+                else:
+                    assert ig[i][key] == ic[i][key], key
+    e_gpu.close(); e_cpu.close()
