@@ -1354,3 +1354,107 @@ void hrgo_test_human_fk(const hrg_model_desc* m, const double* mp, const double*
 }
 int hrgo_test_config_collides(const hrg_model_desc* m, const double* q6) { return config_collides(m, q6); }
 double hrgo_test_u01(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) { return rng_u01(seed, env, ep, stream, idx); }
+
+/* =============================================================================================== human dynamics (study)
+ * Articulated-body forward dynamics of the 23 x 3-hinge human tree hanging off the (static) mocap pelvis, world frame
+ * about the world origin.  In the reference these 69 hinges are dynamic DoFs whose qpos is overwritten every substep
+ * (human_env.py:1766-1767) while qvel integrates freely.  Used by hrgo_test_human_dyn to study how
+ * that velocity drift behaves; not wired into env_step yet. */
+static void m6_mulv(double* r, const double* A, const double* x) {
+  for (int i = 0; i < 6; i++) { double t = 0; for (int j = 0; j < 6; j++) t += A[6 * i + j] * x[j]; r[i] = t; }
+}
+static void crm6(double* r, const double* v, const double* m_) { /* motion cross product */
+  double a[3], b[3], c[3];
+  v3cross(a, v, m_); v3cross(b, v, m_ + 3); v3cross(c, v + 3, m_);
+  for (int i = 0; i < 3; i++) { r[i] = a[i]; r[3 + i] = b[i] + c[i]; }
+}
+static void crf6(double* r, const double* v, const double* f) { /* force cross product */
+  double a[3], b[3], c[3];
+  v3cross(a, v, f); v3cross(b, v + 3, f + 3); v3cross(c, v, f + 3);
+  for (int i = 0; i < 3; i++) { r[i] = a[i] + b[i]; r[3 + i] = c[i]; }
+}
+static void human_aba(const hrg_model_desc* m, const human_kin* h, const double* qh, const double* qd, double armature, double* qacc) {
+  static const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
+  double S[HRG_NHB][3][6], v[HRG_NHB][6], c[HRG_NHB][6], IA[HRG_NHB][36], pA[HRG_NHB][6], U[HRG_NHB][3][6], Di[HRG_NHB][9], u[HRG_NHB][3], a[HRG_NHB][6];
+  memset(v[0], 0, sizeof v[0]);
+  for (int b = 1; b < HRG_NHB; b++) {
+    int par = m->hb_parent[b];
+    double anc[3], t[3], R1[9], R2[9], Rz[9], Ry[9], w[3][3];
+    m3mulv(t, h->R[par], m->hb_anchor[b]); v3add(anc, h->p[par], t);
+    axisangle2mat(Rz, ez, qh[3 * (b - 1)]); axisangle2mat(Ry, ey, qh[3 * (b - 1) + 1]);
+    m3mul(R1, h->R[par], Rz); m3mul(R2, R1, Ry);
+    m3mulv(w[0], h->R[par], ez); m3mulv(w[1], R1, ey); m3mulv(w[2], R2, ex);
+    memcpy(v[b], v[par], sizeof v[b]);
+    memset(c[b], 0, sizeof c[b]);
+    for (int k = 0; k < 3; k++) {
+      v3cpy(S[b][k], w[k]); v3cross(S[b][k] + 3, anc, w[k]);
+      double j[6], cr[6];
+      for (int i = 0; i < 6; i++) j[i] = S[b][k][i] * qd[3 * (b - 1) + k];
+      for (int i = 0; i < 6; i++) v[b][i] += j[i];
+      crm6(cr, v[b], j);
+      for (int i = 0; i < 6; i++) c[b][i] += cr[i];
+    }
+    /* spatial inertia about the origin: mass 1 at the body-frame origin, unit isotropic rotational inertia (human.xml:46) */
+    const double* cm = h->p[b];
+    double mass = 1.0, cc = v3dot(cm, cm), I3[9], hx[9] = {0, -cm[2], cm[1], cm[2], 0, -cm[0], -cm[1], cm[0], 0};
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) I3[3 * i + k] = (i == k ? 1.0 + mass * cc : 0.0) - mass * cm[i] * cm[k];
+    memset(IA[b], 0, sizeof IA[b]);
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) {
+      IA[b][6 * i + k] = I3[3 * i + k];
+      IA[b][6 * i + 3 + k] = mass * hx[3 * i + k];
+      IA[b][6 * (3 + i) + k] = -mass * hx[3 * i + k];
+      IA[b][6 * (3 + i) + 3 + k] = i == k ? mass : 0.0;
+    }
+    double Iv[6];
+    m6_mulv(Iv, IA[b], v[b]);
+    crf6(pA[b], v[b], Iv);
+  }
+  for (int b = HRG_NHB - 1; b >= 1; b--) {
+    double D[9];
+    for (int k = 0; k < 3; k++) m6_mulv(U[b][k], IA[b], S[b][k]);
+    for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { double t = 0; for (int q = 0; q < 6; q++) t += S[b][i][q] * U[b][k][q]; D[3 * i + k] = t + (i == k ? armature : 0.0); }
+    double det = D[0] * (D[4] * D[8] - D[5] * D[7]) - D[1] * (D[3] * D[8] - D[5] * D[6]) + D[2] * (D[3] * D[7] - D[4] * D[6]);
+    double* X = Di[b];
+    X[0] = (D[4] * D[8] - D[5] * D[7]) / det; X[1] = (D[2] * D[7] - D[1] * D[8]) / det; X[2] = (D[1] * D[5] - D[2] * D[4]) / det;
+    X[3] = (D[5] * D[6] - D[3] * D[8]) / det; X[4] = (D[0] * D[8] - D[2] * D[6]) / det; X[5] = (D[2] * D[3] - D[0] * D[5]) / det;
+    X[6] = (D[3] * D[7] - D[4] * D[6]) / det; X[7] = (D[1] * D[6] - D[0] * D[7]) / det; X[8] = (D[0] * D[4] - D[1] * D[3]) / det;
+    for (int k = 0; k < 3; k++) { double t = 0; for (int q = 0; q < 6; q++) t += S[b][k][q] * pA[b][q]; u[b][k] = -t; }
+    int par = m->hb_parent[b];
+    if (par >= 1) {
+      double UD[3][6], Ia[36], pa[6], Iac[6], Du[3];
+      for (int k = 0; k < 3; k++) for (int q = 0; q < 6; q++) UD[k][q] = U[b][0][q] * X[0 * 3 + k] + U[b][1][q] * X[1 * 3 + k] + U[b][2][q] * X[2 * 3 + k];
+      for (int i = 0; i < 6; i++) for (int q = 0; q < 6; q++) Ia[6 * i + q] = IA[b][6 * i + q] - (UD[0][i] * U[b][0][q] + UD[1][i] * U[b][1][q] + UD[2][i] * U[b][2][q]);
+      m6_mulv(Iac, Ia, c[b]);
+      for (int k = 0; k < 3; k++) Du[k] = X[3 * k] * u[b][0] + X[3 * k + 1] * u[b][1] + X[3 * k + 2] * u[b][2];
+      for (int q = 0; q < 6; q++) pa[q] = pA[b][q] + Iac[q] + U[b][0][q] * Du[0] + U[b][1][q] * Du[1] + U[b][2][q] * Du[2];
+      for (int q = 0; q < 36; q++) IA[par][q] += Ia[q];
+      for (int q = 0; q < 6; q++) pA[par][q] += pa[q];
+    }
+  }
+  memset(a[0], 0, sizeof a[0]);
+  for (int i = 0; i < 3; i++) a[0][3 + i] = -m->gravity[i];
+  for (int b = 1; b < HRG_NHB; b++) {
+    int par = m->hb_parent[b];
+    double ap[6], r[3];
+    for (int q = 0; q < 6; q++) ap[q] = a[par][q] + c[b][q];
+    for (int k = 0; k < 3; k++) { double t = 0; for (int q = 0; q < 6; q++) t += U[b][k][q] * ap[q]; r[k] = u[b][k] - t; }
+    for (int k = 0; k < 3; k++) qacc[3 * (b - 1) + k] = Di[b][3 * k] * r[0] + Di[b][3 * k + 1] * r[1] + Di[b][3 * k + 2] * r[2];
+    for (int q = 0; q < 6; q++) a[b][q] = ap[q] + S[b][0][q] * qacc[3 * (b - 1)] + S[b][1][q] * qacc[3 * (b - 1) + 1] + S[b][2][q] * qacc[3 * (b - 1) + 2];
+  }
+}
+/* free evolution of the human joint velocities along one clip: out[t] = max |qvel| after substep t */
+void hrgo_test_human_dyn(const hrg_model_desc* m, const double* frames, int n_frames, int n_sub, double armature, double* out_maxvel, double* out_maxacc) {
+  double qd[HRG_NHQ] = {0}, qa[HRG_NHQ];
+  human_kin h;
+  double site[HRG_NHJ][3];
+  for (int t = 0; t < n_sub; t++) {
+    int fr = (int)floor((double)t / m->anim_step_length) % n_frames;
+    const double* f = frames + (size_t)fr * HRG_FRAME_DIM;
+    double mp[3] = {f[0], f[1], f[2]}, mq[4] = {f[6], f[3], f[4], f[5]};
+    human_fk(m, mp, mq, f + 7, &h, site);
+    human_aba(m, &h, f + 7, qd, armature, qa);
+    double mv = 0, ma = 0;
+    for (int i = 0; i < HRG_NHQ; i++) { qd[i] += m->timestep * qa[i]; if (fabs(qd[i]) > mv) mv = fabs(qd[i]); if (fabs(qa[i]) > ma) ma = fabs(qa[i]); }
+    out_maxvel[t] = mv; out_maxacc[t] = ma;
+  }
+}

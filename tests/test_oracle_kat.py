@@ -207,3 +207,20 @@ def test_human_kinematics_rest_pose_and_bone_lengths(oracle_lib):
         par = d.hb_parent[d.meas_body[k]]
         if par in body_of:
             assert abs(np.linalg.norm(s2[k] - s2[body_of[par]]) - np.linalg.norm(sites[k] - sites[body_of[par]])) < 1e-12
+
+
+def test_study_free_human_joint_dynamics_diverges(oracle_lib):
+    """restating the 69 human hinges as free dynamic DoFs whose qpos is overwritten every substep
+    (human_env.py:1766-1767; unit masses/inertias, armature 0.01, no damping: human.xml:4,46) makes the joint velocities
+    run away within a few simulated seconds even for a static T-pose — articulated-body dynamics under gravity with the
+    configuration pinned.  The reference's episodes last 10-40 s, so this cannot be what its MuJoCo run looks like; the
+    human is therefore kept kinematic until the real engine's behaviour can be observed."""
+    d = hrg.build_model_desc()
+    F = np.ascontiguousarray(hrg.static_clip(100).frames)
+    n = 1000
+    mv, ma = np.zeros(n), np.zeros(n)
+    oracle_lib.hrgo_test_human_dyn(ctypes.byref(d), _p(F), ctypes.c_int(len(F)), ctypes.c_int(n), ctypes.c_double(0.01), _p(mv), _p(ma))
+    assert 5.0 < ma[0] < 20.0            # gravity alone: ~12 rad/s^2 on the worst joint of the T-pose
+    assert mv[250] > 8.0                 # 1 s: > 8 rad/s
+    assert mv[:750].max() > 40.0         # within 3 s: > 40 rad/s somewhere in the tree
+    assert not (mv[-1] < 1e6)            # 4 s: diverged (huge or NaN)
