@@ -673,7 +673,8 @@ size_t hrg_state_bytes(void) { return sizeof(hrg_env_state); }
 
 int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
   if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
-  if (desc->shield_type == HRG_SHIELD_PFL) return fail(HRG_ERR_UNSUPPORTED, "shield_type PFL is not implemented yet");
+  if (!(desc->failsafe_sdot >= 0.0 && desc->failsafe_sdot < 1.0)) return fail(HRG_ERR_INVALID, "failsafe_sdot must be in [0, 1)");
+  if (desc->shield_type != HRG_SHIELD_PFL && desc->failsafe_sdot != 0.0) return fail(HRG_ERR_INVALID, "failsafe_sdot > 0 only with shield_type PFL");
   if (clips->n_clips < 1 || clips->n_clips > HRG_MAX_CLIPS || clips->n_clips != desc->n_clips) return fail(HRG_ERR_INVALID, "clip table / desc.n_clips mismatch");
   for (int i = 0; i < NV; i++) {
     if ((i < NARM) != (desc->jnt_type[i] == 0)) return fail(HRG_ERR_INVALID, "expected 6 hinges followed by 2 slides");
@@ -726,9 +727,9 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   hm->phase_mask = 0xff;
   {
     double se, ve, ae;
-    path_plan(&hm->brake_full, 0.0, 1.0, 0.0, 0.0, desc->path_amax, desc->path_jmax);
+    path_plan(&hm->brake_full, 0.0, 1.0, 0.0, desc->failsafe_sdot, desc->path_amax, desc->path_jmax);
     hm->brake_T = path_total(&hm->brake_full);
-    path_eval(&hm->brake_full, hm->brake_T, 0.0, &se, &ve, &ae);
+    path_eval(&hm->brake_full, hm->brake_T, desc->failsafe_sdot, &se, &ve, &ae);
     hm->brake_ds = se;
   }
   if (const char* pm = getenv("HRG_PHASE_MASK")) hm->phase_mask = atoi(pm); // timing experiments only: results are invalid

@@ -297,12 +297,16 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   wave_sync();
   int use_cand = 0;
   if (s.new_goal) {
-    const bool bad = lane < NARM && fabs(L.ca[lane]) > m.a_max_ltt[lane];
+    // candidate trajectory from the NOMINAL state of the active one at the current path position (q, dq/ds, d2q/ds2): it
+    // continues with the current path velocity, so it can be swapped in at any path speed without a jump
+    double nq = 0, nv = 0, na = 0;
+    if (lane < NARM) ltt_eval(&s.ltt, lane, s.path_s, &nq, &nv, &na);
+    const bool bad = lane < NARM && fabs(na) > m.a_max_ltt[lane];
     if (!__any(bad)) {
       use_cand = 1;
       double tj = 0;
       if (lane < NARM) {
-        ltt_plan_joint(&L.cand, lane, L.cq[lane], L.cv[lane], L.ca[lane], s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
+        ltt_plan_joint(&L.cand, lane, nq, nv, na, s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
         for (int i = 0; i < HRG_LTT_NSEG; i++) tj += L.cand.dur[lane][i];
       }
       L.cand.T = wave_max(tj);
@@ -311,7 +315,7 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   }
   STAMP(10);
   const hrg_ltt* Lp = use_cand ? &L.cand : &s.ltt;
-  const double ps = use_cand ? 0.0 : s.path_s, pv = use_cand ? 1.0 : s.path_v, pa = use_cand ? 0.0 : s.path_a;
+  const double ps = use_cand ? 0.0 : s.path_s, pv = s.path_v, pa = s.path_a;
   hrg_path fs2;
   double s1, v1, a1, se, Tb;
   if (pv == 1.0 && pa == 0.0) {
@@ -327,9 +331,9 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
     double ve_, ae;
     path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
     path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
-    path_plan(&fs2, s1, v1, a1, 0.0, m.path_amax, m.path_jmax);
+    path_plan(&fs2, s1, v1, a1, m.failsafe_sdot, m.path_amax, m.path_jmax);
     Tb = path_total(&fs2);
-    path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+    path_eval(&fs2, Tb, m.failsafe_sdot, &se, &ve_, &ae);
   }
   STAMP(11);
   if (shield_on && lane < NARM) {
@@ -425,10 +429,24 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
     s.path_s = s1; s.path_v = v1; s.path_a = a1;
     s.safe_path = fs2;
   } else {
+    // follow the last verified fail-safe profile
     const double k = s.safe_path.k + 1.0;
     s.safe_path.k = k;
     double ns, nv, na;
-    path_eval(&s.safe_path, k * dt, 0.0, &ns, &nv, &na);
+    path_eval(&s.safe_path, k * dt, m.failsafe_sdot, &ns, &nv, &na);
+    // already at (or below) the fail-safe speed — stopped under SSM, at the PFL safe speed under PFL: a new trajectory may
+    // be swapped in although it is not verified safe (sara-shield swaps "if safe or stopped")
+    if (use_cand && s.path_v <= m.failsafe_sdot + 1e-9 && fabs(s.path_a) <= 1e-9) {
+      const double adv = ns - s.path_s;
+      double* dst = (double*)&s.ltt;
+      const double* src = (const double*)&L.cand;
+      for (int q = lane; q < (int)(sizeof(hrg_ltt) / sizeof(double)); q += 64) dst[q] = src[q];
+      s.new_goal = 0;
+      ns = adv;  // the candidate's path axis starts at the current position
+      hrg_path sp;
+      path_plan(&sp, ns, nv, na, m.failsafe_sdot, m.path_amax, m.path_jmax);
+      s.safe_path = sp;
+    }
     s.path_s = ns; s.path_v = nv; s.path_a = na;
   }
   s.is_safe = safe;

@@ -62,6 +62,7 @@ SHIELD_DEFAULTS = dict(
     v_max_allowed=1.0, a_max_allowed=10.0, j_max_allowed=400.0,
     v_max_ltt=1.0, a_max_ltt=2.0, j_max_ltt=15.0,
     secure_radius=0.02,
+    pfl_v_safe=0.25,   # PFL: Cartesian speed [m/s] the arm may keep when the reachable sets intersect (ISO/TS 15066-style transient contact)
     meas_err_pos=0.0, meas_err_vel=0.0, delay=0.0,
 )
 # body parts: (proximal joint, distal joint, thickness [m], v_max [m/s], a_max [m/s^2], kept in POS model)
@@ -362,6 +363,20 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         reach = max(np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p1[c][:]) - base), np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p2[c][:]) - base))
         d.scap_alpha[c] = reach * (sp["a_max_allowed"] + sp["v_max_allowed"] ** 2)
     d.secure_radius = sp["secure_radius"]
+    # fail-safe target path speed: SSM/OFF brake to a stop; PFL brakes to the path speed at which no link point can move
+    # faster than pfl_v_safe: bound sum_j v_max_ltt_j * (reach of everything downstream of joint j) on the link speeds
+    if d.shield_type == CONST["HRG_SHIELD_PFL"]:
+        v_cart = 0.0
+        for j in range(NARM):
+            rj = 0.0
+            for c in range(j, CONST["HRG_NSHIELD_RCAP"]):
+                b = d.scap_body[c]
+                for q in (d.scap_p1[c][:], d.scap_p2[c][:]):
+                    rj = max(rj, float(np.linalg.norm(p[b] + R[b] @ np.asarray(q) - p[j])) + d.scap_r[c])
+            v_cart += sp["v_max_ltt"] * rj
+        d.failsafe_sdot = min(0.9, sp["pfl_v_safe"] / v_cart)
+    else:
+        d.failsafe_sdot = 0.0
     d.n_bodypart = len(BODY_PARTS)
     for k, (a, b, th, vm, am, inpos) in enumerate(BODY_PARTS):
         d.bp_joint[k][:] = [HUMAN_JOINT_ELEMENTS.index(a), HUMAN_JOINT_ELEMENTS.index(b)]

@@ -168,6 +168,7 @@ typedef struct hrg_model_desc {
   double v_max_allowed[HRG_NARM], a_max_allowed[HRG_NARM], j_max_allowed[HRG_NARM];
   double v_max_ltt[HRG_NARM], a_max_ltt[HRG_NARM], j_max_ltt[HRG_NARM];
   double path_amax, path_jmax;  /* limits on s'' and s''' of fail-safe / recovery manoeuvres */
+  double failsafe_sdot;         /* path speed the fail-safe manoeuvre brakes to: 0 (SSM full stop) or the PFL safe speed */
   int32_t scap_body[HRG_NSHIELD_RCAP];
   double scap_p1[HRG_NSHIELD_RCAP][3];
   double scap_p2[HRG_NSHIELD_RCAP][3];

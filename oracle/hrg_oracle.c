@@ -658,24 +658,30 @@ static void shield_step(hrgo_batch* B, int e, double t) {
   /* ---- current motion ---- */
   double cq[NARM], cv[NARM], ca[NARM];
   motion_at(&s->ltt, s->path_s, s->path_v, s->path_a, cq, cv, ca);
-  /* ---- new goal: plan a candidate long-term trajectory from the current motion ---- */
+  /* ---- new goal: plan a candidate long-term trajectory from the NOMINAL state of the active trajectory at the current
+   * path position (q, dq/ds, d2q/ds2).  The candidate then continues with the current path velocity/acceleration, so it
+   * can be swapped in at any path speed without a jump in the commanded motion (at s' = 1 nominal = actual). ---- */
   hrg_ltt cand;
   int use_cand = 0;
   if (s->new_goal) {
+    double nq[NARM], nv[NARM], na[NARM];
     int plannable = 1;
-    for (int j = 0; j < NARM; j++) if (fabs(ca[j]) > m->a_max_ltt[j]) plannable = 0;
-    if (plannable) { ltt_plan(m, &cand, cq, cv, ca, s->new_goal_q); use_cand = 1; }
+    for (int j = 0; j < NARM; j++) {
+      ltt_eval(&s->ltt, j, s->path_s, &nq[j], &nv[j], &na[j]);
+      if (fabs(na[j]) > m->a_max_ltt[j]) plannable = 0;
+    }
+    if (plannable) { ltt_plan(m, &cand, nq, nv, na, s->new_goal_q); use_cand = 1; }
   }
   const hrg_ltt* L = use_cand ? &cand : &s->ltt;
-  double ps = use_cand ? 0.0 : s->path_s, pv = use_cand ? 1.0 : s->path_v, pa = use_cand ? 0.0 : s->path_a;
+  double ps = use_cand ? 0.0 : s->path_s, pv = s->path_v, pa = s->path_a;
   /* ---- candidate: one recovery step towards s'=1, then fail-safe brake to s'=0 ---- */
   hrg_path rec, fs2;
   double s1, v1, a1, se, ve_, ae;
   path_plan(&rec, ps, pv, pa, 1.0, m->path_amax, m->path_jmax);
   path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
-  path_plan(&fs2, s1, v1, a1, 0.0, m->path_amax, m->path_jmax);
+  path_plan(&fs2, s1, v1, a1, m->failsafe_sdot, m->path_amax, m->path_jmax);
   double Tb = path_total(&fs2);
-  path_eval(&fs2, Tb, 0.0, &se, &ve_, &ae);
+  path_eval(&fs2, Tb, m->failsafe_sdot, &se, &ve_, &ae);
   int safe = 1;
   if (m->shield_type != HRG_SHIELD_OFF) {
     /* robot reach over [current config, config at the end of the brake] */
@@ -712,8 +718,19 @@ static void shield_step(hrgo_batch* B, int e, double t) {
     s->path_s = s1; s->path_v = v1; s->path_a = a1;
     s->safe_path = fs2;
   } else {
+    /* follow the last verified fail-safe profile */
+    double ns, nv_, na_;
     s->safe_path.k += 1.0;
-    path_eval(&s->safe_path, s->safe_path.k * dt, 0.0, &s->path_s, &s->path_v, &s->path_a);
+    path_eval(&s->safe_path, s->safe_path.k * dt, m->failsafe_sdot, &ns, &nv_, &na_);
+    /* the robot already moves at (or below) the fail-safe speed — stopped under SSM, at the PFL safe speed under PFL: a new
+     * trajectory may be swapped in although it is not verified safe (sara-shield swaps "if safe or stopped") */
+    if (use_cand && s->path_v <= m->failsafe_sdot + 1e-9 && fabs(s->path_a) <= 1e-9) {
+      double adv = ns - s->path_s;
+      s->ltt = cand; s->new_goal = 0;
+      ns = adv;  /* the candidate's path axis starts at the current position */
+      path_plan(&s->safe_path, ns, nv_, na_, m->failsafe_sdot, m->path_amax, m->path_jmax);
+    }
+    s->path_s = ns; s->path_v = nv_; s->path_a = na_;
   }
   s->is_safe = safe;
   motion_at(&s->ltt, s->path_s, s->path_v, s->path_a, s->des_q, s->des_v, s->des_a);

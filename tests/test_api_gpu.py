@@ -71,8 +71,10 @@ def test_kernel_timer_and_errors():
     with pytest.raises(ValueError):
         G.step(torch.zeros((63, 7), dtype=torch.float64, device="cuda"))
     G.close()
-    with pytest.raises(HrgError, match="PFL"):
-        HipBatch(hrg.build_model_desc(dict(shield_type="PFL"), n_clips=2), clips, 4)
+    bad = hrg.build_model_desc(dict(shield_type="SSM"), n_clips=2)
+    bad.failsafe_sdot = 0.3                                # only PFL may keep moving when unsafe
+    with pytest.raises(HrgError, match="failsafe_sdot"):
+        HipBatch(bad, clips, 4)
 
 
 def test_hip_vec_env_end_to_end_matches_oracle_backend():
