@@ -68,12 +68,14 @@ __shared__ unsigned long long g_t0;
 #define STAMP_INIT(lane) do { if ((lane) < 20) g_acc[lane] = 0; unsigned long long _t; STAMP_NOW(_t); g_t0 = _t; __syncthreads(); } while (0)
 #define STAMP(k) do { unsigned long long _t; STAMP_NOW(_t); if (threadIdx.x == 0) { g_acc[k] += _t - g_t0; g_t0 = _t; } } while (0)
 #define STAMP_FLUSH(lane)
+#define COUNT(k, n) do { if (threadIdx.x == 0) g_acc[k] += (n); } while (0)
 #define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 20) atomicAdd(&g_stamps[lane], g_acc[lane]); } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_INIT(lane)
 #define STAMP(k)
 #define STAMP_FLUSH(lane)
+#define COUNT(k, n)
 #define STAMP_FINAL(lane)
 #endif
 

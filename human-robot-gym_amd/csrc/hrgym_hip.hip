@@ -44,6 +44,12 @@ DI void row_cost(int type, double D, double floss, double x, double* c, double* 
   }
 }
 
+DI int row_zone(int type, double D, double floss, double x) {  // which quadratic / linear piece of its cost a row is in
+  if (type == 1) return x < 0;
+  const double lim = floss / D;
+  return x <= -lim ? -1 : (x >= lim ? 1 : 0);
+}
+
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
 HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
@@ -132,6 +138,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   }
   const uint64_t mask = __ballot(active);
   const uint64_t cmask = mask >> ROW_CON0;  // active contact rows
+  COUNT(19, __popcll(mask));  // active rows
   wave_sync();
   // J_r . x for a wave-shared vector x (LDS)
   auto rowdot = [&](const double* x) -> double {
@@ -159,6 +166,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     bool h_is_m = true;
 #pragma unroll 1
     for (int it = 0; it < m.solver_iters; it++) {
+      COUNT(16, 1);  // Newton iterations
       const double y = rowdot(L.qacc) - aref;
       double cc = 0, gg = 0, hh = 0;
       if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
@@ -188,6 +196,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
 #pragma unroll
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
       if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      COUNT(18, (__any(hh != 0) || !h_is_m) ? 1 : 0);  // Hessian factorizations
       if (__any(hh != 0) || !h_is_m) {  // no row with curvature: H == M and its factor is still in LDS
         const double hl = chol_lanes(hval, lane, &ok);
         if (!ok) break;
@@ -212,6 +221,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       const double d1_0 = gd0 + wave_sum(gg * p);
 #pragma unroll 1
       for (int ls = 0; ls < 40; ls++) {
+        COUNT(17, 1);  // line-search evaluations
         double c2, g2 = 0, h2 = 0;
         if (active) row_cost(type, D, floss, y + al * p, &c2, &g2, &h2);
         const double d1 = gd0 + al * dMd + wave_sum(g2 * p);
@@ -225,6 +235,10 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       }
       if (lane < NV) L.qacc[lane] += al * dd;
       wave_sync();
+      // a full Newton step that stayed inside one quadratic piece of every row solved the problem exactly
+      bool moved = false;
+      if (active) moved = row_zone(type, D, floss, y) != row_zone(type, D, floss, y + p);
+      if (al == 1.0 && !__any(moved)) break;
     }
   }
   // mj_checkAcc

@@ -896,6 +896,13 @@ static void row_cost(const efc_t* E, int r, double x, double* c, double* g, doub
   }
 }
 
+/* which quadratic / linear piece of its cost a row is in at x */
+static int row_zone(const efc_t* E, int r, double x) {
+  if (E->type[r] == ROW_UNILATERAL) return x < 0;
+  double lim = E->floss[r] / E->D[r];
+  return x <= -lim ? -1 : (x >= lim ? 1 : 0);
+}
+
 static void solve(const hrg_model_desc* m, const double* M, const double* a0, const efc_t* E, double* a) {
   /* a: in = warm start, out = solution */
   double Ma0[NV];
@@ -960,7 +967,12 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
       else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
       al = nx;
     }
+    /* a full Newton step that stayed inside one quadratic piece of every row solves the problem exactly: the gradient at the
+     * new point is zero up to rounding, so the next iteration would only confirm convergence */
+    int exact = al == 1.0;
+    for (int r = 0; r < E->n && exact; r++) if (row_zone(E, r, x[r]) != row_zone(E, r, x[r] + p[r])) exact = 0;
     for (int i = 0; i < NV; i++) a[i] += al * d[i];
+    if (exact) break;
   }
 }
 

@@ -21,3 +21,5 @@ names = {0: "cycle prologue (set_goal)", 1: "shield: tail (after des)", 2: "robo
 tot = out[:16].sum()
 for k in range(16):
     print("%-26s %6.2f %%  (%.0f cycles/env-step)" % (names.get(k, k), 100 * out[k] / tot, out[k] / (50 * 4096)))
+sub = 50 * 4096 * 25
+print("per substep: Newton iterations %.2f, line-search evaluations %.2f, Hessian factorizations %.2f, active rows %.2f" % (out[16] / sub, out[17] / sub, out[18] / sub, out[19] / sub))
