@@ -409,7 +409,11 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
       double d[3];
       v3sub(d, s.human_site[site], s.eef_pos);
       v = a < 3 ? d[a] : v3norm(d);
-    } else v = goal[lane - 12] - s.qpos[lane - 12];
+    } else if (lane < 18) v = goal[lane - 12] - s.qpos[lane - 12];
+    else if (lane < 24) v = s.qpos[lane - 18];      // robot0_joint_pos
+    else if (lane < 30) v = s.qvel[lane - 24];      // robot0_joint_vel
+    else if (lane < 33) v = s.eef_pos[lane - 30];   // robot0_eef_pos
+    else v = goal[lane - 33];                       // desired_goal
     out[lane] = (float)v;
   }
 }

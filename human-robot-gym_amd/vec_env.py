@@ -61,7 +61,15 @@ INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "action_resamples",
 ]
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
-OBS_KEYS = ["object-state", "goal_difference"]
+OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human_reach_ppo_parallel.yaml:14-16
+# columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
+OBS_COLUMNS = {
+    "object-state": range(0, 12), "goal_difference": range(12, 18), "robot0_joint_pos": range(18, 24),
+    "robot0_joint_vel": range(24, 30), "robot0_eef_pos": range(30, 33), "desired_goal": range(33, 39),
+    "robot0_proprio-state": range(18, 33), "goal-state": list(range(33, 39)) + list(range(12, 18)),
+    "vec_eef_to_human_lh": range(0, 3), "dist_eef_to_human_lh": range(3, 4), "vec_eef_to_human_rh": range(4, 7),
+    "dist_eef_to_human_rh": range(7, 8), "vec_eef_to_human_head": range(8, 11), "dist_eef_to_human_head": range(11, 12),
+}
 
 
 class _TorchBackend:
@@ -119,8 +127,12 @@ class HipVecEnv(_VecEnvBase):
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True):
         if env_id != "ReachHuman":
             raise NotImplementedError(f"env_id {env_id!r}: only ReachHuman is built in this round (DESIGN.md §6)")
-        if obs_keys is not None and list(obs_keys) != OBS_KEYS:
-            raise NotImplementedError(f"obs_keys {obs_keys!r}: the compiled observation layout is {OBS_KEYS}")
+        keys = list(obs_keys) if obs_keys is not None else OBS_KEYS
+        unknown = [k for k in keys if k not in OBS_COLUMNS]
+        if unknown:
+            raise NotImplementedError(f"obs_keys {unknown!r}: available {sorted(OBS_COLUMNS)}")
+        self.obs_keys = keys
+        self._cols = np.array([c for k in keys for c in OBS_COLUMNS[k]], dtype=np.int64)  # GymWrapper: concatenate in key order
         kw = dict(env_kwargs or {})
         if seed is not None:
             kw["seed"] = int(seed)
@@ -131,7 +143,7 @@ class HipVecEnv(_VecEnvBase):
         self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check)
         self._device, self._env_id0 = device, env_id0
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
-        obs_space = _Box(-np.inf, np.inf, shape=(CONST["HRG_OBS_DIM"],), dtype=np.float32)
+        obs_space = _Box(-np.inf, np.inf, shape=(len(self._cols),), dtype=np.float32)
         act_space = _Box(-1.0, 1.0, shape=(CONST["HRG_ACT_DIM"],), dtype=np.float32)
         super().__init__(n_envs, obs_space, act_space)
         self.info_dicts = info_dicts
@@ -145,7 +157,7 @@ class HipVecEnv(_VecEnvBase):
     def reset(self):
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
-        return np.array(self._backend.reset(), copy=True)
+        return np.asarray(self._backend.reset())[:, self._cols]
 
     def step_async(self, actions):
         actions = np.asarray(actions, np.float64).reshape(self.num_envs, CONST["HRG_ACT_DIM"])
@@ -154,7 +166,7 @@ class HipVecEnv(_VecEnvBase):
 
     def step_wait(self):
         obs, term_obs, reward, done, info = self._backend.step_wait()
-        obs, reward = np.array(obs, copy=True), np.array(reward, copy=True)
+        obs, reward = np.asarray(obs)[:, self._cols], np.array(reward, copy=True)
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
         self._ep_len += 1
@@ -172,7 +184,7 @@ class HipVecEnv(_VecEnvBase):
             d = {k: (bool(info[i, j]) if k in _BOOL_KEYS else int(info[i, j])) for j, k in enumerate(INFO_KEYS)}
             d["action"] = self._actions[i]  # collision_prevention_wrapper.py:42-43: the executed action
             if dones[i]:
-                d["terminal_observation"] = np.array(term_obs[i], copy=True)
+                d["terminal_observation"] = np.asarray(term_obs[i])[self._cols]
                 d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
             else:
                 d.pop("TimeLimit.truncated")
@@ -229,8 +241,9 @@ class HipGymEnv:
 
     Stepping a finished episode raises ValueError like HumanEnv.step (human_env.py:487-488)."""
 
-    def __init__(self, env_kwargs=None, seed=None, clips=None, device=0, backend=None):
-        self._vec = HipVecEnv(1, env_kwargs=env_kwargs, seed=seed, clips=clips, device=device, backend=backend)
+    def __init__(self, env_kwargs=None, seed=None, clips=None, device=0, backend=None, obs_keys=None, collision_prevention=None):
+        self._vec = HipVecEnv(1, env_kwargs=env_kwargs, seed=seed, clips=clips, device=device, backend=backend, obs_keys=obs_keys,
+                              collision_prevention=collision_prevention)
         self.observation_space = self._vec.observation_space
         self.action_space = self._vec.action_space
         self._done = True
@@ -256,8 +269,13 @@ class HipGymEnv:
         return obs[0], float(rew[0]), False, info
 
     def observation_dict(self, obs):
-        """Split a flat observation back into the reference's modality keys."""
-        return OrderedDict([("object-state", obs[:12]), ("goal_difference", obs[12:])])
+        """Split a flat observation back into the reference's observable / modality keys."""
+        out, k0 = OrderedDict(), 0
+        for key in self._vec.obs_keys:
+            n = len(OBS_COLUMNS[key])
+            out[key] = obs[k0:k0 + n]
+            k0 += n
+        return out
 
     def close(self):
         self._vec.close()

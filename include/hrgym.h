@@ -57,7 +57,9 @@ extern "C" {
 #define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
 #define HRG_NHCAP_MAX 64  /* human reach capsules over all three models (fits one wavefront) */
 #define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
-#define HRG_OBS_DIM 18    /* object-state(12) + goal_difference(6): human_reach_ppo_parallel.yaml:14-16 */
+#define HRG_OBS_DIM 39    /* superset of the flat observation; the host selects columns by obs_keys:
+                          *  [0:12] object-state  [12:18] goal_difference  [18:24] robot0_joint_pos  [24:30] robot0_joint_vel
+                          *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666) */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
 #define HRG_INFO_DIM 13
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */

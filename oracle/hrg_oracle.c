@@ -988,6 +988,9 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const d
     obs[4 * i + 3] = (float)v3norm(d);
   }
   for (int j = 0; j < NARM; j++) obs[12 + j] = (float)(goal[j] - s->qpos[j]);
+  /* robot0_proprio-state = joint_pos, joint_vel, eef_pos (reach_human_env.py:619-636); goal modality: desired_goal (646-647) */
+  for (int j = 0; j < NARM; j++) { obs[18 + j] = (float)s->qpos[j]; obs[24 + j] = (float)s->qvel[j]; obs[33 + j] = (float)goal[j]; }
+  for (int a = 0; a < 3; a++) obs[30 + a] = (float)s->eef_pos[a];
 }
 
 /* HumanEnv._check_action_safety (human_env.py:931-946): does the arm at configuration q6 hit the static collision objects

@@ -25,10 +25,11 @@ def test_shard_range_partitions_the_batch():
 
 def test_packed_layout_matches_hip_batch_layout():
     lay = hdist.packed_layout(4096)
-    assert lay["sizes"] == [4 * 4096 * 18, 4 * 4096 * 18, 4 * 4096, 4 * 4096 * CONST["HRG_INFO_DIM"], 4096] and all(o % 256 == 0 for o in lay["offsets"])
+    od = CONST["HRG_OBS_DIM"]
+    assert lay["sizes"] == [4 * 4096 * od, 4 * 4096 * od, 4 * 4096, 4 * 4096 * CONST["HRG_INFO_DIM"], 4096] and all(o % 256 == 0 for o in lay["offsets"])
     blk = np.arange(lay["total"], dtype=np.uint32).astype(np.uint8)
     u = hdist.unpack(blk, 4096)
-    assert u["obs"].shape == (4096, 18) and u["info"].shape == (4096, CONST["HRG_INFO_DIM"]) and u["done"].shape == (4096,)
+    assert u["obs"].shape == (4096, od) and u["info"].shape == (4096, CONST["HRG_INFO_DIM"]) and u["done"].shape == (4096,)
 
 
 def _rollout(lo, hi, steps):

@@ -18,7 +18,7 @@ def test_vec_env_contract_and_autoreset():
     env = _vec(4, kw)
     assert env.num_envs == 4 and env.observation_space.shape == (18,) and env.action_space.shape == (7,)
     obs = env.reset()
-    assert obs.shape == (4, 18) and obs.dtype == np.float32
+    assert obs.shape == (4, 18) and obs.dtype == np.float32  # default obs_keys: object-state + goal_difference
     rng = np.random.RandomState(0)
     rets = np.zeros(4)
     for k in range(5):
@@ -66,7 +66,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         HipVecEnv(2, env_id="PickPlaceHumanCart", backend=object())
     with pytest.raises(NotImplementedError):
-        HipVecEnv(2, obs_keys=["goal_difference"], backend=object())
+        HipVecEnv(2, obs_keys=["robot0_eef_quat"], backend=object())
     with pytest.raises(NotImplementedError):
         make_vec_env("ReachHuman", type="goal_env")
     with pytest.raises(AssertionError):
@@ -92,3 +92,26 @@ def test_reward_and_success_logic_against_closed_form():
             assert done[i] == reached
     assert B is not None
     env.close()
+
+
+def test_obs_keys_select_and_order_columns_like_the_gym_wrapper():
+    """GymWrapper(env, keys=obs_keys) concatenates obs[key] in key order (utils/env_util.py:40-51); the ICRA "R" configs use
+    obs_keys=[goal_difference] (config_icra_2024/.../R-SAC.yaml:160-161)."""
+    kw = dict(shield_type="OFF", horizon=20)
+    full = _vec(3, kw, obs_keys=["object-state", "goal_difference", "robot0_proprio-state", "desired_goal"])
+    icra = _vec(3, kw, obs_keys=["goal_difference"])
+    mixed = _vec(3, kw, obs_keys=["robot0_eef_pos", "dist_eef_to_human_head", "goal-state"])
+    assert full.observation_space.shape == (39,) and icra.observation_space.shape == (6,) and mixed.observation_space.shape == (16,)
+    of, oi, om = full.reset(), icra.reset(), mixed.reset()
+    a = np.random.RandomState(0).uniform(-1, 1, (3, 7))
+    for _ in range(3):
+        of, _, _, _ = full.step(a); oi, _, _, _ = icra.step(a); om, _, _, _ = mixed.step(a)
+    np.testing.assert_array_equal(oi, of[:, 12:18])
+    np.testing.assert_array_equal(om[:, :3], of[:, 30:33])            # robot0_eef_pos
+    np.testing.assert_array_equal(om[:, 3], of[:, 11])                # dist_eef_to_human_head
+    np.testing.assert_array_equal(om[:, 4:10], of[:, 33:39])          # goal-state = desired_goal, goal_difference
+    np.testing.assert_array_equal(om[:, 10:16], of[:, 12:18])
+    np.testing.assert_allclose(of[:, 33:39] - of[:, 18:24], of[:, 12:18], atol=1e-6)   # goal - q = goal_difference
+    np.testing.assert_allclose(np.linalg.norm(of[:, 0:3], axis=1), of[:, 3], rtol=1e-6)
+    for e in (full, icra, mixed):
+        e.close()
