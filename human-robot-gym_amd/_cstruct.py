@@ -75,6 +75,7 @@ ClipTable = _STRUCTS["hrg_clip_table"]
 LTT = _STRUCTS["hrg_ltt"]
 Path = _STRUCTS["hrg_path"]
 EnvState = _STRUCTS["hrg_env_state"]
+BoxState = _STRUCTS["hrg_box_state"]
 
 
 def struct_to_dict(s):

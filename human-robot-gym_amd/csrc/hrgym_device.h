@@ -21,6 +21,20 @@
 
 #define NV HRG_NV
 #define NARM HRG_NARM
+// HRG_BOX=1 builds the variant with the manipulation object (PickPlaceHumanCart): this file set is compiled a second time
+// by hrgym_box.hip into its own kernels, so the ReachHuman kernels carry none of the object's registers, LDS or code.
+#ifndef HRG_BOX
+#define HRG_BOX 0
+#endif
+#define NVT HRG_NVT
+#if HRG_BOX
+#define NVS NVT                 // DoF of the constrained system: robot tree + free joint of the cube
+#define NCON_DYN HRG_NCON_DYN_BOX
+#else
+#define NVS NV
+#define NCON_DYN HRG_NCON_DYN
+#endif
+#define BODY_BOX 100            // body code of the cube in Contact.b1/b2
 #define DI __device__ __forceinline__
 // tuning knobs (measured on MI355X, profiles/README.md).  Shipping configuration: every phase inlined into the kernel,
 // 128-VGPR cap (4 waves/SIMD: all 4096 envs of a batch resident at once, 16 single-wave workgroups per CU) and the
@@ -57,6 +71,7 @@
 #define GEOM_HUMAN0 HRG_NRCAP
 #define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
 #define GEOM_FLOOR (GEOM_TABLE + 1)
+#define GEOM_BOX (GEOM_FLOOR + 1)
 
 // ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
 #ifdef HRG_STAMPS
@@ -110,7 +125,7 @@ struct Contact {
 
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
-#define NROW (ROW_CON0 + 4 * HRG_NCON_DYN)
+#define NROW (ROW_CON0 + 4 * NCON_DYN)
 
 // per-workgroup (= per-env) LDS image.  Sized to <= 10 KB so that 16 envs (4 waves/SIMD) are resident per CU:
 // 4096 envs on 256 CUs then run in one round.  Phase-local scratch shares one union.
@@ -119,11 +134,16 @@ struct Lds {
   // robot tree at the simulation state (live across the whole cycle)
   double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], vw[NV][3], vv[NV][3];
   double M[NV * NV], H[NV * NV], Hinv[NV];
-  double bias[NV], a0[NV], Ma0[NV], ctrl[NV], qacc[NV], g[NV], d[NV];
+  double bias[NV], a0[NVS], Ma0[NVS], ctrl[NV], qacc[NVS], g[NVS], d[NVS];
+#if HRG_BOX
+  hrg_box_state bx;                      // the cube (streamed from its own HBM array)
+  double bR[9];                          // its rotation matrix at the current substep
+  double Hb[NVT][NVT + 1];               // Newton Hessian / Cholesky factor of the 14-DoF system
+#endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators
   double rcen[HRG_NRCAP][3];
-  Contact con[HRG_NCON_DYN];
+  Contact con[NCON_DYN];
   union {
     struct {  // shield_step
       double cq[NARM], cv[NARM], ca[NARM], qe[NARM];
@@ -139,7 +159,7 @@ struct Lds {
       int cur[HRG_NPREV_MAX];
     };
     struct {  // dynamics_step: contact rows of J (padded to 9: conflict-free ds_read_b64), per-row gradient / curvature
-      double Jc[4 * HRG_NCON_DYN][NV + 1], rg[NROW], rh[NROW];
+      double Jc[4 * NCON_DYN][NVS + 1], rg[NROW], rh[NROW];
     };
   };
 };
@@ -285,7 +305,7 @@ DI double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6 };
 DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);
@@ -320,6 +340,52 @@ DI double seg_seg(PA p1, PB q1, PC p2, PD q2, double* c1, double* c2) {
   v3sub(d, c1, c2);
   return v3dot(d, d);
 }
+
+#if HRG_BOX
+// closest points of a segment and a cube (centre c, rotation R row-major, half edge hb): the squared distance along the
+// segment is a convex piecewise quadratic in t; safeguarded Newton on its derivative (exact inside one piece).
+template <class PA, class PB, class PC, class PR>
+DI double seg_box(PA p1, PB p2, PC c, PR R, double hb, double* on_seg, double* on_box) {
+  double a[3], d[3], t0[3];
+  v3sub(t0, p1, c);
+  for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  v3sub(t0, p2, p1);
+  for (int k = 0; k < 3; k++) d[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  double g0 = 0, g1 = 0, t;
+  for (int k = 0; k < 3; k++) {
+    const double x0 = a[k], x1 = a[k] + d[k];
+    g0 += (x0 > hb ? x0 - hb : (x0 < -hb ? x0 + hb : 0.0)) * d[k];
+    g1 += (x1 > hb ? x1 - hb : (x1 < -hb ? x1 + hb : 0.0)) * d[k];
+  }
+  if (g0 >= 0) t = 0;
+  else if (g1 <= 0) t = 1;
+  else {
+    double lo = 0, hi = 1;
+    t = -g0 / (g1 - g0);
+#pragma unroll 1
+    for (int it = 0; it < 10; it++) {
+      double g = 0, H = 0;
+      for (int k = 0; k < 3; k++) {
+        const double x = a[k] + t * d[k], e = x > hb ? x - hb : (x < -hb ? x + hb : 0.0);
+        g += e * d[k];
+        if (e != 0) H += d[k] * d[k];
+      }
+      if (fabs(g) <= 1e-13 * (g1 - g0)) break; /* the slope vanished up to rounding: t is the minimiser */
+      if (g < 0) lo = t; else hi = t;
+      double nt = H > 0 ? t - g / H : 0.5 * (lo + hi);
+      if (!(nt > lo && nt < hi)) nt = 0.5 * (lo + hi);
+      t = nt;
+    }
+  }
+  double x[3], y[3], e2 = 0;
+  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb, hb); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+  for (int k = 0; k < 3; k++) {
+    on_seg[k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
+    on_box[k] = c[k] + R[3 * k] * y[0] + R[3 * k + 1] * y[1] + R[3 * k + 2] * y[2];
+  }
+  return e2;
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------ profiles
 DI double scurve_time(double dv, double amax, double jmax) {
@@ -503,6 +569,57 @@ DI void chol_store(double l, int lane, double* Lm, double* invd) {
   Lm[lane] = l;
   if ((lane >> 3) == (lane & 7)) invd[lane & 7] = 1.0 / l;
 }
+#if HRG_BOX
+// Cholesky of the 14x14 Newton Hessian held in g_L.Hb (lower triangle, in place; column NVT of row k receives 1 / L_kk).
+// Right-looking: the pivot column is scaled by lanes = rows, the trailing update runs over lanes = (i, j) entries (4 per
+// lane).  Same subtraction order per entry as a left-looking scalar factorisation.
+DI bool chol_box(int lane) {
+  Lds& L = g_L;
+  int ei[4], ej[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int e = lane + 64 * t;
+    ei[t] = e < NVT * NVT ? e / NVT : -1;
+    ej[t] = e - (e / NVT) * NVT;
+  }
+#pragma unroll 1
+  for (int k = 0; k < NVT; k++) {
+    const double dkk = L.Hb[k][k];
+    if (!(dkk > 0)) return false;
+    const double piv = sqrt(dkk);
+    wave_sync();
+    if (lane == k) { L.Hb[k][k] = piv; L.Hb[k][NVT] = 1.0 / piv; }
+    else if (lane > k && lane < NVT) L.Hb[lane][k] = L.Hb[lane][k] / piv;
+    wave_sync();
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int i = ei[t], j = ej[t];
+      if (i >= 0 && j > k && j <= i) L.Hb[i][j] = L.Hb[i][j] - L.Hb[i][k] * L.Hb[j][k];
+    }
+    wave_sync();
+  }
+  return true;
+}
+// solve with that factor; x_i lives in lane i (< 14)
+DI double chol_box_solve(double b, int lane) {
+  Lds& L = g_L;
+  double x = b;
+#pragma unroll 1
+  for (int k = 0; k < NVT; k++) {
+    const double xk = __shfl(x, k, 64) * L.Hb[k][NVT];
+    if (lane == k) x = xk;
+    else if (lane > k && lane < NVT) x -= L.Hb[lane][k] * xk;
+  }
+#pragma unroll 1
+  for (int k = NVT - 1; k >= 0; k--) {
+    const double xk = __shfl(x, k, 64) * L.Hb[k][NVT];
+    if (lane == k) x = xk;
+    else if (lane < k) x -= L.Hb[k][lane] * xk;
+  }
+  return x;
+}
+#endif
+
 // solve L L' x = b with x_i living in lane i (< 8): column-oriented substitution, the pivot value is broadcast
 // with a scalar readlane, the column of the factor comes from LDS.  Register footprint: one double.
 DI double chol_solve_lanes(const double* Lm, const double* invd, double b, int lane) {

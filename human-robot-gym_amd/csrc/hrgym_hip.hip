@@ -72,6 +72,18 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     L.Ma0[lane] = act - m.jnt_damping[lane] * s.qvel[lane] - L.bias[lane];  // M a0 (exactly the solve's right-hand side)
     L.qacc[lane] = s.qacc_warmstart[lane];
   }
+#if HRG_BOX
+  // free cube: block-diagonal inertia (isotropic: no gyroscopic term), gravity only
+  hrg_box_state& bx = L.bx;
+  const double mdiag = (lane - NV) < 3 ? m.box_mass : m.box_inertia;  // inertia entry of system dof `lane` for NV <= lane < NVT
+  if (lane >= NV && lane < NVT) {
+    const int a = lane - NV;
+    const double ga = a < 3 ? m.gravity[a] : 0.0;
+    L.a0[lane] = ga;
+    L.Ma0[lane] = a < 3 ? m.box_mass * ga : 0.0;
+    L.qacc[lane] = bx.acc_warmstart[a];
+  }
+#endif
   wave_sync();
   {
     const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
@@ -96,7 +108,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     }
   } else if (r < NROW) {
     const int c = (r - ROW_CON0) >> 2, d = (r - ROW_CON0) & 3;
-    if (c < ncon && c < HRG_NCON_DYN) {
+    if (c < ncon && c < NCON_DYN) {
       const Contact& cc = L.con[c];
       const double n[3] = {cc.n[0], cc.n[1], cc.n[2]}, cp[3] = {cc.pos[0], cc.pos[1], cc.pos[2]};
       double t1[3], t2[3], dir[3];
@@ -108,8 +120,9 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
       pos = cc.dist;
       margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
-      diag = ((cc.b1 >= 0 ? m.body_invweight0[cc.b1] : 0.0) + (cc.b2 >= 0 ? m.body_invweight0[cc.b2] : 0.0)) * (1.0 + m.friction_static * m.friction_static);
-      const int am1 = cc.b1 >= 0 ? dm->anc_mask[cc.b1] : 0, am2 = cc.b2 >= 0 ? dm->anc_mask[cc.b2] : 0;
+      const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
+      diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
+      const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
       double nz = 0;
 #pragma unroll 1
       for (int i = 0; i < NV; i++) {
@@ -124,6 +137,19 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         vel += acc * s.qvel[i];
         nz += fabs(acc);
       }
+#if HRG_BOX
+      if (cc.b2 == BODY_BOX) { // the cube is always geom 2: J = dir . (v + w x r); body_invweight0 of a free body = 1/m
+        double rr[3], rxd[3];
+        for (int a = 0; a < 3; a++) rr[a] = cp[a] - bx.pos[a];
+        v3cross(rxd, rr, dir);
+        for (int a = 0; a < 3; a++) { L.Jc[r - ROW_CON0][NV + a] = dir[a]; vel += dir[a] * bx.vel[a]; nz += fabs(dir[a]); }
+        for (int a = 0; a < 3; a++) { L.Jc[r - ROW_CON0][NV + 3 + a] = rxd[a]; vel += rxd[a] * bx.vel[3 + a]; nz += fabs(rxd[a]); }
+        diag += 1.0 / m.box_mass;
+      } else {
+        for (int a = 0; a < HRG_NBOXV; a++) L.Jc[r - ROW_CON0][NV + a] = 0.0;
+      }
+#endif
+      diag *= 1.0 + m.friction_static * m.friction_static;
       cand = nz > 0;
     }
   }
@@ -147,20 +173,24 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     const double* Jr = L.Jc[r - ROW_CON0];
     double t = 0;
 #pragma unroll
-    for (int i = 0; i < NV; i++) t += Jr[i] * x[i];
+    for (int i = 0; i < NVS; i++) t += Jr[i] * x[i];
     return t;
   };
   if (mask == 0) {
-    if (lane < NV) L.qacc[lane] = L.a0[lane];
+    if (lane < NVS) L.qacc[lane] = L.a0[lane];
     wave_sync();
   } else {
     { // warm start vs unconstrained acceleration: keep the cheaper point
       const double ei = L.qacc[mi] - L.a0[mi], ej = L.qacc[mj] - L.a0[mj];
       double c0 = 0, c1 = 0, g_, h_;
       if (active) { row_cost(type, D, floss, rowdot(L.qacc) - aref, &c0, &g_, &h_); row_cost(type, D, floss, rowdot(L.a0) - aref, &c1, &g_, &h_); }
-      const double cost_ws = wave_sum(0.5 * Mij * ei * ej + c0), cost_a0 = wave_sum(c1);
+      double quad = 0.5 * Mij * ei * ej;
+#if HRG_BOX
+      if (lane < HRG_NBOXV) { const double eb = L.qacc[NV + lane] - L.a0[NV + lane]; quad += 0.5 * (lane < 3 ? m.box_mass : m.box_inertia) * eb * eb; }
+#endif
+      const double cost_ws = wave_sum(quad + c0), cost_a0 = wave_sum(c1);
       wave_sync();
-      if (!(cost_ws < cost_a0)) { if (lane < NV) L.qacc[lane] = L.a0[lane]; }
+      if (!(cost_ws < cost_a0)) { if (lane < NVS) L.qacc[lane] = L.a0[lane]; }
       wave_sync();
     }
     bool h_is_m = true;
@@ -184,6 +214,45 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         for (uint64_t mm = cmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
         L.g[lane] = t;
       }
+#if HRG_BOX
+      else if (lane < NVT) {
+        double t = -L.Ma0[lane] + mdiag * L.qacc[lane];
+        gm = t;
+        for (uint64_t mm = cmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+        L.g[lane] = t;
+      }
+      // Hessian of the 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
+#pragma unroll 1
+      for (int e = lane; e < NVT * NVT; e += 64) {
+        const int i = e / NVT, j = e - i * NVT;
+        double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j ? (i - NV < 3 ? m.box_mass : m.box_inertia) : 0.0);
+        if (i == j && i < NV) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; }
+        for (uint64_t mm = cmask; mm;) {
+          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+          const double hq = L.rh[ROW_CON0 + q];
+          if (hq != 0) hv += hq * L.Jc[q][i] * L.Jc[q][j];
+        }
+        L.Hb[i][j] = hv;
+      }
+      wave_sync();
+      double gn = 0, sc = 0;
+#pragma unroll
+      for (int i = 0; i < NVT; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
+      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      if (!chol_box(lane)) break;
+      {
+        const double x = chol_box_solve(lane < NVT ? -L.g[lane] : 0.0, lane);
+        if (lane < NVT) L.d[lane] = x;
+      }
+      wave_sync();
+      const double p = rowdot(L.d);
+      double dd = 0, Mdi = 0;
+      if (lane < NV) {
+        dd = L.d[lane];
+#pragma unroll
+        for (int j = 0; j < NV; j++) Mdi += L.M[lane * NV + j] * L.d[j];
+      } else if (lane < NVT) { dd = L.d[lane]; Mdi = mdiag * dd; }
+#else
       double hval = Mij;
       if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
       for (uint64_t mm = cmask; mm;) {
@@ -216,6 +285,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
 #pragma unroll
         for (int j = 0; j < NV; j++) Mdi += L.M[lane * NV + j] * L.d[j];
       }
+#endif
       const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
       double al = 1.0, lo = 0, hi = -1;
       const double d1_0 = gd0 + wave_sum(gg * p);
@@ -233,7 +303,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
         al = nx;
       }
-      if (lane < NV) L.qacc[lane] += al * dd;
+      if (lane < NVS) L.qacc[lane] += al * dd;
       wave_sync();
       // a full Newton step that stayed inside one quadratic piece of every row solved the problem exactly
       bool moved = false;
@@ -242,7 +312,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     }
   }
   // mj_checkAcc
-  const bool badacc = lane < NV && !(fabs(L.qacc[lane]) < 1e10);
+  const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
   {
@@ -266,6 +336,28 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       s.qpos[lane] = s.qpos[lane] + h * v;
     }
   }
+#if HRG_BOX
+  { // free joint: no damping; the quaternion is integrated with the world-frame angular velocity
+    double vnew = 0;
+    if (lane < HRG_NBOXV) {
+      const double acc = L.qacc[NV + lane];
+      bx.acc_warmstart[lane] = acc;
+      vnew = bx.vel[lane] + h * acc;
+      bx.vel[lane] = vnew;
+    }
+    if (lane < 3) { const double p0 = bx.pos[lane]; bx.obs_pos[lane] = p0; bx.pos[lane] = p0 + h * vnew; }  // obs_pos: body_xpos of the forward pass inside mj_step
+    const double w0 = __shfl(vnew, 3, 64), w1 = __shfl(vnew, 4, 64), w2 = __shfl(vnew, 5, 64);
+    const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+    if (wn > 1e-12) {
+      const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
+      double qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]}, qn[4];
+      quatmul(qn, dq, qo);
+      const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+      wave_sync();
+      if (lane < 4) bx.quat[lane] = qn[lane] / nn;
+    }
+  }
+#endif
   wave_sync();
   return 0;
 }
@@ -413,10 +505,37 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
     else if (lane < 24) v = s.qpos[lane - 18];      // robot0_joint_pos
     else if (lane < 30) v = s.qvel[lane - 24];      // robot0_joint_vel
     else if (lane < 33) v = s.eef_pos[lane - 30];   // robot0_eef_pos
-    else v = goal[lane - 33];                       // desired_goal
+    else if (lane < 39) v = goal[lane - 33];        // desired_goal
+    else v = 0.0;                                   // PickPlaceHumanCart columns
+#if HRG_BOX
+    // PickPlaceHumanCart._setup_observables (pick_place_human_cartesian_env.py:726-841), gripper_aperture (human_env.py:1508-1524)
+    const hrg_box_state& bx = L.bx;
+    if ((lane >= 12 && lane < 18) || (lane >= 33 && lane < 39)) v = 0.0;
+    else if (lane == 39) v = (double)bx.gripped;
+    else if (lane >= 40 && lane < 43) v = bx.obs_pos[lane - 40] - s.eef_pos[lane - 40];
+    else if (lane >= 43 && lane < 46) v = bx.target[lane - 43] - s.eef_pos[lane - 43];
+    else if (lane == 46) {
+      double ap = 0;
+      for (int f = 0; f < HRG_NFINGER; f++) ap += (s.qpos[NARM + f] - m.finger_qpos_range[0][f]) / (m.finger_qpos_range[1][f] - m.finger_qpos_range[0][f]);
+      v = ap / HRG_NFINGER;
+    } else if (lane >= 47 && lane < 50) v = bx.obs_pos[lane - 47];
+    else if (lane >= 50 && lane < 53) v = bx.target[lane - 50];
+#endif
     out[lane] = (float)v;
   }
 }
+
+#if HRG_BOX
+// i-th object placement / target of an episode (UniformRandomSampler over the bins, pick_place_human_cartesian_env.py:613-635,
+// 843-875), counter-based; wave-uniform
+DI void placement_of(ModelPtr dm, int64_t gid, int episode, int idx, int target, double* p) {
+  const auto& m = dm->m;
+  const uint64_t st = target ? STREAM_TARGET : STREAM_OBJECT;
+  const double u0 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx)), u1 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx + 1));
+  if (target) { p[0] = m.tgt_bin[0] + (m.tgt_bin[1] - m.tgt_bin[0]) * u0; p[1] = m.tgt_bin[2] + (m.tgt_bin[3] - m.tgt_bin[2]) * u1; p[2] = m.tgt_z; }
+  else { p[0] = m.obj_bin[0] + (m.obj_bin[1] - m.obj_bin[0]) * u0; p[1] = m.obj_bin[2] + (m.obj_bin[3] - m.obj_bin[2]) * u1; p[2] = m.obj_z; }
+}
+#endif
 
 DI void eef_update(const DevModel* __restrict__ dm_) {
   const ModelPtr dm = uniform_model(dm_);
@@ -456,7 +575,21 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   eef_update(dm_);
   shield_reset(dm_, lane);
   wave_sync();
+#if HRG_BOX
+  { // PickPlaceHumanCart._reset_internal: first object placement and target, object at rest
+    hrg_box_state& bx = L.bx;
+    for (int k = lane; k < (int)(sizeof(hrg_box_state) / sizeof(double)); k += 64) ((double*)&bx)[k] = 0.0;
+    wave_sync();
+    double po[3], pt[3];
+    placement_of(dm, gid, episode, 0, 0, po);
+    placement_of(dm, gid, episode, 0, 1, pt);
+    if (lane < 3) { bx.pos[lane] = po[lane]; bx.obs_pos[lane] = po[lane]; bx.target[lane] = pt[lane]; }
+    if (lane == 0) bx.quat[0] = 1.0;
+    wave_sync();
+  }
+#else
   goal_sample(dm_, lane, gid, 0);
+#endif
   if (obs_out) write_obs(dm_, lane, s.cur_goal, obs_out);
   wave_sync();
 }
@@ -507,7 +640,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   { // gripper: RethinkGripper.format_action + ctrl-range mapping
     const double grip_a = L.act[NARM];
     const double sg = grip_a > 0 ? 1.0 : (grip_a < 0 ? -1.0 : 0.0);
-    const double ga = clampd(s.grip_action + m.gripper_speed * sg, -1.0, 1.0);
+    const double ga = clampd(s.grip_action - m.gripper_speed * sg, -1.0, 1.0);
     wave_sync();
     s.grip_action = ga;
     if (lane < HRG_NFINGER) {
@@ -564,14 +697,26 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   double goal[NARM];
   for (int j = 0; j < NARM; j++) goal[j] = s.cur_goal[j];
   write_obs(dm_, lane, goal, term_obs);
+#if HRG_BOX
+  // PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611);
+  // _check_object_in_target_zone (550-572), _sparse_reward (471-500), _dense_reward (502-526)
+  hrg_box_state& bx = L.bx;
+  double e2o = 0, o2t = 0;
+  for (int a = 0; a < 3; a++) { e2o += (bx.obs_pos[a] - s.eef_pos[a]) * (bx.obs_pos[a] - s.eef_pos[a]); o2t += (bx.target[a] - bx.obs_pos[a]) * (bx.target[a] - bx.obs_pos[a]); }
+  const int goal_reached = !crash && sqrt(o2t) <= m.goal_dist;
+  double r = goal_reached ? m.task_reward : (bx.gripped ? m.object_gripped_reward : -1.0);
+  const double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
+#else
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
   const double dist = sqrt(dist2);
   const int goal_reached = !crash && dist <= m.goal_dist;
+  double r = goal_reached ? m.task_reward : -1.0;
+  const double dense = -0.1 * dist;
+#endif
   if (goal_reached) s.n_goal_reached = s.n_goal_reached + 1;
   const int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0;
-  double r = goal_reached ? m.task_reward : -1.0;
-  if (m.reward_shaping) r += 1.0 + (-0.1 * dist);
+  if (m.reward_shaping) r += 1.0 + dense;
   if (illegal) r += m.collision_reward;
   r *= m.reward_scale;
   int d = 0;
@@ -604,27 +749,69 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   }
   if (lane == 0) { *reward = (float)r; *done = (uint8_t)d; }
   wave_sync();
+#if HRG_BOX
+  if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
+  wave_sync();
+  if (goal_reached && !d) { // _on_goal_reached (440-453): next target, object teleported to its next placement (velocity kept)
+    const int ti = (bx.tgt_index + 1) % m.n_targets, oi = (bx.obj_index + 1) % m.n_obj_placements;
+    double po[3], pt[3];
+    placement_of(dm, gid, s.episode, oi, 0, po);
+    placement_of(dm, gid, s.episode, ti, 1, pt);
+    wave_sync();
+    bx.tgt_index = ti; bx.obj_index = oi;
+    if (lane < 3) { bx.pos[lane] = po[lane]; bx.target[lane] = pt[lane]; }
+    if (lane < 4) bx.quat[lane] = lane == 0 ? 1.0 : 0.0;
+    wave_sync();
+  }
+#else
   if (goal_reached && !d) { // reach_human_env.py:399-407 (a finished episode resamples its goals at reset anyway)
     s.goal_index = (s.goal_index + 1) % m.n_goals;
     goal_sample(dm_, lane, gid, s.goal_index);
   }
+#endif
   STAMP(8);
   if (d) env_reset(dm_, lane, gid, obs);
+#if !HRG_BOX
   else write_obs(dm_, lane, goal, obs);
+#endif
   STAMP(9);
   STAMP_FINAL(lane);
 }
 
 // ================================================================================================ kernels
-__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
+#if HRG_BOX
+#define hrg_step_kernel hrg_step_kernel_box
+#define hrg_reset_kernel hrg_reset_kernel_box
+#define HRG_KERNEL_WAVES 2   // the variant with the cube needs more registers and LDS; it is not the tuned path
+// the cube's state block: streamed like the env block
+DI void box_load(const hrg_box_state* __restrict__ boxes, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_box_state) / sizeof(double));
+  const double* src = (const double*)(boxes + e);
+  double* dst = (double*)&g_L.bx;
+  if (lane < NB) dst[lane] = src[lane];
+}
+DI void box_store(hrg_box_state* __restrict__ boxes, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_box_state) / sizeof(double));
+  double* out = (double*)(boxes + e);
+  const double* src = (const double*)&g_L.bx;
+  if (lane < NB) out[lane] = src[lane];
+}
+#else
+#define HRG_KERNEL_WAVES HRG_MIN_WAVES
+#endif
+__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
-                                                     int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs) {
+                                                     int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs,
+                                                     hrg_box_state* __restrict__ boxes) {
   Lds& L = g_L;
   const int e = blockIdx.x, lane = threadIdx.x;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
   for (int k = lane; k < NW; k += 64) dst[k] = src[k];
+#if HRG_BOX
+  box_load(boxes, e, lane);
+#endif
   wave_sync();
   float* tobs = term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : scratch_obs + (size_t)e * HRG_OBS_DIM;
   env_step(dm, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
@@ -632,10 +819,13 @@ __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_step_kernel(const DevMo
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
+#if HRG_BOX
+  box_store(boxes, e, lane);
+#endif
 }
 
-__global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ obs, int64_t env_id0) {
+__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ obs, int64_t env_id0, hrg_box_state* __restrict__ boxes) {
   Lds& L = g_L;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[e]) return;
@@ -648,7 +838,28 @@ __global__ __launch_bounds__(64, HRG_MIN_WAVES) void hrg_reset_kernel(const DevM
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
+#if HRG_BOX
+  box_store(boxes, e, lane);
+#endif
 }
+
+// launch shims of the cube variant: defined by hrgym_box.hip (this file compiled with HRG_BOX=1), called by the host side below
+extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                           float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                           float* scratch_obs, hrg_box_state* boxes);
+extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                            int64_t env_id0, hrg_box_state* boxes);
+#if HRG_BOX
+extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
+                                    int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes) {
+  hipLaunchKernelGGL(hrg_step_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, boxes);
+}
+extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_box_state* boxes) {
+  hipLaunchKernelGGL(hrg_reset_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, mask, obs, env_id0, boxes);
+}
+#endif
+
+#if !HRG_BOX
 
 // ================================================================================================ host side
 static thread_local std::string g_err;
@@ -670,6 +881,8 @@ struct hrg_batch {
   double* d_hcaps = nullptr;
   int32_t* d_nh = nullptr;
   float* d_scratch_obs = nullptr;
+  hrg_box_state* d_boxes = nullptr;   // the manipulation object of each env (PickPlaceHumanCart)
+  int32_t task = HRG_TASK_REACH;
   bool timing = false;
   bool taps = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
@@ -688,6 +901,7 @@ extern "C" {
 const char* hrg_last_error(void) { return g_err.c_str(); }
 const char* hrg_version(void) { return "hrgym-hip 0.1.0 (gfx950)"; }
 size_t hrg_state_bytes(void) { return sizeof(hrg_env_state); }
+size_t hrg_box_bytes(void) { return sizeof(hrg_box_state); }
 
 int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
   if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
@@ -703,9 +917,12 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
+  if (desc->task != HRG_TASK_REACH && desc->task != HRG_TASK_PICK_PLACE) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task == HRG_TASK_PICK_PLACE && !(desc->box_half > 0 && desc->box_mass > 0 && desc->box_inertia > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
+    return fail(HRG_ERR_INVALID, "PickPlaceHumanCart needs box_half, box_mass, box_inertia, n_targets, n_obj_placements > 0");
   HIPCHK(hipSetDevice(device));
   hrg_batch* b = new hrg_batch();
-  b->device = device; b->n_envs = n_envs; b->env_id0 = env_id0;
+  b->device = device; b->n_envs = n_envs; b->env_id0 = env_id0; b->task = desc->task;
   // ---- device model ----
   DevModel* hm = new DevModel();
   memset(hm, 0, sizeof *hm);
@@ -779,6 +996,8 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   HIPCHK(hipMemset(b->d_rcaps, 0, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
   HIPCHK(hipMemset(b->d_hcaps, 0, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
   HIPCHK(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
+  HIPCHK(hipMalloc(&b->d_boxes, sizeof(hrg_box_state) * (size_t)n_envs));
+  HIPCHK(hipMemset(b->d_boxes, 0, sizeof(hrg_box_state) * (size_t)n_envs));
   *out = b;
   return HRG_OK;
 }
@@ -789,13 +1008,14 @@ void hrg_batch_destroy(hrg_batch* b) {
   hipDeviceSynchronize();
   for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs);
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes);
   delete b;
 }
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
-  hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0);
+  if (b->task == HRG_TASK_PICK_PLACE) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   HIPCHK(hipGetLastError());
   return HRG_OK;
 }
@@ -809,8 +1029,12 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  hipLaunchKernelGGL(hrg_step_kernel, dim3(b->n_envs), dim3(64), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                     b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs);
+  if (b->task == HRG_TASK_PICK_PLACE)
+    hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+  else
+    hipLaunchKernelGGL(hrg_step_kernel, dim3(b->n_envs), dim3(64), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(ev.second, st)); b->events.push_back(ev); }
   return HRG_OK;
@@ -851,6 +1075,20 @@ int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t 
   return HRG_OK;
 }
 
+int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_box_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(buf_host, b->d_boxes + env, bytes, hipMemcpyDeviceToHost));
+  return HRG_OK;
+}
+
+int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_box_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_boxes + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
 int hrg_batch_enable_taps(hrg_batch* b, int32_t on) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
   b->taps = on != 0;
@@ -886,3 +1124,4 @@ int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
 }
 
 } // extern "C"
+#endif // !HRG_BOX

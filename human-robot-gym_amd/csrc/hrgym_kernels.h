@@ -559,11 +559,71 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
     const uint64_t mask = __ballot(hit);
     if (hit) {
       const int idx = base + __popcll(mask & lt);
-      if (idx < HRG_NCON_DYN) L.con[idx] = c;  // full geometry only for the contacts that enter the solve
+      if (idx < NCON_DYN) L.con[idx] = c;  // full geometry only for the contacts that enter the solve
       if (idx < HRG_NCON_MAX) { L.st.con_pairs[idx][0] = c.g1; L.st.con_pairs[idx][1] = c.g2; }
     }
     base += __popcll(mask);
   }
+#if HRG_BOX
+  { // the cube: lanes 0..9 robot capsule - cube, 16..23 table - cube corners, 24..31 floor - cube corners
+    hrg_box_state& bx = L.bx;
+    if (lane == 0) { double Rm[9]; quat2mat(Rm, bx.quat); for (int a = 0; a < 9; a++) L.bR[a] = Rm[a]; }
+    wave_sync();
+    bool hit = false;
+    Contact c;
+    c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
+    const double hb = m.box_half;
+    if (lane < HRG_NRCAP) {
+      const int i = lane;
+      if (m.rcap_body[i] >= 0) {
+        double cs[3], cb[3];
+        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, cs, cb), dd = sqrt(e2);
+        double dist = dd - m.rcap_r[i];
+        if (dist < 0) {
+          hit = true;
+          if (dd > 1e-9) { v3sub(c.n, cb, cs); v3scl(c.n, c.n, 1.0 / dd); }
+          else { // capsule axis inside the cube: push out through the nearest face
+            double loc[3], rel[3], best = 1e300;
+            int ax = 0;
+            v3sub(rel, cs, bx.pos);
+            for (int a = 0; a < 3; a++) { loc[a] = L.bR[a] * rel[0] + L.bR[3 + a] * rel[1] + L.bR[6 + a] * rel[2]; if (hb - fabs(loc[a]) < best) { best = hb - fabs(loc[a]); ax = a; } }
+            const double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+            for (int a = 0; a < 3; a++) c.n[a] = sg * L.bR[3 * a + ax];
+            dist = -best - m.rcap_r[i];
+          }
+          v3madd(c.pos, cs, c.n, m.rcap_r[i] + 0.5 * dist);
+          c.g1 = i; c.g2 = GEOM_BOX; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX; c.dist = dist;
+        }
+      }
+    } else if (lane >= 16 && lane < 32) {
+      const int pl = (lane - 16) >> 3, cn = lane & 7;
+      const double loc[3] = {(cn & 1) ? hb : -hb, (cn & 2) ? hb : -hb, (cn & 4) ? hb : -hb};
+      double p[3];
+      m3mulv(p, L.bR, loc);
+      v3add(p, p, bx.pos);
+      const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
+      bool ok = true;
+      if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+      if (ok && dist < 0) {
+        hit = true;
+        v3set(c.n, 0, 0, 1);
+        v3set(c.pos, p[0], p[1], z0 + 0.5 * dist);
+        c.g1 = pl ? GEOM_FLOOR : GEOM_TABLE; c.g2 = GEOM_BOX; c.b1 = -1; c.b2 = BODY_BOX; c.dist = dist;
+      }
+    }
+    const uint64_t mask = __ballot(hit);
+    if (hit) {
+      const int idx = base + __popcll(mask & lt);
+      if (idx < NCON_DYN) L.con[idx] = c;
+      if (idx < HRG_NCON_MAX) { L.st.con_pairs[idx][0] = c.g1; L.st.con_pairs[idx][1] = c.g2; }
+    }
+    // _check_grasp: both fingers touch the cube (contacts beyond HRG_NCON_MAX are not reported and do not count)
+    const int slot = base + __popcll(mask & lt);
+    const bool f0 = __any(hit && lane == HRG_NRCAP - 2 && slot < HRG_NCON_MAX), f1 = __any(hit && lane == HRG_NRCAP - 1 && slot < HRG_NCON_MAX);
+    bx.gripped = f0 && f1;
+    base += __popcll(mask);
+  }
+#endif
   const int ncon = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
   if (lane < HRG_NCON_MAX && lane >= ncon) { L.st.con_pairs[lane][0] = -1; L.st.con_pairs[lane][1] = -1; }
   L.st.ncon = ncon;
@@ -571,7 +631,8 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
   wave_sync();
 }
 
-DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : HRG_GEOM_STATIC); }
+// the manipulation object is whitelisted -> COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717)
+DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g == GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
@@ -605,7 +666,8 @@ HRG_PHASE void classify(const DevModel* __restrict__ dm_, int ncon, int* has_col
       robot_point_vel(m.rcap_body[rg], L.rcen[rg], v);
       if (v3norm(v) <= m.safe_vel) { *collision_type |= HRG_COL_HUMAN; s.n_collisions_human = s.n_collisions_human + 1; }
       else { *collision_type |= HRG_COL_HUMAN_CRIT; s.n_collisions_critical = s.n_collisions_critical + 1; }
-    } else { *collision_type |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + 1; }
+    } else if (ot == HRG_GEOM_ALLOWED) { *collision_type |= HRG_COL_ALLOWED; }
+    else { *collision_type |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + 1; }
   }
   s.debounce_timer = deb;
   s.n_prev = ncur;

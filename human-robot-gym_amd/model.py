@@ -56,6 +56,23 @@ DEFAULT_ENV_KWARGS = dict(
     seed=0,
 )
 
+# PickPlaceHumanCart constructor defaults overlaid with config/environment/pick_place_human_cart.yaml (+ default/human_env.yaml)
+PICK_PLACE_ENV_KWARGS = dict(
+    DEFAULT_ENV_KWARGS,
+    horizon=1000,
+    done_at_success=False,
+    safe_vel=0.001,
+    self_collision_safety=0.01,
+    table_full_size=[1.5, 2.0, 0.05],
+    object_full_size=[0.04, 0.04, 0.04],
+    n_object_placements_sampled_per_100_steps=3,
+    n_targets_sampled_per_100_steps=3,
+    object_gripped_reward=-0.25,
+)
+ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS}
+# RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
+FINGER_QPOS_RANGE = [[-0.0118366, 0.011499], [0.0118366, -0.011499]]
+
 # Synthetic shield parameters (stand-ins for sara-shield's trajectory_parameters_schunk.yaml,
 # robot_parameters_schunk.yaml, mujoco_mocap.yaml, which are absent from the reference checkout).
 SHIELD_DEFAULTS = dict(
@@ -99,7 +116,9 @@ GRIPPER = dict(
     speed=0.01,
     grip_site=[0.0, 0.0, 0.109],
     base_capsule=([0.0, 0.0, 0.0], [0.0, 0.0, 0.06], 0.045),
-    finger_capsule=([0.0, 0.0, 0.0], [0.0, 0.0075, 0.075], 0.012),
+    # pad-side bar of a finger: offset outwards from the finger origin so that the open gripper (qpos_range[1]) spans 6.5 cm
+    # and the closed one 1.9 cm between the inner surfaces, parallel to the closing axis normal
+    finger_capsule=([0.0, 0.019, 0.03], [0.0, 0.019, 0.09], 0.008),
     shield_capsule=([0.0, 0.0, 0.0], [0.0, 0.0, 0.11], 0.07),
 )
 
@@ -152,14 +171,17 @@ def load_assets(name="reach_human_schunk.json"):
         return json.load(f)
 
 
-def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True):
-    """Return a filled `ModelDesc` for ReachHuman/Schunk.
+def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True,
+                     env_id="ReachHuman"):
+    """Return a filled `ModelDesc` for `env_id` ("ReachHuman" or "PickPlaceHumanCart") on the Schunk arm.
 
     `env_kwargs` takes the same keys as the reference's environment config
     (training/config/environment/reach_human.yaml, default/human_env.yaml).
     `collision_prevention` takes the keys of config/wrappers/collision_prevention/*.yaml (replace_type, n_resamples);
     None = wrapper not in the stack.  `goal_check=False` takes the non-pinocchio branch of `_sample_valid_pos`."""
-    kw = dict(DEFAULT_ENV_KWARGS)
+    if env_id not in ENV_DEFAULTS:
+        raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)}")
+    kw = dict(ENV_DEFAULTS[env_id])
     kw.update(env_kwargs or {})
     sp = dict(SHIELD_DEFAULTS)
     sp.update(shield_params or {})
@@ -240,7 +262,7 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     caps.append((NARM - 1, dict(p1=(p_hand + R_hand @ np.asarray(bc[0])).tolist(), p2=(p_hand + R_hand @ np.asarray(bc[1])).tolist(), r=bc[2])))
     fc = GRIPPER["finger_capsule"]
     caps.append((NARM, dict(p1=fc[0], p2=fc[1], r=fc[2])))
-    caps.append((NARM + 1, dict(p1=fc[0], p2=[fc[1][0], -fc[1][1], fc[1][2]], r=fc[2])))
+    caps.append((NARM + 1, dict(p1=[fc[0][0], -fc[0][1], fc[0][2]], p2=[fc[1][0], -fc[1][1], fc[1][2]], r=fc[2])))
     assert len(caps) == CONST["HRG_NRCAP"]
     for c, (b, cap) in enumerate(caps):
         d.rcap_body[c] = b
@@ -419,8 +441,32 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         raise ValueError("collision_prevention: replace_type in {0,1,2}, n_resamples <= 64")
     d.goal_check = int(bool(goal_check))
     d.self_collision_safety = float(kw["self_collision_safety"])
-    d.obstacle_margin = 0.01
+    d.obstacle_margin = 0.0 if env_id == "PickPlaceHumanCart" else 0.01   # safety_margin: pick_place_human_cartesian_env.py:696-700 / reach_human_env.py:589-593
     d.base_cyl_r, d.base_cyl_z = 0.2, 0.91
+    # ---- manipulation object / task (pick_place_human_cartesian_env.py:257-404, 613-708, 843-875)
+    for f in range(CONST["HRG_NFINGER"]):
+        d.finger_qpos_range[0][f], d.finger_qpos_range[1][f] = FINGER_QPOS_RANGE[0][f], FINGER_QPOS_RANGE[1][f]
+    d.task = CONST["HRG_TASK_REACH"]
+    if env_id == "PickPlaceHumanCart":
+        d.task = CONST["HRG_TASK_PICK_PLACE"]
+        d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616
+        size = [float(x) for x in kw["object_full_size"]]
+        if not (size[0] == size[1] == size[2]):
+            raise NotImplementedError("object_full_size: the stepper models a cube")
+        d.box_half = 0.5 * size[0]
+        d.box_mass = 1000.0 * size[0] ** 3                       # BoxObject default density [UPSTREAM robosuite]
+        d.box_inertia = d.box_mass * size[0] ** 2 / 6.0
+        tx, ty = kw["table_full_size"][0], kw["table_full_size"][1]
+        d.table_half[:] = [0.5 * tx, 0.5 * ty]
+        bx, by = 0.5 * tx - 0.05, 0.5 * ty - 0.05
+        d.obj_bin[:] = [bx * 0.35, bx * 0.6, by * 0.25, by * 0.45]
+        d.tgt_bin[:] = [bx * 0.35, bx * 0.6, by * -0.45, by * -0.25]
+        # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]
+        d.obj_z = 0.8 + d.box_half
+        d.tgt_z = 0.8 + 0.5 * size[2] + d.box_half
+        d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)
+        d.n_targets = max(int(kw["horizon"] * kw["n_targets_sampled_per_100_steps"] / 100), 1)
+        d.object_gripped_reward = float(kw["object_gripped_reward"])
     d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
     return d
 

@@ -20,7 +20,7 @@ import numpy as np
 
 from ._cstruct import CONST
 from .animation import synthetic_clips
-from .model import build_model_desc, DEFAULT_ENV_KWARGS
+from .model import build_model_desc, DEFAULT_ENV_KWARGS, ENV_DEFAULTS
 
 try:  # pragma: no cover - not installed in the build image
     from stable_baselines3.common.vec_env import VecEnv as _VecEnvBase
@@ -62,6 +62,10 @@ INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
 ]
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
 OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human_reach_ppo_parallel.yaml:14-16
+# training/config/run/obs_keys of the pick-place experiments (e.g. PP-SAC): the observables the policy sees
+PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "gripper_aperture", "dist_eef_to_human_head",
+                       "dist_eef_to_human_lh", "dist_eef_to_human_rh"]
+DEFAULT_OBS_KEYS = {"ReachHuman": OBS_KEYS, "PickPlaceHumanCart": PICK_PLACE_OBS_KEYS}
 # columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
 OBS_COLUMNS = {
     "object-state": range(0, 12), "goal_difference": range(12, 18), "robot0_joint_pos": range(18, 24),
@@ -69,6 +73,9 @@ OBS_COLUMNS = {
     "robot0_proprio-state": range(18, 33), "goal-state": list(range(33, 39)) + list(range(12, 18)),
     "vec_eef_to_human_lh": range(0, 3), "dist_eef_to_human_lh": range(3, 4), "vec_eef_to_human_rh": range(4, 7),
     "dist_eef_to_human_rh": range(7, 8), "vec_eef_to_human_head": range(8, 11), "dist_eef_to_human_head": range(11, 12),
+    # PickPlaceHumanCart (pick_place_human_cartesian_env.py:726-841); zero columns for ReachHuman
+    "object_gripped": range(39, 40), "vec_eef_to_object": range(40, 43), "vec_eef_to_target": range(43, 46),
+    "gripper_aperture": range(46, 47), "object_pos": range(47, 50), "target_pos": range(50, 53),
 }
 
 
@@ -125,9 +132,10 @@ class HipVecEnv(_VecEnvBase):
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True):
-        if env_id != "ReachHuman":
-            raise NotImplementedError(f"env_id {env_id!r}: only ReachHuman is built in this round (DESIGN.md §6)")
-        keys = list(obs_keys) if obs_keys is not None else OBS_KEYS
+        if env_id not in ENV_DEFAULTS:
+            raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
+        self.env_id = env_id
+        keys = list(obs_keys) if obs_keys is not None else DEFAULT_OBS_KEYS[env_id]
         unknown = [k for k in keys if k not in OBS_COLUMNS]
         if unknown:
             raise NotImplementedError(f"obs_keys {unknown!r}: available {sorted(OBS_COLUMNS)}")
@@ -140,7 +148,7 @@ class HipVecEnv(_VecEnvBase):
         self._clips = clips if clips is not None else synthetic_clips()
         # collision_prevention: dict(replace_type=0|1|2, n_resamples=20) = config/wrappers/collision_prevention/*.yaml
         self._cp, self._goal_check = collision_prevention, goal_check
-        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check)
+        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id)
         self._device, self._env_id0 = device, env_id0
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
         obs_space = _Box(-np.inf, np.inf, shape=(len(self._cols),), dtype=np.float32)
@@ -199,7 +207,8 @@ class HipVecEnv(_VecEnvBase):
         if seed is None:
             return [None] * self.num_envs
         self.env_kwargs["seed"] = int(seed)
-        self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check)
+        self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check,
+                                      env_id=self.env_id)
         if isinstance(self._backend, _TorchBackend):
             self._backend.close()
             self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)
@@ -241,8 +250,9 @@ class HipGymEnv:
 
     Stepping a finished episode raises ValueError like HumanEnv.step (human_env.py:487-488)."""
 
-    def __init__(self, env_kwargs=None, seed=None, clips=None, device=0, backend=None, obs_keys=None, collision_prevention=None):
-        self._vec = HipVecEnv(1, env_kwargs=env_kwargs, seed=seed, clips=clips, device=device, backend=backend, obs_keys=obs_keys,
+    def __init__(self, env_kwargs=None, seed=None, clips=None, device=0, backend=None, obs_keys=None, collision_prevention=None,
+                 env_id="ReachHuman"):
+        self._vec = HipVecEnv(1, env_id=env_id, env_kwargs=env_kwargs, seed=seed, clips=clips, device=device, backend=backend, obs_keys=obs_keys,
                               collision_prevention=collision_prevention)
         self.observation_space = self._vec.observation_space
         self.action_space = self._vec.action_space

@@ -57,13 +57,19 @@ extern "C" {
 #define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
 #define HRG_NHCAP_MAX 64  /* human reach capsules over all three models (fits one wavefront) */
 #define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
-#define HRG_OBS_DIM 39    /* superset of the flat observation; the host selects columns by obs_keys:
+#define HRG_OBS_DIM 53    /* superset of the flat observation; the host selects columns by obs_keys:
                           *  [0:12] object-state  [12:18] goal_difference  [18:24] robot0_joint_pos  [24:30] robot0_joint_vel
-                          *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666) */
+                          *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666)
+                          *  PickPlaceHumanCart (pick_place_human_cartesian_env.py:726-841; zero for ReachHuman):
+                          *  [39] object_gripped  [40:43] vec_eef_to_object  [43:46] vec_eef_to_target  [46] gripper_aperture
+                          *  [47:50] object_pos  [50:53] target_pos */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
 #define HRG_INFO_DIM 13
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */
 #define HRG_NCON_DYN 6    /* contacts that enter the constraint solve (4 pyramid rows each) */
+#define HRG_NCON_DYN_BOX 8 /* ... for tasks with the manipulation object (rows 24 + 32 still fit one wavefront) */
+#define HRG_NBOXV 6       /* free-joint DoF of the manipulation object */
+#define HRG_NVT (HRG_NV + HRG_NBOXV)
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
 
@@ -91,6 +97,9 @@ enum { HRG_COL_NULL = 0, HRG_COL_ALLOWED = 1, HRG_COL_HUMAN = 2, HRG_COL_ROBOT =
 enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 
 /* geom classes used by the contact classifier (human_env.py:948-964) */
+/* tasks: ReachHuman (reach_human_env.py), PickPlaceHumanCart (pick_place_human_cartesian_env.py) */
+enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1 };
+
 enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
 
 typedef enum {
@@ -209,6 +218,15 @@ typedef struct hrg_model_desc {
   double obstacle_margin;       /* safety_margin of the table / base obstacles (reach_human_env.py:589-593) */
   double base_cyl_r, base_cyl_z; /* mount pedestal cylinder (human_env.py:1333-1339) */
   uint32_t chk_selfmask[HRG_NRCAP]; /* self-collision candidates of the pre-check model: capsules 0..6 + gripper cylinder (7) */
+  /* ---- manipulation object + task of PickPlaceHumanCart (pick_place_human_cartesian_env.py:257-404, 637-708) ---- */
+  int32_t task;                 /* HRG_TASK_* */
+  int32_t n_obj_placements, n_targets; /* max(int(horizon * n_*_sampled_per_100_steps / 100), 1): 338-349 */
+  double box_half;              /* half edge of the cube (object_full_size / 2) */
+  double box_mass, box_inertia; /* BoxObject default density 1000; cube inertia m (2h)^2 / 6 */
+  double obj_bin[4], tgt_bin[4]; /* xmin xmax ymin ymax of the sampling bins (843-875) */
+  double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
+  double object_gripped_reward;
+  double finger_qpos_range[2][HRG_NFINGER]; /* RethinkValidGripper.qpos_range, rethink_valid_gripper.py:29-42 */
   uint64_t seed;
 } hrg_model_desc;
 
@@ -267,6 +285,11 @@ int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int
 int hrg_batch_enable_taps(hrg_batch* b, int32_t on);
 int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
+/* the manipulation object's part of the environment state (hrg_box_state, include/hrgym_state.h):
+ * PickPlaceHumanCart.get/set_environment_state, pick_place_human_cartesian_env.py:946-975; zeros for ReachHuman */
+size_t hrg_box_bytes(void);
+int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
+int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 
 /* Kernel timing hook for bench.py: records HIP events on the launch stream around every step kernel
  * since the last call; returns average kernel milliseconds and the number of launches measured. */

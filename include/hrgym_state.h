@@ -76,6 +76,19 @@ typedef struct hrg_env_state {
   int32_t con_pairs[HRG_NCON_MAX][2];
 } hrg_env_state;
 
+/* The manipulation object of the tasks that have one (PickPlaceHumanCart).  Kept out of hrg_env_state so that ReachHuman
+ * neither streams nor holds it; get/set_state exchange hrg_env_state followed by hrg_box_state. */
+typedef struct hrg_box_state {
+  double pos[3], quat[4];       /* free joint qpos (w,x,y,z) */
+  double vel[6];                /* linear, angular velocity (world frame) */
+  double acc_warmstart[6];
+  double obs_pos[3];            /* body_xpos of the last forward pass (what the observables read) */
+  double target[3];
+  int32_t obj_index, tgt_index; /* _object_placements_list_index, _target_positions_index */
+  int32_t gripped;              /* _check_grasp at the last substep */
+  int32_t pad_;
+} hrg_box_state;
+
 #ifdef __cplusplus
 }
 #endif

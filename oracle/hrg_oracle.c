@@ -25,7 +25,9 @@
 
 #define NV HRG_NV
 #define NARM HRG_NARM
+#define NVT HRG_NVT    /* robot tree + free joint of the manipulation object */
 #define NEFC_MAX 64
+#define BODY_BOX 100   /* body code of the manipulation object in contact_t.b1/b2 */
 #define PI 3.14159265358979323846
 
 #include <stdio.h>
@@ -98,7 +100,7 @@ static double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t st
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6 };
 static double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * PI * u2);
@@ -112,6 +114,7 @@ typedef struct hrgo_batch {
   int32_t n_envs;
   int64_t env_id0;
   hrg_env_state* st;
+  hrg_box_state* box; /* manipulation object per env (unused by ReachHuman) */
   /* parity taps of the last shield cycle */
   double (*rcaps)[HRG_NSHIELD_RCAP][7];
   double (*hcaps)[HRG_NHCAP_MAX][7];
@@ -750,7 +753,54 @@ typedef struct {
   double dist, n[3], pos[3];
 } contact_t;
 
-static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, contact_t* con) {
+#define GEOM_BOX (GEOM_FLOOR + 1)
+
+/* ---- manipulation object: a cube with a free joint (BoxObject, pick_place_human_cartesian_env.py:660-678) ---- */
+/* Closest points of a segment p1-p2 and a cube (centre c, rotation R row-major, half edge hb): squared distance of
+ * f(t) = |P(t) - clamp(P(t))|^2 in the cube frame, a convex piecewise quadratic in t, minimised on [0,1] by a
+ * safeguarded Newton iteration (each step is exact inside one piece).  Stand-in for mjc_CapsuleBox. */
+static double seg_box(const double* p1, const double* p2, const double* c, const double* R, double hb, double* tmin, double* on_seg, double* on_box) {
+  double a[3], d[3], t0[3];
+  v3sub(t0, p1, c);
+  for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2]; /* R' (p1 - c) */
+  v3sub(t0, p2, p1);
+  for (int k = 0; k < 3; k++) d[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  double g0 = 0, g1 = 0, t;
+  for (int k = 0; k < 3; k++) {
+    double x0 = a[k], x1 = a[k] + d[k];
+    g0 += (x0 > hb ? x0 - hb : (x0 < -hb ? x0 + hb : 0.0)) * d[k];
+    g1 += (x1 > hb ? x1 - hb : (x1 < -hb ? x1 + hb : 0.0)) * d[k];
+  }
+  if (g0 >= 0) t = 0; /* convex: slope >= 0 at t = 0 */
+  else if (g1 <= 0) t = 1;
+  else {
+    double lo = 0, hi = 1;
+    t = -g0 / (g1 - g0);
+    for (int it = 0; it < 10; it++) {
+      double g = 0, H = 0;
+      for (int k = 0; k < 3; k++) {
+        double x = a[k] + t * d[k], e = x > hb ? x - hb : (x < -hb ? x + hb : 0.0);
+        g += e * d[k];
+        if (e != 0) H += d[k] * d[k];
+      }
+      if (fabs(g) <= 1e-13 * (g1 - g0)) break; /* the slope vanished up to rounding: t is the minimiser */
+      if (g < 0) lo = t; else hi = t;
+      double nt = H > 0 ? t - g / H : 0.5 * (lo + hi);
+      if (!(nt > lo && nt < hi)) nt = 0.5 * (lo + hi);
+      t = nt;
+    }
+  }
+  double x[3], y[3], e2 = 0;
+  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb, hb); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+  *tmin = t;
+  for (int k = 0; k < 3; k++) {
+    on_seg[k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
+    on_box[k] = c[k] + R[3 * k] * y[0] + R[3 * k + 1] * y[1] + R[3 * k + 2] * y[2];
+  }
+  return e2;
+}
+
+static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, const hrg_box_state* bx, contact_t* con) {
   double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3];
   double Rb[9];
   quat2mat(Rb, m->base_quat);
@@ -801,11 +851,46 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
         }
       }
     }
+  if (bx) { /* robot capsule - cube, table - cube corners, floor - cube corners */
+    double Rx[9];
+    quat2mat(Rx, bx->quat);
+    const double hb = m->box_half;
+    for (int i = 0; i < HRG_NRCAP; i++) {
+      if (m->rcap_body[i] < 0) continue;
+      double t, cs[3], cb[3], nn[3], pos[3];
+      double e2 = seg_box(rp1[i], rp2[i], bx->pos, Rx, hb, &t, cs, cb), dd = sqrt(e2), dist = dd - m->rcap_r[i];
+      if (!(dist < 0)) continue;
+      if (dd > 1e-9) { v3sub(nn, cb, cs); v3scl(nn, nn, 1.0 / dd); }
+      else { /* capsule axis inside the cube: push out through the nearest face */
+        double loc[3], best = 1e300; int ax = 0;
+        v3sub(pos, cs, bx->pos);
+        for (int a = 0; a < 3; a++) { loc[a] = Rx[a] * pos[0] + Rx[3 + a] * pos[1] + Rx[6 + a] * pos[2]; if (hb - fabs(loc[a]) < best) { best = hb - fabs(loc[a]); ax = a; } }
+        double sg = loc[ax] >= 0 ? -1.0 : 1.0; /* normal points from the capsule into the cube */
+        for (int a = 0; a < 3; a++) nn[a] = sg * Rx[3 * a + ax];
+        dist = -best - m->rcap_r[i];
+      }
+      v3madd(pos, cs, nn, m->rcap_r[i] + 0.5 * dist);
+      EMIT(i, GEOM_BOX, m->rcap_body[i], BODY_BOX, dist, nn, pos);
+    }
+    for (int pl = 0; pl < 2; pl++)
+      for (int cn = 0; cn < 8; cn++) {
+        double loc[3] = {(cn & 1) ? hb : -hb, (cn & 2) ? hb : -hb, (cn & 4) ? hb : -hb}, p[3];
+        m3mulv(p, Rx, loc);
+        v3add(p, p, bx->pos);
+        double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
+        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (dist < 0) {
+          double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
+          EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_BOX, -1, BODY_BOX, dist, nn, pos);
+        }
+      }
+  }
 #undef EMIT
   return n;
 }
 
-static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : HRG_GEOM_STATIC); }
+/* the manipulation object is whitelisted: COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717) */
+static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g == GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
 static int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; } /* utils/pairing.py:4-16 */
 
 /* HumanEnv._collision_detection + _on_*_detected, human_env.py:966-1123 */
@@ -849,7 +934,8 @@ enum { ROW_FRICTION = 0, ROW_UNILATERAL = 1 };
 typedef struct {
   int n;
   int type[NEFC_MAX];
-  double J[NEFC_MAX][NV], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
+  int nv; /* DoF of the system the rows act on: NV, or NVT with the manipulation object */
+  double J[NEFC_MAX][NVT], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
 } efc_t;
 
 static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* imp, double* K, double* Bd) {
@@ -871,12 +957,12 @@ static void efc_add(const hrg_model_desc* m, efc_t* E, const double* J, const do
    * the two bodies' translational body_invweight0 for contact rows), not the exact J M^-1 J' */
   if (E->n >= NEFC_MAX) return;
   double vel = 0, nz = 0;
-  for (int i = 0; i < NV; i++) { vel += J[i] * qd[i]; nz += fabs(J[i]); }
+  for (int i = 0; i < E->nv; i++) { vel += J[i] * qd[i]; nz += fabs(J[i]); }
   if (!(nz > 0) || !(diag > 0)) return; /* row does not act on the robot tree */
   double imp, K, Bd;
   impedance(m, pos - margin, &imp, &K, &Bd);
   int r = E->n++;
-  memcpy(E->J[r], J, sizeof(double) * NV);
+  memcpy(E->J[r], J, sizeof(double) * E->nv);
   E->type[r] = type;
   E->aref[r] = -Bd * vel - K * imp * (pos - margin);
   E->D[r] = 1.0 / ((1 - imp) / imp * diag);
@@ -904,49 +990,50 @@ static int row_zone(const efc_t* E, int r, double x) {
 }
 
 static void solve(const hrg_model_desc* m, const double* M, const double* a0, const efc_t* E, double* a) {
+  const int nv = E->nv; /* M is nv x nv, row-major */
   /* a: in = warm start, out = solution */
-  double Ma0[NV];
-  for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a0[j]; Ma0[i] = t; }
-  if (E->n == 0) { memcpy(a, a0, sizeof(double) * NV); return; }
+  double Ma0[NVT];
+  for (int i = 0; i < nv; i++) { double t = 0; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a0[j]; Ma0[i] = t; }
+  if (E->n == 0) { memcpy(a, a0, sizeof(double) * nv); return; }
   /* pick the better of warm start and unconstrained acceleration */
   double cost_ws = 0, cost_a0 = 0;
   for (int pass = 0; pass < 2; pass++) {
     const double* x = pass ? a0 : a;
     double c = 0;
-    for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * (x[j] - a0[j]); c += 0.5 * (x[i] - a0[i]) * t; }
+    for (int i = 0; i < nv; i++) { double t = 0; for (int j = 0; j < nv; j++) t += M[i * nv + j] * (x[j] - a0[j]); c += 0.5 * (x[i] - a0[i]) * t; }
     for (int r = 0; r < E->n; r++) {
       double y = -E->aref[r], cc, g, h;
-      for (int i = 0; i < NV; i++) y += E->J[r][i] * x[i];
+      for (int i = 0; i < nv; i++) y += E->J[r][i] * x[i];
       row_cost(E, r, y, &cc, &g, &h);
       c += cc;
     }
     if (pass) cost_a0 = c; else cost_ws = c;
   }
-  if (!(cost_ws < cost_a0)) memcpy(a, a0, sizeof(double) * NV);
+  if (!(cost_ws < cost_a0)) memcpy(a, a0, sizeof(double) * nv);
   for (int it = 0; it < m->solver_iters; it++) {
-    double x[NEFC_MAX], g[NV], H[NV * NV];
-    for (int i = 0; i < NV; i++) { double t = -Ma0[i]; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a[j]; g[i] = t; }
-    memcpy(H, M, sizeof H);
+    double x[NEFC_MAX], g[NVT], H[NVT * NVT];
+    for (int i = 0; i < nv; i++) { double t = -Ma0[i]; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a[j]; g[i] = t; }
+    memcpy(H, M, sizeof(double) * nv * nv);
     for (int r = 0; r < E->n; r++) {
       double y = -E->aref[r], cc, gg, hh;
-      for (int i = 0; i < NV; i++) y += E->J[r][i] * a[i];
+      for (int i = 0; i < nv; i++) y += E->J[r][i] * a[i];
       x[r] = y;
       row_cost(E, r, y, &cc, &gg, &hh);
-      for (int i = 0; i < NV; i++) g[i] += E->J[r][i] * gg;
-      if (hh != 0) for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) H[i * NV + j] += hh * E->J[r][i] * E->J[r][j];
+      for (int i = 0; i < nv; i++) g[i] += E->J[r][i] * gg;
+      if (hh != 0) for (int i = 0; i < nv; i++) for (int j = 0; j < nv; j++) H[i * nv + j] += hh * E->J[r][i] * E->J[r][j];
     }
     double gn = 0, sc = 0;
-    for (int i = 0; i < NV; i++) { gn += g[i] * g[i]; sc += Ma0[i] * Ma0[i]; }
+    for (int i = 0; i < nv; i++) { gn += g[i] * g[i]; sc += Ma0[i] * Ma0[i]; }
     if (sqrt(gn) <= m->solver_tol * (1.0 + sqrt(sc))) break;
-    double d[NV], Md[NV], p[NEFC_MAX];
-    for (int i = 0; i < NV; i++) d[i] = -g[i];
-    if (!chol(H, NV)) break;
-    chol_solve(H, NV, d);
-    for (int i = 0; i < NV; i++) { double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * d[j]; Md[i] = t; }
-    for (int r = 0; r < E->n; r++) { double t = 0; for (int i = 0; i < NV; i++) t += E->J[r][i] * d[i]; p[r] = t; }
+    double d[NVT], Md[NVT], p[NEFC_MAX];
+    for (int i = 0; i < nv; i++) d[i] = -g[i];
+    if (!chol(H, nv)) break;
+    chol_solve(H, nv, d);
+    for (int i = 0; i < nv; i++) { double t = 0; for (int j = 0; j < nv; j++) t += M[i * nv + j] * d[j]; Md[i] = t; }
+    for (int r = 0; r < E->n; r++) { double t = 0; for (int i = 0; i < nv; i++) t += E->J[r][i] * d[i]; p[r] = t; }
     /* exact line search on phi(al) = cost(a + al d): safeguarded Newton on phi' */
     double dMd = 0, gd0 = 0;
-    for (int i = 0; i < NV; i++) { dMd += d[i] * Md[i]; double t = -Ma0[i]; for (int j = 0; j < NV; j++) t += M[i * NV + j] * a[j]; gd0 += d[i] * t; }
+    for (int i = 0; i < nv; i++) { dMd += d[i] * Md[i]; double t = -Ma0[i]; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a[j]; gd0 += d[i] * t; }
     double al = 1.0, lo = 0, hi = -1, d1_0 = 0;
     for (int ls = 0; ls < 40; ls++) {
       double d1 = gd0 + al * dMd, d2 = dMd;
@@ -971,13 +1058,13 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
      * new point is zero up to rounding, so the next iteration would only confirm convergence */
     int exact = al == 1.0;
     for (int r = 0; r < E->n && exact; r++) if (row_zone(E, r, x[r]) != row_zone(E, r, x[r] + p[r])) exact = 0;
-    for (int i = 0; i < NV; i++) a[i] += al * d[i];
+    for (int i = 0; i < nv; i++) a[i] += al * d[i];
     if (exact) break;
   }
 }
 
 /* =============================================================================================== env */
-static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const double* goal, float* obs) {
+static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const hrg_box_state* bx, const double* goal, float* obs) {
   /* object-state: vec/dist eef -> {L hand, R hand, head} (human_env.py:1536-1590, reach_human_env.py:637-640),
    * then goal_difference (reach_human_env.py:649-651) */
   int sites[3] = {m->site_lhand, m->site_rhand, m->site_head};
@@ -991,6 +1078,31 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const d
   /* robot0_proprio-state = joint_pos, joint_vel, eef_pos (reach_human_env.py:619-636); goal modality: desired_goal (646-647) */
   for (int j = 0; j < NARM; j++) { obs[18 + j] = (float)s->qpos[j]; obs[24 + j] = (float)s->qvel[j]; obs[33 + j] = (float)goal[j]; }
   for (int a = 0; a < 3; a++) obs[30 + a] = (float)s->eef_pos[a];
+  for (int c = 39; c < HRG_OBS_DIM; c++) obs[c] = 0.0f;
+  if (bx) { /* PickPlaceHumanCart._setup_observables, pick_place_human_cartesian_env.py:726-841; gripper_aperture human_env.py:1508-1524 */
+    for (int j = 0; j < NARM; j++) { obs[12 + j] = 0.0f; obs[33 + j] = 0.0f; }
+    obs[39] = (float)bx->gripped;
+    double ap = 0;
+    for (int f = 0; f < HRG_NFINGER; f++) ap += (s->qpos[NARM + f] - m->finger_qpos_range[0][f]) / (m->finger_qpos_range[1][f] - m->finger_qpos_range[0][f]);
+    obs[46] = (float)(ap / HRG_NFINGER);
+    for (int a = 0; a < 3; a++) {
+      obs[40 + a] = (float)(bx->obs_pos[a] - s->eef_pos[a]);
+      obs[43 + a] = (float)(bx->target[a] - s->eef_pos[a]);
+      obs[47 + a] = (float)bx->obs_pos[a];
+      obs[50 + a] = (float)bx->target[a];
+    }
+  }
+}
+
+/* i-th object placement / target of an episode: UniformRandomSampler over the bins (pick_place_human_cartesian_env.py:
+ * 613-635, 680-708, 843-875), drawn counter-based instead of as lists filled at reset */
+static void placement_of(const hrgo_batch* B, int64_t gid, int episode, int idx, int target, double* p) {
+  const hrg_model_desc* m = &B->m;
+  const double* bin = target ? m->tgt_bin : m->obj_bin;
+  uint64_t st = target ? STREAM_TARGET : STREAM_OBJECT;
+  p[0] = bin[0] + (bin[1] - bin[0]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx));
+  p[1] = bin[2] + (bin[3] - bin[2]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx + 1));
+  p[2] = target ? m->tgt_z : m->obj_z;
 }
 
 /* HumanEnv._check_action_safety (human_env.py:931-946): does the arm at configuration q6 hit the static collision objects
@@ -1117,8 +1229,15 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   eef_of(m, &k, s->eef_pos);
   shield_reset(m, s, s->qpos); /* FailsafeController.reset, failsafe_controller.py:204-250 */
   for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
-  goal_of(B, gid, s, 0, s->cur_goal);
-  if (obs) compute_obs(m, s, s->cur_goal, obs);
+  hrg_box_state* bx = m->task == HRG_TASK_PICK_PLACE ? &B->box[e] : NULL;
+  if (bx) { /* PickPlaceHumanCart._reset_internal: first object placement and target, object at rest */
+    memset(bx, 0, sizeof *bx);
+    placement_of(B, gid, episode, 0, 0, bx->pos);
+    placement_of(B, gid, episode, 0, 1, bx->target);
+    bx->quat[0] = 1;
+    v3cpy(bx->obs_pos, bx->pos);
+  } else goal_of(B, gid, s, 0, s->cur_goal);
+  if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
 }
 
 static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
@@ -1132,6 +1251,8 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   robot_kin k;
   human_kin hk;
   double M[NV * NV], bias[NV];
+  hrg_box_state* bx = m->task == HRG_TASK_PICK_PLACE ? &B->box[e] : NULL;
+  const int nvt = bx ? NVT : NV, ncon_dyn = bx ? HRG_NCON_DYN_BOX : HRG_NCON_DYN;
   for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
     /* ---- sim.forward() #1 (human_env.py:504): positions, M, bias at the current state ---- */
     robot_fk(m, s->qpos, &k);
@@ -1157,9 +1278,9 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       for (int j = 0; j < NARM; j++) t += s->mass_matrix[i * NARM + j] * (m->kp * (s->des_q[j] - s->qpos[j]) + m->kd * (s->des_v[j] - s->qvel[j]) + s->des_a[j]);
       ctrl[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
     }
-    { /* RethinkGripper.format_action + actuator ctrl range mapping */
+    { /* RethinkGripper.format_action + actuator ctrl range mapping; +1 closes, -1 opens (experts/pick_place_human_cart_expert.py:282-288), finger 0 opens towards positive qpos (rethink_valid_gripper.py:25-42) */
       double a = action[NARM], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
-      s->grip_action = clampd(s->grip_action + m->gripper_speed * sg, -1.0, 1.0);
+      s->grip_action = clampd(s->grip_action - m->gripper_speed * sg, -1.0, 1.0);
       for (int f = 0; f < HRG_NFINGER; f++) {
         double lo = m->finger_ctrlrange[f][0], hi = m->finger_ctrlrange[f][1];
         ctrl[NARM + f] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (f == 0 ? s->grip_action : -s->grip_action);
@@ -1173,7 +1294,12 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     human_fk(m, mp, mq, qh, &hk, s->human_site);
     /* ---- contacts + bookkeeping (human_env.py:522) ---- */
     contact_t con[HRG_NCON_MAX];
-    int ncon = collide(m, &k, &hk, con);
+    int ncon = collide(m, &k, &hk, bx, con);
+    if (bx) { /* _check_grasp [UPSTREAM robosuite]: both fingers touch the object (pick_place_human_cartesian_env.py:804-809) */
+      int f0 = 0, f1 = 0;
+      for (int c = 0; c < ncon; c++) if (con[c].g2 == GEOM_BOX) { f0 |= con[c].g1 == HRG_NRCAP - 2; f1 |= con[c].g1 == HRG_NRCAP - 1; }
+      bx->gripped = f0 && f1;
+    }
     double rc[HRG_NRCAP][3], Rb[9];
     quat2mat(Rb, m->base_quat);
     for (int c = 0; c < HRG_NRCAP; c++) {
@@ -1187,7 +1313,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     s->ncon = ncon;
     for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
     /* ---- sim.step() (human_env.py:523): smooth acceleration, constraints, Euler ---- */
-    double LM[NV * NV], a0[NV], frc[NV];
+    double LM[NV * NV], a0[NVT], frc[NV], qd[NVT], Mt[NVT * NVT];
     memcpy(LM, M, sizeof LM);
     if (!chol(LM, NV)) { crash = 1; break; }
     for (int i = 0; i < NV; i++) {
@@ -1195,18 +1321,31 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       if (i >= NARM) act = clampd(m->finger_kp * (ctrl[i] - s->qpos[i]), m->finger_forcerange[0], m->finger_forcerange[1]);
       frc[i] = act - m->jnt_damping[i] * s->qvel[i] - bias[i];
       a0[i] = frc[i];
+      qd[i] = s->qvel[i];
     }
     chol_solve(LM, NV, a0);
+    if (bx) { /* free cube: block-diagonal inertia (isotropic, so no gyroscopic term), gravity only */
+      memset(Mt, 0, sizeof Mt);
+      for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Mt[i * NVT + j] = M[i * NV + j];
+      for (int a = 0; a < 3; a++) {
+        Mt[(NV + a) * NVT + NV + a] = m->box_mass;
+        Mt[(NV + 3 + a) * NVT + NV + 3 + a] = m->box_inertia;
+        a0[NV + a] = m->gravity[a];
+        a0[NV + 3 + a] = 0;
+      }
+      for (int a = 0; a < HRG_NBOXV; a++) qd[NV + a] = bx->vel[a];
+    } else memcpy(Mt, M, sizeof M);
     efc_t E;
     E.n = 0;
+    E.nv = nvt;
     for (int i = 0; i < NV; i++) /* friction loss rows */
-      if (m->jnt_frictionloss[i] > 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, J, s->qvel, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i], m->dof_invweight0[i]); }
+      if (m->jnt_frictionloss[i] > 0) { double J[NVT] = {0}; J[i] = 1; efc_add(m, &E, J, qd, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i], m->dof_invweight0[i]); }
     for (int i = 0; i < NV; i++) { /* joint limit rows */
       double dlo = s->qpos[i] - m->jnt_range[i][0], dhi = m->jnt_range[i][1] - s->qpos[i];
-      if (dlo < 0) { double J[NV] = {0}; J[i] = 1; efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, dlo, 0, 0, m->dof_invweight0[i]); }
-      if (dhi < 0) { double J[NV] = {0}; J[i] = -1; efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, dhi, 0, 0, m->dof_invweight0[i]); }
+      if (dlo < 0) { double J[NVT] = {0}; J[i] = 1; efc_add(m, &E, J, qd, ROW_UNILATERAL, dlo, 0, 0, m->dof_invweight0[i]); }
+      if (dhi < 0) { double J[NVT] = {0}; J[i] = -1; efc_add(m, &E, J, qd, ROW_UNILATERAL, dhi, 0, 0, m->dof_invweight0[i]); }
     }
-    for (int c = 0; c < ncon && c < HRG_NCON_DYN; c++) { /* pyramidal frictional contact rows */
+    for (int c = 0; c < ncon && c < ncon_dyn; c++) { /* pyramidal frictional contact rows */
       const double* n = con[c].n;
       double t1[3], t2[3], e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
       v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
@@ -1214,30 +1353,38 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       v3cross(t2, n, t1);
       double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
       for (int d = 0; d < 4; d++) {
-        double dir[3], J[NV] = {0};
+        double dir[3], J[NVT] = {0};
         const double* tt = d < 2 ? t1 : t2;
         double sg = (d & 1) ? -1.0 : 1.0;
         for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m->friction_static * tt[a];
         /* separation velocity along n (from geom1 to geom2): v2 - v1 */
-        if (con[c].b1 >= 0) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
-        if (con[c].b2 >= 0) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
-        double diag = (con[c].b1 >= 0 ? m->body_invweight0[con[c].b1] : 0.0) + (con[c].b2 >= 0 ? m->body_invweight0[con[c].b2] : 0.0);
-        efc_add(m, &E, J, s->qvel, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
+        if (con[c].b1 >= 0 && con[c].b1 < NV) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
+        if (con[c].b2 >= 0 && con[c].b2 < NV) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
+        double diag = (con[c].b1 >= 0 && con[c].b1 < NV ? m->body_invweight0[con[c].b1] : 0.0) + (con[c].b2 >= 0 && con[c].b2 < NV ? m->body_invweight0[con[c].b2] : 0.0);
+        if (con[c].b2 == BODY_BOX) { /* the cube is always geom 2: J = dir . (v + w x r), body_invweight0 of a free body = 1/m */
+          double r[3], rxd[3];
+          v3sub(r, con[c].pos, bx->pos);
+          v3cross(rxd, r, dir);
+          for (int a = 0; a < 3; a++) { J[NV + a] = dir[a]; J[NV + 3 + a] = rxd[a]; }
+          diag += 1.0 / m->box_mass;
+        }
+        efc_add(m, &E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
       }
     }
-    double qacc[NV];
-    memcpy(qacc, s->qacc_warmstart, sizeof qacc);
-    solve(m, M, a0, &E, qacc);
+    double qacc[NVT];
+    memcpy(qacc, s->qacc_warmstart, sizeof(double) * NV);
+    if (bx) memcpy(qacc + NV, bx->acc_warmstart, sizeof(double) * HRG_NBOXV);
+    solve(m, Mt, a0, &E, qacc);
     if (g_debug && (ncon > 0 || g_debug > 1)) {
-      double mx = 0; for (int i = 0; i < NV; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
+      double mx = 0; for (int i = 0; i < nvt; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
       fprintf(stderr, "[oracle] env %d cyc %d ncon %d nefc %d max|qacc| %.3e", e, cyc, ncon, E.n, mx);
       for (int c = 0; c < ncon; c++) fprintf(stderr, " (%d,%d d=%.4f)", con[c].g1, con[c].g2, con[c].dist);
       fprintf(stderr, "\n");
     }
     /* mj_checkAcc -> MujocoException handler (human_env.py:527-546) */
-    for (int i = 0; i < NV; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
+    for (int i = 0; i < nvt; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
     if (crash) break;
-    memcpy(s->qacc_warmstart, qacc, sizeof qacc);
+    memcpy(s->qacc_warmstart, qacc, sizeof(double) * NV);
     /* mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc */
     double Mh[NV * NV], rhs[NV];
     memcpy(Mh, M, sizeof Mh);
@@ -1245,6 +1392,19 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     if (!chol(Mh, NV)) { crash = 1; break; }
     chol_solve(Mh, NV, rhs);
     for (int i = 0; i < NV; i++) { s->qvel[i] += h * rhs[i]; s->qpos[i] += h * s->qvel[i]; }
+    if (bx) { /* free joint: no damping; quaternion integrated with the world-frame angular velocity */
+      memcpy(bx->acc_warmstart, qacc + NV, sizeof(double) * HRG_NBOXV);
+      v3cpy(bx->obs_pos, bx->pos); /* body_xpos of the forward pass inside mj_step (pre-integration) */
+      for (int a = 0; a < HRG_NBOXV; a++) bx->vel[a] += h * qacc[NV + a];
+      for (int a = 0; a < 3; a++) bx->pos[a] += h * bx->vel[a];
+      double w[3] = {bx->vel[3], bx->vel[4], bx->vel[5]}, wn = v3norm(w), ang = h * wn;
+      if (wn > 1e-12) {
+        double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w[0] * sh, w[1] * sh, w[2] * sh}, qn[4];
+        quatmul(qn, dq, bx->quat);
+        double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (int a = 0; a < 4; a++) bx->quat[a] = qn[a] / nn;
+      }
+    }
     s->time += h;
     eef_of(m, &k, s->eef_pos); /* site_xpos of the forward pass inside mj_step (pre-integration) */
     s->low_level_time += 1; /* human_env.py:526 */
@@ -1252,15 +1412,26 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   /* ---- observation, success, info, reward, done (human_env.py:561-581) ---- */
   double goal[NARM];
   memcpy(goal, s->cur_goal, sizeof goal);
-  compute_obs(m, s, goal, term_obs);
-  double dist2 = 0;
-  for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
-  double dist = sqrt(dist2);
-  int goal_reached = !crash && dist <= m->goal_dist; /* reach_human_env.py:457-475 */
+  compute_obs(m, s, bx, goal, term_obs);
+  double dist2 = 0, dense;
+  int goal_reached;
+  double r;
+  if (bx) { /* PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611) */
+    double e2o = 0, o2t = 0;
+    for (int a = 0; a < 3; a++) { e2o += (bx->obs_pos[a] - s->eef_pos[a]) * (bx->obs_pos[a] - s->eef_pos[a]); o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]); }
+    goal_reached = !crash && sqrt(o2t) <= m->goal_dist; /* _check_object_in_target_zone, 550-572 */
+    r = goal_reached ? m->task_reward : (bx->gripped ? m->object_gripped_reward : -1.0); /* _sparse_reward, 471-500 */
+    dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1; /* _dense_reward, 502-526 */
+  } else {
+    for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
+    double dist = sqrt(dist2);
+    goal_reached = !crash && dist <= m->goal_dist; /* reach_human_env.py:457-475 */
+    r = goal_reached ? m->task_reward : -1.0; /* human_env.py:666-691 */
+    dense = -0.1 * dist; /* reach_human_env.py:437-455 */
+  }
   if (goal_reached) s->n_goal_reached++;
   int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0; /* human_env.py:860-878 */
-  double r = goal_reached ? m->task_reward : -1.0; /* human_env.py:666-691 */
-  if (m->reward_shaping) r += 1.0 + (-0.1 * dist); /* human_env.py:650-651, reach_human_env.py:437-455 */
+  if (m->reward_shaping) r += 1.0 + dense; /* human_env.py:650-651 */
   if (illegal) r += m->collision_reward;
   r *= m->reward_scale;
   int d = 0;
@@ -1283,7 +1454,13 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   info[HRG_INFO_SIM_CRASH] = crash;
   info[HRG_INFO_TRUNCATED] = 0;
   info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
-  if (goal_reached) { /* reach_human_env.py:399-407 */
+  if (goal_reached && bx) { /* _on_goal_reached, pick_place_human_cartesian_env.py:440-453: next target, object teleported to its next placement (velocity kept) */
+    bx->tgt_index = (bx->tgt_index + 1) % m->n_targets;
+    bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
+    placement_of(B, gid, s->episode, bx->tgt_index, 1, bx->target);
+    placement_of(B, gid, s->episode, bx->obj_index, 0, bx->pos);
+    bx->quat[0] = 1; bx->quat[1] = bx->quat[2] = bx->quat[3] = 0;
+  } else if (goal_reached) { /* reach_human_env.py:399-407 */
     s->goal_index = (s->goal_index + 1) % m->n_goals;
     goal_of(B, gid, s, s->goal_index, s->cur_goal);
   }
@@ -1305,6 +1482,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
   B->n_envs = n_envs;
   B->env_id0 = env_id0;
   B->st = (hrg_env_state*)calloc((size_t)n_envs, sizeof(hrg_env_state));
+  B->box = (hrg_box_state*)calloc((size_t)n_envs, sizeof(hrg_box_state));
   B->rcaps = calloc((size_t)n_envs, sizeof *B->rcaps);
   B->hcaps = calloc((size_t)n_envs, sizeof *B->hcaps);
   B->n_hcaps = calloc((size_t)n_envs, sizeof(int32_t));
@@ -1314,7 +1492,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
 }
 void hrgo_destroy(hrgo_batch* B) {
   if (!B) return;
-  free(B->frames); free(B->st); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
+  free(B->frames); free(B->st); free(B->box); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
 }
 int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
   for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
@@ -1346,7 +1524,18 @@ int hrgo_set_state(hrgo_batch* B, int e, const void* buf, size_t bytes) {
   memcpy(&B->st[e], buf, bytes);
   return 0;
 }
+int hrgo_get_box(hrgo_batch* B, int e, void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_box_state)) return -1;
+  memcpy(buf, &B->box[e], bytes);
+  return 0;
+}
+int hrgo_set_box(hrgo_batch* B, int e, const void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_box_state)) return -1;
+  memcpy(&B->box[e], buf, bytes);
+  return 0;
+}
 size_t hrgo_state_bytes(void) { return sizeof(hrg_env_state); }
+size_t hrgo_box_bytes(void) { return sizeof(hrg_box_state); }
 size_t hrgo_desc_bytes(void) { return sizeof(hrg_model_desc); }
 int hrgo_contacts(hrgo_batch* B, int32_t* pairs, int32_t* ncon) {
   for (int e = 0; e < B->n_envs; e++) {
@@ -1489,4 +1678,10 @@ void hrgo_test_human_dyn(const hrg_model_desc* m, const double* frames, int n_fr
     for (int i = 0; i < HRG_NHQ; i++) { qd[i] += m->timestep * qa[i]; if (fabs(qd[i]) > mv) mv = fabs(qd[i]); if (fabs(qa[i]) > ma) ma = fabs(qa[i]); }
     out_maxvel[t] = mv; out_maxacc[t] = ma;
   }
+}
+/* out: squared distance, closest point on the segment (3), closest point on the cube (3) */
+void hrgo_test_segbox(const double* p1, const double* p2, const double* c, const double* quat, double hb, double* out) {
+  double R[9], t;
+  quat2mat(R, quat);
+  out[0] = seg_box(p1, p2, c, R, hb, &t, out + 1, out + 4);
 }

@@ -82,6 +82,15 @@ class OracleBatch:
     def set_state(self, e, s):
         assert self.lib.hrgo_set_state(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
 
+    def get_box(self, e):
+        from human_robot_gym_amd._cstruct import BoxState
+        s = BoxState()
+        assert self.lib.hrgo_get_box(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+        return s
+
+    def set_box(self, e, s):
+        assert self.lib.hrgo_set_box(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+
     def contacts(self):
         pairs = np.zeros((self.n, self.C["HRG_NCON_MAX"], 2), np.int32)
         ncon = np.zeros(self.n, np.int32)

@@ -16,21 +16,44 @@ from tools_cases import CASES  # noqa: E402
 from make_golden import clips_for as _clips  # noqa: E402
 
 
+def _desc(name, clips):
+    kw = dict(CASES[name])
+    env_id = kw.pop("env_id", "ReachHuman")
+    return hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=env_id), env_id
+
+
+def _deliver(B, n, env_id, k):  # the scripted delivery of the pick-place case (tools/make_golden.py)
+    if env_id == "PickPlaceHumanCart" and k == 20:
+        for e in range(n):
+            bx = B.get_box(e)
+            bx.pos[:] = [bx.target[0] + 0.02, bx.target[1], 0.845]
+            B.set_box(e, bx)
+
+
+def _box(B, n):
+    bxs = [B.get_box(e) for e in range(n)]
+    return np.array([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs])
+
+
 @pytest.mark.parametrize("name", sorted(CASES))
 def test_oracle_reproduces_golden(name):
     from oracle.oracle import OracleBatch
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     clips = _clips(name)
-    B = OracleBatch(hrg.build_model_desc(CASES[name], n_clips=clips.n_clips), clips, g["obs0"].shape[0])
+    desc, env_id = _desc(name, clips)
+    n = g["obs0"].shape[0]
+    B = OracleBatch(desc, clips, n)
     np.testing.assert_array_equal(B.reset(), g["obs0"])
     for k in range(g["actions"].shape[0]):
+        _deliver(B, n, env_id, k)
         o, r, d, i = B.step(g["actions"][k])
+        np.testing.assert_allclose(_box(B, n), g["box"][k], rtol=1e-6, atol=1e-9)
         np.testing.assert_array_equal(i, g["info"][k], err_msg=f"step {k}")
         np.testing.assert_array_equal(d, g["done"][k])
         np.testing.assert_allclose(o, g["obs"][k], rtol=1e-6, atol=1e-7)
         np.testing.assert_allclose(r, g["reward"][k], rtol=1e-6, atol=1e-7)
-        p, n = B.contacts()
-        np.testing.assert_array_equal(n, g["ncon"][k])
+        p, nc = B.contacts()
+        np.testing.assert_array_equal(nc, g["ncon"][k])
         np.testing.assert_array_equal(p, g["pairs"][k].astype(np.int32))
 
 
@@ -42,10 +65,12 @@ def test_hip_reproduces_golden(name):
     g = np.load(os.path.join(GOLD, f"{name}.npz"))
     clips = _clips(name)
     n = g["obs0"].shape[0]
-    B = HipBatch(hrg.build_model_desc(CASES[name], n_clips=clips.n_clips), clips, n)
+    desc, env_id = _desc(name, clips)
+    B = HipBatch(desc, clips, n)
     np.testing.assert_allclose(B.reset().cpu().numpy(), g["obs0"], rtol=1e-5, atol=1e-6)
     live = np.ones(n, bool)  # an env that turns violent (|qvel| > 5 rad/s or crash) is chaotic from then on: dropped
     for k in range(g["actions"].shape[0]):
+        _deliver(B, n, env_id, k)
         o, r, d, i = B.step(torch.from_numpy(g["actions"][k]).cuda())
         torch.cuda.synchronize()
         live &= (np.abs(g["qvel"][k]).max(1) <= 5.0) & (g["info"][k][:, 11] == 0)
@@ -55,6 +80,7 @@ def test_hip_reproduces_golden(name):
         np.testing.assert_allclose(r.cpu().numpy()[live], g["reward"][k][live], rtol=1e-5, atol=1e-6)
         q = np.array([list(B.get_state(e).qpos) for e in range(n)])
         np.testing.assert_allclose(q[live], g["qpos"][k][live], rtol=1e-5, atol=1e-7)               # north_star: qpos within 1e-5 rel
+        np.testing.assert_allclose(_box(B, n)[live], g["box"][k][live], rtol=1e-5, atol=1e-7)
         p, nc = B.contacts()
         np.testing.assert_array_equal(nc[live], g["ncon"][k][live])                                   # contact-pair indices bit-exact
         np.testing.assert_array_equal(p[live], g["pairs"][k].astype(np.int32)[live])

@@ -1,0 +1,168 @@
+"""PickPlaceHumanCart on the CPU oracle: behaviour of the restated task (pick_place_human_cartesian_env.py) and of the cube's
+contact model.  PARITY UNPINNED: the reference holds no fixtures for this path; these tests pin behaviour
+the reference documents (reward terms, success rule, target / placement cycling, observables) and physical sanity."""
+import ctypes
+
+import numpy as np
+import pytest
+
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd._cstruct import CONST
+from oracle.oracle import OracleBatch, load
+from pp_scenarios import PP, between_fingers, deliver, grasp_and_carry, put_box, tumble
+
+KW = dict(shield_type="OFF", horizon=200, seed=3)
+
+
+def _batch(n, kw=KW):
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    d = hrg.build_model_desc(kw, n_clips=clips.n_clips, **PP)
+    return OracleBatch(d, clips, n), d
+
+
+def test_desc_follows_the_reference_defaults():
+    d = hrg.build_model_desc(None, **PP)
+    assert d.task == CONST["HRG_TASK_PICK_PLACE"] and d.horizon == 1000 and d.n_targets == 30 and d.n_obj_placements == 30
+    np.testing.assert_allclose(list(d.init_qpos), [0, 0, -np.pi / 2, 0, -np.pi / 2, np.pi / 4])
+    np.testing.assert_allclose(list(d.obj_bin), [0.7 * 0.35, 0.7 * 0.6, 0.95 * 0.25, 0.95 * 0.45])      # 843-858
+    np.testing.assert_allclose(list(d.tgt_bin), [0.7 * 0.35, 0.7 * 0.6, 0.95 * -0.45, 0.95 * -0.25])    # 860-875
+    assert d.box_half == 0.02 and abs(d.box_mass - 0.064) < 1e-12 and d.object_gripped_reward == -0.25 and d.obstacle_margin == 0.0
+    assert abs(d.obj_z - 0.82) < 1e-12 and abs(d.tgt_z - 0.84) < 1e-12
+    assert hrg.build_model_desc(None).task == CONST["HRG_TASK_REACH"]
+
+
+def test_reset_places_object_and_target_in_their_bins_and_observes_them():
+    B, d = _batch(16)
+    obs = B.reset()
+    for e in range(16):
+        bx = B.get_box(e)
+        assert d.obj_bin[0] <= bx.pos[0] <= d.obj_bin[1] and d.obj_bin[2] <= bx.pos[1] <= d.obj_bin[3] and bx.pos[2] == d.obj_z
+        assert d.tgt_bin[0] <= bx.target[0] <= d.tgt_bin[1] and d.tgt_bin[2] <= bx.target[1] <= d.tgt_bin[3] and bx.target[2] == d.tgt_z
+        assert list(bx.quat) == [1, 0, 0, 0] and not any(bx.vel)
+        s = B.get_state(e)
+        np.testing.assert_allclose(obs[e, 47:50], list(bx.pos), rtol=1e-6)
+        np.testing.assert_allclose(obs[e, 50:53], list(bx.target), rtol=1e-6)
+        np.testing.assert_allclose(obs[e, 40:43], np.array(bx.pos) - np.array(s.eef_pos), rtol=1e-5, atol=1e-7)
+        np.testing.assert_allclose(obs[e, 43:46], np.array(bx.target) - np.array(s.eef_pos), rtol=1e-5, atol=1e-7)
+        assert obs[e, 39] == 0 and abs(obs[e, 46] - 1.0) < 1e-6          # not gripped, gripper fully open (qpos_range[1])
+        assert not obs[e, 12:18].any() and not obs[e, 33:39].any()
+    assert len({round(B.get_box(e).pos[0], 9) for e in range(16)}) == 16   # per-env streams
+    B.close()
+
+
+def test_cube_settles_on_the_table_and_stays():
+    """The sampler drops the cube centre at the table surface (reference_pos z 0.8 + half edge): the contact solver has to
+    push it out and bring it to rest on its face."""
+    B, d = _batch(4)
+    B.reset()
+    for _ in range(8):
+        _, r, _, info = B.step(np.zeros((4, 7)))
+    for e in range(4):
+        bx = B.get_box(e)
+        assert abs(bx.pos[2] - (d.table_top_z + d.box_half)) < 3e-4 and max(abs(v) for v in bx.vel) < 1e-3
+        assert abs(bx.quat[0]) > 1 - 1e-6
+    pairs, ncon = B.contacts()
+    assert (ncon == 4).all() and (pairs[:, :4, 0] == 34).all() and (pairs[:, :4, 1] == 36).all()   # table (34) - cube (36) corners
+    assert (r == -1).all() and not info[:, 0].any()                        # sparse reward, no robot collision
+    B.close()
+
+
+def test_tumbling_cube_comes_to_rest_on_a_face():
+    B, d = _batch(8)
+    B.reset()
+    rng = np.random.RandomState(0)
+    for k in range(40):
+        a = tumble(k, [B], rng, 8)
+        _, _, _, info = B.step(a)
+        assert not info[:, 11].any()
+    for e in range(8):
+        bx = B.get_box(e)
+        assert abs(bx.pos[2] - (d.table_top_z + d.box_half)) < 1e-3, bx.pos[2]
+        assert max(abs(v) for v in bx.vel) < 0.05
+        assert abs(np.linalg.norm(list(bx.quat)) - 1) < 1e-12
+    B.close()
+
+
+def test_grasp_carry_release():
+    B, d = _batch(2)
+    B.reset()
+    rng = np.random.RandomState(0)
+    grip, rew, dz = [], [], []
+    for k in range(40):
+        a = grasp_and_carry(k, [B], rng, 2, d)
+        obs, r, _, info = B.step(a)
+        assert not info[:, 11].any()
+        grip.append(obs[:, 39].copy()); rew.append(r.copy())
+        dz.append([np.linalg.norm(obs[e, 40:43]) for e in range(2)])
+        assert not (info[:, 1] & (4 | 8 | 16)).any()          # finger - cube contacts are ALLOWED, not illegal collisions
+    grip, rew, dz = np.array(grip), np.array(rew), np.array(dz)
+    assert (grip[3:30] == 1).all() and (rew[3:30] == -0.25).all()          # object_gripped_reward while held
+    assert (dz[5:30] < 0.045).all()                                         # carried along with the end effector
+    assert (grip[33:] == 0).all() and (rew[33:] == -1).all()                # released
+    for e in range(2):
+        assert abs(B.get_box(e).pos[2] - (d.table_top_z + d.box_half)) < 1e-3   # and back on the table
+    B.close()
+
+
+def test_success_advances_target_and_placement_and_pays_task_reward():
+    B, d = _batch(4, dict(KW, reward_shaping=False))
+    B.reset()
+    rng = np.random.RandomState(1)
+    first = [(list(B.get_box(e).target), list(B.get_box(e).pos)) for e in range(4)]
+    hits = 0
+    for k in range(12):
+        a = deliver(k, [B], rng, 4)
+        pre = [B.get_box(e) for e in range(4)]
+        obs, r, done, info = B.step(a)
+        if k in (3, 9):
+            hits += 1
+            assert (r == 1.0).all() and not done.any()                       # task_reward, done_at_success False in the yaml
+            assert (info[:, 9] == hits).all()
+            for e in range(4):
+                bx = B.get_box(e)
+                assert bx.tgt_index == hits and bx.obj_index == hits
+                assert list(bx.target) != list(pre[e].target)
+                assert d.obj_bin[0] <= bx.pos[0] <= d.obj_bin[1] and d.obj_bin[2] <= bx.pos[1] <= d.obj_bin[3] and bx.pos[2] == d.obj_z
+                np.testing.assert_allclose(obs[e, 50:53], list(pre[e].target), rtol=1e-6)   # the observation still shows the reached target
+        else:
+            assert (r == -1.0).all()
+    assert first[0][0] != list(B.get_box(0).target)
+    B.close()
+
+
+def test_dense_reward_terms():
+    B, d = _batch(3, dict(KW, reward_shaping=True))
+    B.reset()
+    obs, r, _, _ = B.step(np.zeros((3, 7)))
+    for e in range(3):
+        e2o, o2t = np.linalg.norm(obs[e, 40:43]), np.linalg.norm(obs[e, 50:53] - obs[e, 47:50])
+        assert abs(r[e] - (-1 + 1 - (0.2 * e2o + o2t) * 0.1)) < 1e-5        # human_env.py:650-651 + _dense_reward 502-526
+    B.close()
+
+
+def test_seg_box_known_answers():
+    lib = load()
+    out = (ctypes.c_double * 7)()
+    def sb(p1, p2, c=(0, 0, 0), q=(1, 0, 0, 0), hb=0.5):
+        lib.hrgo_test_segbox((ctypes.c_double * 3)(*p1), (ctypes.c_double * 3)(*p2), (ctypes.c_double * 3)(*c), (ctypes.c_double * 4)(*q), ctypes.c_double(hb), out)
+        return np.array(out[:])
+    o = sb((2, 0, 0), (3, 0, 0))                      # pointing away: closest at the first end point, face +x
+    assert abs(o[0] - 1.5 ** 2) < 1e-14 and np.allclose(o[1:4], (2, 0, 0)) and np.allclose(o[4:7], (0.5, 0, 0))
+    o = sb((-3, 2, 0), (3, 2, 0))                     # parallel above the +y face: distance 1.5, closest point over the face
+    assert abs(o[0] - 1.5 ** 2) < 1e-14 and abs(o[2] - 2) < 1e-14 and abs(o[5] - 0.5) < 1e-14 and abs(o[1]) <= 0.5 + 1e-12
+    o = sb((-2, 2, 0), (2, -2, 0))                    # through the centre
+    assert o[0] == 0
+    o = sb((0, 2, 2), (2, 0, 2))                      # diagonal past the +x+y+z corner region: closest to the edge x=y=.5... at the corner (0.5,0.5,0.5)
+    assert np.allclose(o[4:7], (0.5, 0.5, 0.5)) and np.allclose(o[1:4], (1, 1, 2)) and abs(o[0] - (0.25 + 0.25 + 2.25)) < 1e-12
+    rng = np.random.RandomState(0)                    # against dense sampling of the segment, rotated cubes
+    for _ in range(200):
+        p1, p2, c = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3), rng.uniform(-0.5, 0.5, 3)
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        o = sb(p1, p2, c, q, 0.4)
+        w, x, y, z = q
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+        t = np.linspace(0, 1, 4001)[:, None]
+        P = (p1 + t * (p2 - p1) - c) @ R
+        e = P - np.clip(P, -0.4, 0.4)
+        assert o[0] <= (e ** 2).sum(1).min() + 1e-12 and o[0] >= (e ** 2).sum(1).min() - 1e-5

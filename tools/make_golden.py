@@ -20,6 +20,8 @@ CASES = {
     "reach_ssm": dict(shield_type="SSM", reward_shaping=True, horizon=25),
     "reach_ssm_freq5": dict(shield_type="SSM", control_freq=5, horizon=1000, human_rand=[0.2, 0.2, 0.2]),  # config 1 shape: 50 cycles/step
     "contact_static": dict(shield_type="OFF", horizon=60, done_at_collision=False, collision_reward=-10),
+    # PickPlaceHumanCart (BASELINE config 4 shape): the cube pops out of the table, rests, gets re-placed after a delivery
+    "pick_place_ssm": dict(env_id="PickPlaceHumanCart", shield_type="SSM", reward_shaping=True, horizon=30),
 }
 
 
@@ -31,13 +33,20 @@ def clips_for(name):
 
 def run(name, kw, n_envs=8, n_steps=40, seed=11):
     clips = clips_for(name)
-    d = hrg.build_model_desc(kw, n_clips=clips.n_clips)
+    kw = dict(kw)
+    env_id = kw.pop("env_id", "ReachHuman")
+    d = hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=env_id)
     B = OracleBatch(d, clips, n_envs)
     out = dict(obs0=B.reset())
     rng = np.random.RandomState(seed)
-    acts, obs, rew, done, info, qpos, qvel, ncon, pairs = [], [], [], [], [], [], [], [], []
-    for _ in range(n_steps):
+    acts, obs, rew, done, info, qpos, qvel, ncon, pairs, box = [], [], [], [], [], [], [], [], [], []
+    for k in range(n_steps):
         a = rng.uniform(-1, 1, (n_envs, 7))
+        if env_id == "PickPlaceHumanCart" and k == 20:  # a delivery: cube teleported next to its target
+            for e in range(n_envs):
+                bx = B.get_box(e)
+                bx.pos[:] = [bx.target[0] + 0.02, bx.target[1], 0.845]
+                B.set_box(e, bx)
         if name == "contact_static":  # tilt the arm towards / away from the hand
             a[:, 1] = np.where(np.arange(n_envs) % 2 == 0, 1.0, -1.0)
             a[:, [0, 2, 3, 4, 5]] *= 0.2
@@ -47,8 +56,10 @@ def run(name, kw, n_envs=8, n_steps=40, seed=11):
         qpos.append([list(s.qpos) for s in st]); qvel.append([list(s.qvel) for s in st])
         p, n = B.contacts()
         ncon.append(n); pairs.append(p)
+        bxs = [B.get_box(e) for e in range(n_envs)]
+        box.append([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs])
     out.update(actions=np.array(acts), obs=np.array(obs), reward=np.array(rew), done=np.array(done), info=np.array(info),
-               qpos=np.array(qpos), qvel=np.array(qvel), ncon=np.array(ncon), pairs=np.array(pairs).astype(np.int8))
+               qpos=np.array(qpos), qvel=np.array(qvel), ncon=np.array(ncon), pairs=np.array(pairs).astype(np.int8), box=np.array(box))
     return out
 
 
