@@ -36,7 +36,7 @@ def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
     return 2 * state_bytes + n_cycles * frame + C["HRG_ACT_DIM"] * 8 + out
 
 
-def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16):
+def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="ReachHuman", n_envs=ENVS_PER_GPU):
     """Oracle on the host cores: P threads (ctypes releases the GIL) x n/P envs each, barrier per vec-step —
     the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per step)."""
     import numpy as np
@@ -44,9 +44,9 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16):
     from oracle.oracle import OracleBatch
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(avail, max_threads)  # a 1-GPU box is given a 16-core CPU share
-    n = ENVS_PER_GPU
+    n = n_envs
     clips = hrg.synthetic_clips(13, seed=clips_seed)
-    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id)
     B = OracleBatch(desc, clips, n, 0)
     B.reset()
     rng = np.random.RandomState(1234)
@@ -79,7 +79,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
-    ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
+    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart"],
+                    help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs)")
+    ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
@@ -103,11 +105,16 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ReachHuman training configuration: training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
-    env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
-                      reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
-    n = args.envs_per_gpu
+    pick_place = args.env == "PickPlaceHumanCart"
+    if pick_place:  # training/config/environment/pick_place_human_cart.yaml
+        env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=1000, done_at_success=False, goal_dist=0.1,
+                          reward_shaping=False, collision_reward=0, object_gripped_reward=-0.25, seed=1234)
+    else:
+        env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
+                          reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
+    n = args.envs_per_gpu or (8192 if pick_place else ENVS_PER_GPU)
     clips = hrg.synthetic_clips(13, seed=0)
-    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips)
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env)
     G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
     dev = G.device
     G.reset()
@@ -140,7 +147,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        state_bytes = load_library().hrg_state_bytes()
+        state_bytes = load_library().hrg_state_bytes() + (load_library().hrg_box_bytes() if pick_place else 0)
         per_env = algorithmic_bytes_per_env_step(C, state_bytes, desc.n_cycles)
         achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
@@ -149,8 +156,10 @@ def main():
                 traffic = json.load(f).get("hbm_bytes_per_launch")
         except Exception:
             pass
+        if pick_place or n != ENVS_PER_GPU:
+            traffic = None  # the committed PMC capture is of the default workload's kernel
         out = {
-            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs",
+            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else "env steps/sec (whole node), PickPlaceHumanCart+shield 8192 envs",
             "value": world * n * args.steps / elapsed,
             "unit": "env steps/s",
             "n_gpus": world,
@@ -162,17 +171,17 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"ReachHuman, {n} envs/GPU, sara-shield {args.shield}, control_freq 10 (25 x 4 ms shield cycles per step), "
+            "config": {"workload": f"{args.env}, {n} envs/GPU, sara-shield {args.shield}, control_freq 10 (25 x 4 ms shield cycles per step), "
                                    "random actions U(-1,1)^7, 13 synthetic human clips, auto-reset",
-                       "envs_per_gpu": n, "shield_type": args.shield, "horizon": 100, "substeps_per_step": int(desc.n_cycles),
+                       "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" if world > 1 else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "hrg_step_kernel", "kernel_ms": kernel_ms, "launches": n_launch,
+                         "traffic": traffic, "kernel": "hrg_step_kernel_box" if pick_place else "hrg_step_kernel", "kernel_ms": kernel_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": per_env * n},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads)
+            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n)
         print(json.dumps(out), flush=True)
     G.close()
     if world > 1:

@@ -23,6 +23,10 @@ DI void impedance(const MD& m, double x0, double* imp, double* K, double* Bd) {
   double y;
   if (x >= 1) y = 1;
   else if (x <= 0) y = 0;
+  else if (power == 2.0) { // MuJoCo's default solimp power: the square, not a libm call
+    if (x <= mid) { const double u = x / mid; y = u * u * mid; }
+    else { const double u = (1 - x) / (1 - mid); y = 1 - u * u * (1 - mid); }
+  }
   else if (x <= mid) y = pow(x / mid, power) * mid;
   else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
   *imp = d0 + y * (dmax - d0);
@@ -89,10 +93,12 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
     if (lane < NV) L.a0[lane] = x;
   }
+  STAMP(20);
   // ---- this lane's constraint row (fixed slot) ----
   const int r = lane;
   int type = 1, rdof = 0;
   bool cand = false;
+  bool rpart = true, bpart = false;  // row acts on the robot tree / on the cube
   double rsgn = 0, pos = 0, margin = 0, floss = 0, diag = 0, vel = 0;
   if (r < NV) {
     if (m.jnt_frictionloss[r] > 0) {
@@ -124,6 +130,11 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
       const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
       double nz = 0;
+#if HRG_BOX
+      if (!(rb1 || rb2)) { // table / floor - cube: no robot part
+        for (int i = 0; i < NV; i++) L.Jc[r - ROW_CON0][i] = 0.0;
+      } else
+#endif
 #pragma unroll 1
       for (int i = 0; i < NV; i++) {
         double t[3], v[3];
@@ -137,7 +148,9 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         vel += acc * s.qvel[i];
         nz += fabs(acc);
       }
+      rpart = nz > 0;
 #if HRG_BOX
+      bpart = cc.b2 == BODY_BOX;
       if (cc.b2 == BODY_BOX) { // the cube is always geom 2: J = dir . (v + w x r); body_invweight0 of a free body = 1/m
         double rr[3], rxd[3];
         for (int a = 0; a < 3; a++) rr[a] = cp[a] - bx.pos[a];
@@ -164,6 +177,15 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   }
   const uint64_t mask = __ballot(active);
   const uint64_t cmask = mask >> ROW_CON0;  // active contact rows
+#if HRG_BOX
+  // contact rows by the block of the Hessian they touch.  Without a robot-cube contact the 14-DoF system is block diagonal
+  // (8x8 robot tree, 6x6 cube) and both blocks are factored in registers; a coupled system takes the 14x14 LDS path.
+  const uint64_t rmask = __ballot(active && is_con && rpart) >> ROW_CON0, bmask = __ballot(active && is_con && bpart) >> ROW_CON0;
+  const bool coupled = (rmask & bmask) != 0;
+#else
+  const uint64_t rmask = cmask;
+#endif
+  STAMP(21);
   COUNT(19, __popcll(mask));  // active rows
   wave_sync();
   // J_r . x for a wave-shared vector x (LDS)
@@ -193,6 +215,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       if (!(cost_ws < cost_a0)) { if (lane < NVS) L.qacc[lane] = L.a0[lane]; }
       wave_sync();
     }
+    STAMP(22);
     bool h_is_m = true;
 #pragma unroll 1
     for (int it = 0; it < m.solver_iters; it++) {
@@ -211,17 +234,59 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         t += L.rg[lane];
         t += L.rg[NV + 2 * lane];
         t -= L.rg[NV + 2 * lane + 1];
-        for (uint64_t mm = cmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+        for (uint64_t mm = rmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
         L.g[lane] = t;
       }
 #if HRG_BOX
       else if (lane < NVT) {
         double t = -L.Ma0[lane] + mdiag * L.qacc[lane];
         gm = t;
-        for (uint64_t mm = cmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+        for (uint64_t mm = bmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
         L.g[lane] = t;
       }
-      // Hessian of the 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
+      wave_sync();
+      double gn = 0, sc = 0;
+#pragma unroll
+      for (int i = 0; i < NVT; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
+      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      if (!coupled) {
+        // robot block (as in the ReachHuman solver) and cube block (6x6 padded to 8x8 with a unit diagonal), lanes = (mi, mj)
+        double hval = Mij;
+        if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
+        for (uint64_t mm = rmask; mm;) {
+          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+          const double hq = L.rh[ROW_CON0 + q];
+          if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
+        }
+        double sval = mi == mj ? (mi < 3 ? m.box_mass : (mi < HRG_NBOXV ? m.box_inertia : 1.0)) : 0.0;
+        if (mi < HRG_NBOXV && mj < HRG_NBOXV)
+          for (uint64_t mm = bmask; mm;) {
+            const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+            const double hq = L.rh[ROW_CON0 + q];
+            if (hq != 0) sval += hq * L.Jc[q][NV + mi] * L.Jc[q][NV + mj];
+          }
+        STAMP(23);
+        if (__any(hh != 0 && rpart) || !h_is_m) {  // no robot row with curvature: the robot block is M and its factor is still in LDS
+          const double hl = chol_lanes(hval, lane, &ok);
+          if (!ok) break;
+          chol_store(hl, lane, L.H, L.Hinv);
+          h_is_m = false;
+          wave_sync();
+        }
+        double* Hs = &L.Hb[0][0];   // factor of the cube block: 64 + 8 doubles of the (idle) 14x14 buffer
+        {
+          const double sl = chol_lanes(sval, lane, &ok);
+          if (!ok) break;
+          chol_store(sl, lane, Hs, Hs + 64);
+          wave_sync();
+        }
+        STAMP(24);
+        const double x1 = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
+        const double x2 = chol_solve_lanes(Hs, Hs + 64, lane < HRG_NBOXV ? -L.g[NV + lane] : 0.0, lane);
+        if (lane < NV) L.d[lane] = x1;
+        if (lane < HRG_NBOXV) L.d[NV + lane] = x2;
+      } else {
+      // Hessian of the coupled 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
 #pragma unroll 1
       for (int e = lane; e < NVT * NVT; e += 64) {
         const int i = e / NVT, j = e - i * NVT;
@@ -235,14 +300,13 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         L.Hb[i][j] = hv;
       }
       wave_sync();
-      double gn = 0, sc = 0;
-#pragma unroll
-      for (int i = 0; i < NVT; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
-      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      STAMP(23);
       if (!chol_box(lane)) break;
+      STAMP(24);
       {
         const double x = chol_box_solve(lane < NVT ? -L.g[lane] : 0.0, lane);
         if (lane < NVT) L.d[lane] = x;
+      }
       }
       wave_sync();
       const double p = rowdot(L.d);
@@ -286,6 +350,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         for (int j = 0; j < NV; j++) Mdi += L.M[lane * NV + j] * L.d[j];
       }
 #endif
+      STAMP(25);
       const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
       double al = 1.0, lo = 0, hi = -1;
       const double d1_0 = gd0 + wave_sum(gg * p);
@@ -303,6 +368,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
         al = nx;
       }
+      STAMP(26);
       if (lane < NVS) L.qacc[lane] += al * dd;
       wave_sync();
       // a full Newton step that stayed inside one quadratic piece of every row solved the problem exactly
@@ -782,7 +848,10 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
 #if HRG_BOX
 #define hrg_step_kernel hrg_step_kernel_box
 #define hrg_reset_kernel hrg_reset_kernel_box
-#define HRG_KERNEL_WAVES 2   // the variant with the cube needs more registers and LDS; it is not the tuned path
+#ifndef HRG_BOX_WAVES
+#define HRG_BOX_WAVES 3
+#endif
+#define HRG_KERNEL_WAVES HRG_BOX_WAVES   // the variant with the cube needs more registers and LDS
 // the cube's state block: streamed like the env block
 DI void box_load(const hrg_box_state* __restrict__ boxes, int e, int lane) {
   constexpr int NB = (int)(sizeof(hrg_box_state) / sizeof(double));
@@ -856,6 +925,19 @@ extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* 
 }
 extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_box_state* boxes) {
   hipLaunchKernelGGL(hrg_reset_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, mask, obs, env_id0, boxes);
+}
+#endif
+
+#ifdef HRG_STAMPS
+#if HRG_BOX
+#define hrg_debug_stamps hrg_debug_stamps_box
+#endif
+extern "C" int hrg_debug_stamps(double* out, int reset) {
+  unsigned long long h[32];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < 32; i++) out[i] = (double)h[i];
+  if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
+  return 0;
 }
 #endif
 
@@ -1095,15 +1177,6 @@ int hrg_batch_enable_taps(hrg_batch* b, int32_t on) {
   return HRG_OK;
 }
 
-#ifdef HRG_STAMPS
-int hrg_debug_stamps(double* out, int reset) {
-  unsigned long long h[32];
-  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps), sizeof h) != hipSuccess) return -1;
-  for (int i = 0; i < 32; i++) out[i] = (double)h[i];
-  if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
-  return 0;
-}
-#endif
 
 int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");

@@ -943,6 +943,10 @@ static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* 
   double x = fabs(pos_minus_margin) / width, y;
   if (x >= 1) y = 1;
   else if (x <= 0) y = 0;
+  else if (power == 2.0) { /* MuJoCo's default solimp power: the square, not a libm call */
+    if (x <= mid) { const double u = x / mid; y = u * u * mid; }
+    else { const double u = (1 - x) / (1 - mid); y = 1 - u * u * (1 - mid); }
+  }
   else if (x <= mid) y = pow(x / mid, power) * mid;
   else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
   *imp = d0 + y * (dmax - d0);
