@@ -166,3 +166,29 @@ def test_seg_box_known_answers():
         P = (p1 + t * (p2 - p1) - c) @ R
         e = P - np.clip(P, -0.4, 0.4)
         assert o[0] <= (e ** 2).sum(1).min() + 1e-12 and o[0] >= (e ** 2).sum(1).min() - 1e-5
+
+
+def test_vec_env_serves_the_pp_sac_observation_layout():
+    """`make_vec_env("PickPlaceHumanCart")` surface: default obs_keys = the observables the pick-place policies are trained on
+    (object_gripped, vec_eef_to_object, vec_eef_to_target, gripper_aperture, 3 human distances = 11 values)."""
+    from helpers import OracleBackend
+    from human_robot_gym_amd.vec_env import HipVecEnv, PICK_PLACE_OBS_KEYS
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    kw = dict(shield_type="SSM", horizon=6, seed=2)
+    desc = hrg.build_model_desc(kw, n_clips=clips.n_clips, **PP)
+    back = OracleBackend(desc, clips, 3)
+    env = HipVecEnv(3, env_id="PickPlaceHumanCart", env_kwargs=kw, clips=clips, backend=back)
+    assert env.obs_keys == PICK_PLACE_OBS_KEYS and env.observation_space.shape == (11,)
+    obs = env.reset()
+    full = back.B.obs
+    np.testing.assert_array_equal(obs[:, 0], full[:, 39])
+    np.testing.assert_array_equal(obs[:, 1:4], full[:, 40:43])
+    np.testing.assert_array_equal(obs[:, 4:7], full[:, 43:46])
+    np.testing.assert_array_equal(obs[:, 7], full[:, 46])
+    np.testing.assert_array_equal(obs[:, 8:11], full[:, [11, 3, 7]])          # dist to head, left hand, right hand
+    for k in range(6):
+        obs, rew, done, infos = env.step(np.zeros((3, 7)))
+    assert done.all() and infos[0]["TimeLimit.truncated"] and infos[0]["terminal_observation"].shape == (11,)
+    env2 = HipVecEnv(2, env_id="PickPlaceHumanCart", env_kwargs=kw, clips=clips, obs_keys=["object_pos", "target_pos", "robot0_eef_pos"],
+                     backend=OracleBackend(hrg.build_model_desc(kw, n_clips=clips.n_clips, **PP), clips, 2))
+    assert env2.reset().shape == (2, 9)
