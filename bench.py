@@ -36,7 +36,7 @@ def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
     return 2 * state_bytes + n_cycles * frame + C["HRG_ACT_DIM"] * 8 + out
 
 
-def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="ReachHuman", n_envs=ENVS_PER_GPU):
+def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="ReachHuman", n_envs=ENVS_PER_GPU, wrappers=None):
     """Oracle on the host cores: P threads (ctypes releases the GIL) x n/P envs each, barrier per vec-step —
     the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per step)."""
     import numpy as np
@@ -46,7 +46,7 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="
     cores = min(avail, max_threads)  # a 1-GPU box is given a 16-core CPU share
     n = n_envs
     clips = hrg.synthetic_clips(13, seed=clips_seed)
-    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id)
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id, **(wrappers or {}))
     B = OracleBatch(desc, clips, n, 0)
     B.reset()
     rng = np.random.RandomState(1234)
@@ -59,11 +59,17 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="
         for t in ts:
             t.join()
 
-    vec_step(rng.uniform(-1, 1, (n, 7)))  # warm-up
+    def draw():
+        a = rng.uniform(-1, 1, (n, 7))
+        if wrappers:
+            a[:, :3] *= 0.15
+        return a
+
+    vec_step(draw())  # warm-up
     t0 = time.perf_counter()
     k = 0
     while True:
-        vec_step(rng.uniform(-1, 1, (n, 7)))
+        vec_step(draw())
         k += 1
         el = time.perf_counter() - t0
         if el >= budget_s and k >= 2:
@@ -81,6 +87,8 @@ def main():
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
     ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart"],
                     help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs)")
+    ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
+                    "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -114,17 +122,27 @@ def main():
                           reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
     n = args.envs_per_gpu or (8192 if pick_place else ENVS_PER_GPU)
     clips = hrg.synthetic_clips(13, seed=0)
-    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env)
+    wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if args.ik else {}
+    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env, **wrappers)
     G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
     dev = G.device
     G.reset()
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     pool = [torch.rand((n, C["HRG_ACT_DIM"]), generator=gen, device=dev, dtype=torch.float64) * 2 - 1 for _ in range(32)]
+    if args.ik:  # position deltas U(-0.15, 0.15)^3, gripper U(-1, 1)
+        for a in pool:
+            a[:, :3] *= 0.15
+    fresh = [torch.empty_like(pool[0]) for _ in range(2)]  # the kernel rewrites action rows in place when wrappers are on
     gathered = torch.empty(world * G.packed.numel(), dtype=torch.uint8, device=dev) if world > 1 else None
 
     def one_step(k):
-        G.step(pool[k % len(pool)])
+        if args.ik:
+            a = fresh[k & 1]
+            a.copy_(pool[k % len(pool)])
+            G.step(a)
+        else:
+            G.step(pool[k % len(pool)])
         if world > 1:
             dist.all_gather_into_tensor(gathered, G.packed)  # one fused RCCL all-gather of obs/reward/done/info
 
@@ -172,7 +190,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} envs/GPU, sara-shield {args.shield}, control_freq 10 (25 x 4 ms shield cycles per step), "
-                                   "random actions U(-1,1)^7, 13 synthetic human clips, auto-reset",
+                                   + ("Cartesian random actions through the IK front-end + collision prevention, " if args.ik else "random actions U(-1,1)^7, ")
+                                   + "13 synthetic human clips, auto-reset",
                        "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" if world > 1 else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
@@ -181,7 +200,7 @@ def main():
                          "algorithmic_bytes_per_launch": per_env * n},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n)
+            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n, wrappers=wrappers)
         print(json.dumps(out), flush=True)
     G.close()
     if world > 1:

@@ -516,6 +516,101 @@ DI void action_goal(ModelPtr dm, int lane, const double* act) {
   wave_sync();
 }
 
+// IKPositionDeltaWrapper.step (wrappers/ik_position_delta_wrapper.py:93-142): L.act = [dx, dy, dz, gripper] -> joint action.
+// Damped least squares on [position; orientation] of the end-effector link (orientation held at the initial one).  Lane 0 runs
+// the chain kinematics, lanes = joints build the Jacobian columns, lanes = (i, j) build and factor J J' + lambda^2 I (6x6 padded
+// into the 8x8 lane Cholesky), lanes = joints apply the step.  Scratch: the shield's part of the LDS union (idle here).
+DI void ik_action(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  const hrg_env_state& s = L.st;
+  double* sc = &L.scap[0][0][0];
+  double *ax = sc, *org = sc + 18, *R6 = sc + 36, *pee = sc + 45, *ee = sc + 48;  // 54 of 84 doubles
+  double* J = &L.rc[0][0];                                                          // [6][6] of 49 doubles
+  const double grip = clampd(L.act[3], -1.0, 1.0);
+  const double ws = lane < 3 ? clampd(L.act[lane], -m.ik_action_limit, m.ik_action_limit) * m.ik_x_output_max : 0.0;
+  wave_sync();
+  if (lane < NARM) L.cq[lane] = s.qpos[lane];
+  wave_sync();
+  double target = 0;  // lane a < 3 holds target[a]
+#pragma unroll 1
+  for (int it = 0;; it++) {
+    if (lane == 0) {
+      double R[9], p[3], t[3];
+      for (int k = 0; k < 9; k++) R[k] = dm->Rbase[k];
+      v3cpy(p, m.base_pos);
+#pragma unroll 1
+      for (int i = 0; i < NARM; i++) {
+        double Rl[9], Rj[9];
+        m3mul(Rl, R, dm->Rq[i]);
+        m3mulv(t, R, m.body_pos[i]);
+        v3add(p, p, t);
+        axisangle2mat(Rj, m.jnt_axis[i], L.cq[i]);
+        m3mul(R, Rl, Rj);
+        m3mulv(t, R, m.jnt_axis[i]);
+        v3cpy(ax + 3 * i, t);
+        v3cpy(org + 3 * i, p);
+      }
+      for (int k = 0; k < 9; k++) R6[k] = R[k];
+      m3mulv(t, R, m.ik_ee_offset);
+      v3add(t, p, t);
+      v3cpy(pee, t);
+    }
+    wave_sync();
+    if (it == 0 && lane < 3) {
+      target = pee[lane] + ws;
+      if (m.ik_use_pos_limits) target = clampd(target, m.ik_pos_limits[0][lane], m.ik_pos_limits[1][lane]);
+    }
+    const double dl = lane < 3 ? target - pee[lane] : 0.0;
+    const double d0 = __shfl(dl, 0, 64), d1 = __shfl(dl, 1, 64), d2 = __shfl(dl, 2, 64);
+    if (it > 0 && sqrt(d0 * d0 + d1 * d1 + d2 * d2) <= m.ik_residual_threshold) break;
+    if (it >= m.ik_max_iter) break;
+    if (lane == 0) {  // error vector: position, rotation vector of R_target R6'
+      double E[9], v[3];
+      for (int a = 0; a < 3; a++)
+        for (int b = 0; b < 3; b++) E[3 * a + b] = m.ik_target_rot[3 * a] * R6[3 * b] + m.ik_target_rot[3 * a + 1] * R6[3 * b + 1] + m.ik_target_rot[3 * a + 2] * R6[3 * b + 2];
+      v3set(v, 0.5 * (E[7] - E[5]), 0.5 * (E[2] - E[6]), 0.5 * (E[3] - E[1]));
+      const double sn = v3norm(v), cs = 0.5 * (E[0] + E[4] + E[8] - 1.0), ang = atan2(sn, cs);
+      ee[0] = d0; ee[1] = d1; ee[2] = d2;
+      for (int a = 0; a < 3; a++) ee[3 + a] = sn > 1e-12 ? v[a] / sn * ang : 0.0;
+    }
+    if (lane < NARM) {
+      double r[3], c[3];
+      v3sub(r, pee, org + 3 * lane);
+      v3cross(c, ax + 3 * lane, r);
+      for (int a = 0; a < 3; a++) { J[a * 6 + lane] = c[a]; J[(3 + a) * 6 + lane] = ax[3 * lane + a]; }
+    }
+    wave_sync();
+    const int mi = lane >> 3, mj = lane & 7;
+    double aij = mi == mj ? 1.0 : 0.0;
+    if (mi < 6 && mj < 6) {
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += J[mi * 6 + j] * J[mj * 6 + j];
+      aij = t + (mi == mj ? m.ik_damping * m.ik_damping : 0.0);
+    }
+    bool ok;
+    const double lij = chol_lanes(aij, lane, &ok);
+    if (!ok) break;
+    chol_store(lij, lane, L.H, L.Hinv);
+    wave_sync();
+    const double y = chol_solve_lanes(L.H, L.Hinv, lane < 6 ? ee[lane] : 0.0, lane);
+    double dq = 0;
+    for (int a = 0; a < 6; a++) { const double ya = __shfl(y, a, 64); if (lane < NARM) dq += J[a * 6 + lane] * ya; }
+    double mx = 0;
+    for (int j = 0; j < NARM; j++) { const double v = fabs(__shfl(dq, j, 64)); if (v > mx) mx = v; }
+    const double scl = mx > 0.25 * HRG_PI ? 0.25 * HRG_PI / mx : 1.0;
+    wave_sync();
+    if (lane < NARM) L.cq[lane] = L.cq[lane] + scl * dq;
+    wave_sync();
+  }
+  wave_sync();
+  const double out = lane < NARM ? L.cq[lane] - s.qpos[lane] : grip;
+  wave_sync();
+  if (lane <= NARM) L.act[lane] = out;
+  wave_sync();
+}
+
 // CollisionPreventionWrapper.action (wrappers/collision_prevention_wrapper.py:46-103) on L.act
 DI void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
   const ModelPtr dm = uniform_model(dm_);
@@ -751,8 +846,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   STAMP_INIT(lane);
   if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
   wave_sync();
+  if (m.ik_enabled) ik_action(dm_, lane);  // IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373)
   screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
-  if (m.cp_enabled && lane < HRG_ACT_DIM) action[lane] = L.act[lane];
+  if ((m.cp_enabled || m.ik_enabled) && lane < HRG_ACT_DIM) action[lane] = L.act[lane];
   s.timestep = s.timestep + 1;
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
   wave_sync();
@@ -1000,6 +1096,8 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
   if (desc->task != HRG_TASK_REACH && desc->task != HRG_TASK_PICK_PLACE) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->ik_enabled && !(desc->ik_max_iter >= 1 && desc->ik_max_iter <= 1000 && desc->ik_damping > 0 && desc->ik_action_limit > 0 && desc->ik_residual_threshold >= 0))
+    return fail(HRG_ERR_INVALID, "ik: need 1 <= max_iter <= 1000, damping > 0, action_limit > 0, residual_threshold >= 0");
   if (desc->task == HRG_TASK_PICK_PLACE && !(desc->box_half > 0 && desc->box_mass > 0 && desc->box_inertia > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
     return fail(HRG_ERR_INVALID, "PickPlaceHumanCart needs box_half, box_mass, box_inertia, n_targets, n_obj_placements > 0");
   HIPCHK(hipSetDevice(device));

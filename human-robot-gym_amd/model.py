@@ -171,14 +171,21 @@ def load_assets(name="reach_human_schunk.json"):
         return json.load(f)
 
 
+# config/wrappers/ik_position_delta/default_ik_position_delta.yaml (+ the DLS damping, which pybullet keeps internal)
+IK_DEFAULTS = dict(action_limit=0.15, x_output_max=1, x_position_limits=None, residual_threshold=1e-3, max_iter=50, damping=0.1)
+IK_EE_OFFSET = [0.0, 0.0, 0.17]   # models/assets/robots/schunk/robot_pybullet.urdf:226-228 (fixed_gripper_joint)
+
+
 def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True,
-                     env_id="ReachHuman"):
+                     env_id="ReachHuman", ik_position_delta=None):
     """Return a filled `ModelDesc` for `env_id` ("ReachHuman" or "PickPlaceHumanCart") on the Schunk arm.
 
     `env_kwargs` takes the same keys as the reference's environment config
     (training/config/environment/reach_human.yaml, default/human_env.yaml).
     `collision_prevention` takes the keys of config/wrappers/collision_prevention/*.yaml (replace_type, n_resamples);
-    None = wrapper not in the stack.  `goal_check=False` takes the non-pinocchio branch of `_sample_valid_pos`."""
+    None = wrapper not in the stack.  `goal_check=False` takes the non-pinocchio branch of `_sample_valid_pos`.
+    `ik_position_delta` takes the keys of config/wrappers/ik_position_delta/*.yaml (action_limit, x_output_max,
+    x_position_limits, residual_threshold, max_iter): actions become [dx, dy, dz, gripper]; None = joint-space actions."""
     if env_id not in ENV_DEFAULTS:
         raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)}")
     kw = dict(ENV_DEFAULTS[env_id])
@@ -467,6 +474,25 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)
         d.n_targets = max(int(kw["horizon"] * kw["n_targets_sampled_per_100_steps"] / 100), 1)
         d.object_gripped_reward = float(kw["object_gripped_reward"])
+    # ---- Cartesian action front-end (wrappers/ik_position_delta_wrapper.py)
+    d.ik_enabled = int(ik_position_delta is not None)
+    ik = dict(IK_DEFAULTS)
+    unknown = set(ik_position_delta or {}) - set(ik) - {"urdf_file"}
+    if unknown:
+        raise ValueError(f"ik_position_delta: unknown keys {sorted(unknown)}")
+    ik.update({k: v for k, v in (ik_position_delta or {}).items() if k != "urdf_file"})
+    d.ik_max_iter = int(ik["max_iter"])
+    d.ik_action_limit = float(ik["action_limit"])
+    d.ik_x_output_max = float(ik["x_output_max"])
+    d.ik_residual_threshold = float(ik["residual_threshold"])
+    d.ik_damping = float(ik["damping"])
+    d.ik_use_pos_limits = int(ik["x_position_limits"] is not None)
+    if ik["x_position_limits"] is not None:
+        for a in range(3):
+            d.ik_pos_limits[0][a], d.ik_pos_limits[1][a] = float(ik["x_position_limits"][0][a]), float(ik["x_position_limits"][1][a])
+    d.ik_ee_offset[:] = IK_EE_OFFSET
+    R_init, _ = robot_fk_numpy(d, np.concatenate([np.asarray(d.init_qpos[:]), np.zeros(NV - NARM)]))
+    d.ik_target_rot[:] = R_init[NARM - 1].reshape(-1).tolist()      # orientation at init_qpos, ik_position_delta_wrapper.py:74-82
     d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
     return d
 

@@ -131,7 +131,7 @@ class HipVecEnv(_VecEnvBase):
     global env id, so sharding does not change results)."""
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
-                 device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True):
+                 device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
@@ -147,12 +147,19 @@ class HipVecEnv(_VecEnvBase):
         self.env_kwargs = kw
         self._clips = clips if clips is not None else synthetic_clips()
         # collision_prevention: dict(replace_type=0|1|2, n_resamples=20) = config/wrappers/collision_prevention/*.yaml
-        self._cp, self._goal_check = collision_prevention, goal_check
-        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id)
+        # ik_position_delta: dict(action_limit=0.15, x_output_max=1, ...) = config/wrappers/ik_position_delta/*.yaml: actions become
+        # [dx, dy, dz, gripper] (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py), converted in the kernel
+        self._cp, self._goal_check, self._ik = collision_prevention, goal_check, ik_position_delta
+        self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id,
+                                      ik_position_delta=ik_position_delta)
         self._device, self._env_id0 = device, env_id0
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
         obs_space = _Box(-np.inf, np.inf, shape=(len(self._cols),), dtype=np.float32)
-        act_space = _Box(-1.0, 1.0, shape=(CONST["HRG_ACT_DIM"],), dtype=np.float32)
+        if ik_position_delta is None:
+            act_space = _Box(-1.0, 1.0, shape=(CONST["HRG_ACT_DIM"],), dtype=np.float32)
+        else:  # ik_position_delta_wrapper.py:84-88: position delta limits + one gripper dof
+            lim = float(self._desc.ik_action_limit)
+            act_space = _Box(np.array([-lim] * 3 + [-1.0], np.float32), np.array([lim] * 3 + [1.0], np.float32), dtype=np.float32)
         super().__init__(n_envs, obs_space, act_space)
         self.info_dicts = info_dicts
         self._ep_ret = np.zeros(n_envs, np.float64)
@@ -168,6 +175,10 @@ class HipVecEnv(_VecEnvBase):
         return np.asarray(self._backend.reset())[:, self._cols]
 
     def step_async(self, actions):
+        if self._ik is not None:  # [dx, dy, dz, gripper] in the first four columns of the 7-wide action rows
+            a4 = np.asarray(actions, np.float64).reshape(self.num_envs, 4)
+            actions = np.zeros((self.num_envs, CONST["HRG_ACT_DIM"]))
+            actions[:, :4] = a4
         actions = np.asarray(actions, np.float64).reshape(self.num_envs, CONST["HRG_ACT_DIM"])
         self._actions = actions
         self._backend.step_async(actions)
@@ -178,7 +189,7 @@ class HipVecEnv(_VecEnvBase):
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
         self._ep_len += 1
-        if self._cp is not None and self.info_dicts:
+        if (self._cp is not None or self._ik is not None) and self.info_dicts:
             self._actions = np.array(self._backend.executed_actions(), copy=True)
         infos = self._make_infos(info, dones, term_obs) if self.info_dicts else [{} for _ in range(self.num_envs)]
         self._ep_ret[dones] = 0
@@ -208,7 +219,7 @@ class HipVecEnv(_VecEnvBase):
             return [None] * self.num_envs
         self.env_kwargs["seed"] = int(seed)
         self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check,
-                                      env_id=self.env_id)
+                                      env_id=self.env_id, ik_position_delta=self._ik)
         if isinstance(self._backend, _TorchBackend):
             self._backend.close()
             self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)

@@ -227,6 +227,19 @@ typedef struct hrg_model_desc {
   double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
   double object_gripped_reward;
   double finger_qpos_range[2][HRG_NFINGER]; /* RethinkValidGripper.qpos_range, rethink_valid_gripper.py:29-42 */
+  /* ---- Cartesian action front-end (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py:26-142;
+   *      config/wrappers/ik_position_delta/default_ik_position_delta.yaml).  When enabled an action row is
+   *      [dx, dy, dz, gripper, -, -, -] and is rewritten in place to the joint action it was converted to. ---- */
+  int32_t ik_enabled;
+  int32_t ik_max_iter;          /* max_iter (50) */
+  int32_t ik_use_pos_limits;    /* x_position_limits is not None */
+  double ik_action_limit;       /* action_limit (0.15): clip of the position delta */
+  double ik_x_output_max;       /* x_output_max (1) */
+  double ik_residual_threshold; /* residual_threshold (1e-3) */
+  double ik_damping;            /* lambda of the damped least squares step (pybullet [UPSTREAM]: stand-in 0.1) */
+  double ik_pos_limits[2][3];
+  double ik_ee_offset[3];       /* end-effector link origin in the link-6 frame: fixed_gripper_joint of robot_pybullet.urdf (0, 0, 0.17) */
+  double ik_target_rot[9];      /* end-effector orientation at init_qpos, held fixed (ik_position_delta_wrapper.py:74-82) */
   uint64_t seed;
 } hrg_model_desc;
 

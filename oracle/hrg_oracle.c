@@ -1175,6 +1175,76 @@ static int action_collides(const hrg_model_desc* m, const hrg_env_state* s, cons
   return config_collides(m, g);
 }
 
+/* IKPositionDeltaWrapper.step (wrappers/ik_position_delta_wrapper.py:93-142): position delta of the end-effector link with
+ * its orientation held at the initial one -> joint delta.  pybullet.calculateInverseKinematics is [UPSTREAM]; restated as the
+ * damped-least-squares iteration it documents (BussIK DLS): dq = J' (J J' + lambda^2 I)^-1 [e_pos; e_rot], at least one
+ * step, then until the position residual is below the threshold or max_iter steps are done; steps are scaled down to
+ * 45 deg per joint.  Kinematics = the stepper's own chain (same joint frames as robot_pybullet.urdf). */
+static void ik_fk(const hrg_model_desc* m, const double* q6, double ax[NARM][3], double org[NARM][3], double* R6, double* pee) {
+  double R[9], p[3], t[3];
+  quat2mat(R, m->base_quat);
+  v3cpy(p, m->base_pos);
+  for (int i = 0; i < NARM; i++) {
+    double Rq[9], Rl[9], Rj[9];
+    quat2mat(Rq, m->body_quat[i]);
+    m3mul(Rl, R, Rq);
+    m3mulv(t, R, m->body_pos[i]);
+    v3add(p, p, t);
+    axisangle2mat(Rj, m->jnt_axis[i], q6[i]);
+    m3mul(R, Rl, Rj);
+    m3mulv(ax[i], R, m->jnt_axis[i]);
+    v3cpy(org[i], p);
+  }
+  memcpy(R6, R, sizeof(double) * 9);
+  m3mulv(t, R, m->ik_ee_offset);
+  v3add(pee, p, t);
+}
+static void ik_action(const hrg_model_desc* m, const hrg_env_state* s, double* act) {
+  double ws[3], q[NARM], ax[NARM][3], org[NARM][3], R6[9], pee[3], target[3];
+  for (int a = 0; a < 3; a++) ws[a] = clampd(act[a], -m->ik_action_limit, m->ik_action_limit) * m->ik_x_output_max;
+  const double grip = clampd(act[3], -1.0, 1.0);
+  for (int j = 0; j < NARM; j++) q[j] = s->qpos[j];
+  ik_fk(m, q, ax, org, R6, pee);
+  for (int a = 0; a < 3; a++) {
+    target[a] = pee[a] + ws[a];
+    if (m->ik_use_pos_limits) target[a] = clampd(target[a], m->ik_pos_limits[0][a], m->ik_pos_limits[1][a]);
+  }
+  for (int it = 0;; it++) {
+    if (it > 0) ik_fk(m, q, ax, org, R6, pee);
+    double e[6], d[3];
+    v3sub(d, target, pee);
+    if (it > 0 && v3norm(d) <= m->ik_residual_threshold) break;
+    if (it >= m->ik_max_iter) break;
+    /* orientation error: rotation vector of R_target R6' */
+    double E[9], v[3];
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) E[3 * a + b] = m->ik_target_rot[3 * a] * R6[3 * b] + m->ik_target_rot[3 * a + 1] * R6[3 * b + 1] + m->ik_target_rot[3 * a + 2] * R6[3 * b + 2];
+    v3set(v, 0.5 * (E[7] - E[5]), 0.5 * (E[2] - E[6]), 0.5 * (E[3] - E[1]));
+    double sn = v3norm(v), cs = 0.5 * (E[0] + E[4] + E[8] - 1.0), ang = atan2(sn, cs);
+    for (int a = 0; a < 3; a++) { e[a] = d[a]; e[3 + a] = sn > 1e-12 ? v[a] / sn * ang : 0.0; }
+    double J[6][NARM], A[36], y[6];
+    for (int j = 0; j < NARM; j++) {
+      double r[3], c[3];
+      v3sub(r, pee, org[j]);
+      v3cross(c, ax[j], r);
+      for (int a = 0; a < 3; a++) { J[a][j] = c[a]; J[3 + a][j] = ax[j][a]; }
+    }
+    for (int a = 0; a < 6; a++) for (int b = 0; b < 6; b++) {
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += J[a][j] * J[b][j];
+      A[6 * a + b] = t + (a == b ? m->ik_damping * m->ik_damping : 0.0);
+    }
+    memcpy(y, e, sizeof y);
+    if (!chol(A, 6)) break;
+    chol_solve(A, 6, y);
+    double dq[NARM], mx = 0;
+    for (int j = 0; j < NARM; j++) { double t = 0; for (int a = 0; a < 6; a++) t += J[a][j] * y[a]; dq[j] = t; if (fabs(t) > mx) mx = fabs(t); }
+    const double sc = mx > 0.25 * PI ? 0.25 * PI / mx : 1.0;
+    for (int j = 0; j < NARM; j++) q[j] += sc * dq[j];
+  }
+  for (int j = 0; j < NARM; j++) act[j] = q[j] - s->qpos[j];
+  act[NARM] = grip;
+}
+
 /* CollisionPreventionWrapper.action (wrappers/collision_prevention_wrapper.py:46-103) */
 static void screen_action(const hrgo_batch* B, int64_t gid, hrg_env_state* s, double* act) {
   const hrg_model_desc* m = &B->m;
@@ -1249,6 +1319,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   hrg_env_state* s = &B->st[e];
   int64_t gid = B->env_id0 + e;
   const double h = m->timestep;
+  if (m->ik_enabled) ik_action(m, s, action); /* IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373) */
   screen_action(B, gid, s, action); /* CollisionPreventionWrapper.step wraps env.step: uses the pre-step state */
   s->timestep += 1; /* human_env.py:490 */
   int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
@@ -1688,4 +1759,14 @@ void hrgo_test_segbox(const double* p1, const double* p2, const double* c, const
   double R[9], t;
   quat2mat(R, quat);
   out[0] = seg_box(p1, p2, c, R, hb, &t, out + 1, out + 4);
+}
+void hrgo_test_ik(const hrg_model_desc* m, const double* q6, double* act7) {
+  hrg_env_state s;
+  memset(&s, 0, sizeof s);
+  for (int j = 0; j < NARM; j++) s.qpos[j] = q6[j];
+  ik_action(m, &s, act7);
+}
+void hrgo_test_ik_fk(const hrg_model_desc* m, const double* q6, double* pee3, double* R9) {
+  double ax[NARM][3], org[NARM][3];
+  ik_fk(m, q6, ax, org, R9, pee3);
 }

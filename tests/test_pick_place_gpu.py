@@ -123,3 +123,32 @@ def test_full_size_properties():
         G.close()
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, b)
+
+
+def test_cartesian_action_front_end_parity():
+    """IKPositionDeltaWrapper in the kernel: [dx, dy, dz, gripper] rows are converted by the damped-least-squares IK, screened
+    by the collision prevention, executed; the executed joint actions written back must agree with the oracle's."""
+    import torch
+    kw = dict(shield_type="SSM", horizon=40, seed=8)
+    ik = dict(action_limit=0.15)
+    O, G = make_pair(12, kw, **PP, ik_position_delta=ik, collision_prevention=dict(replace_type=0, n_resamples=20))
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    rng = np.random.RandomState(4)
+    moved = 0.0
+    for k in range(30):
+        a = np.zeros((12, 7))
+        a[:, :3] = rng.uniform(-0.2, 0.2, (12, 3))
+        a[:, 3] = rng.uniform(-1.5, 1.5, 12)
+        ag = torch.from_numpy(a.copy()).cuda()
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(ag)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ag.cpu().numpy(), O.last_actions, rtol=1e-6, atol=1e-9, err_msg=f"executed joint actions, step {k}")
+        moved = max(moved, float(np.abs(O.last_actions[:, :6]).max()))
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=1e-6, err_msg=f"step {k}")
+        for e in range(12):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+    assert moved > 0.05
+    O.close(); G.close()
