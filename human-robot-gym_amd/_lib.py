@@ -17,7 +17,7 @@ SRC_BOX = os.path.join(_HERE, "csrc", "hrgym_box.hip")   # the same sources comp
 EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
-    "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box",
+    "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box", "hrg_batch_get_states", "hrg_batch_set_states",
 ]
 
 
@@ -59,6 +59,8 @@ def load_library():
     lib.hrg_batch_capsules.argtypes = [vp, vp, vp, vp]
     lib.hrg_batch_get_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_batch_get_states.argtypes = [vp, vp, i32, vp, vp]
+    lib.hrg_batch_set_states.argtypes = [vp, vp, i32, vp, vp]
     lib.hrg_box_bytes.restype = ctypes.c_size_t
     lib.hrg_batch_get_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
@@ -151,6 +153,22 @@ class HipBatch:
 
     def set_state(self, e, s):
         _check(self.lib, self.lib.hrg_batch_set_state(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
+
+    def get_states(self, envs):
+        """Environment states (+ manipulation objects) of several envs in one call: (EnvState[n], BoxState[n])."""
+        import numpy as np
+        idx = np.ascontiguousarray(envs, np.int32)
+        st, bx = (EnvState * len(idx))(), (BoxState * len(idx))()
+        _check(self.lib, self.lib.hrg_batch_get_states(self.h, idx.ctypes.data_as(ctypes.c_void_p), len(idx), ctypes.byref(st), ctypes.byref(bx)))
+        return st, bx
+
+    def set_states(self, envs, states, boxes=None):
+        """Reference-state initialisation: overwrite the listed envs' states (wrappers/dataset_wrapper.py:88-160)."""
+        import numpy as np
+        idx = np.ascontiguousarray(envs, np.int32)
+        assert len(states) == len(idx) and (boxes is None or len(boxes) == len(idx))
+        _check(self.lib, self.lib.hrg_batch_set_states(self.h, idx.ctypes.data_as(ctypes.c_void_p), len(idx), ctypes.byref(states),
+                                                       ctypes.byref(boxes) if boxes is not None else None))
 
     def get_box(self, e):
         """The manipulation object of env e (PickPlaceHumanCart; zeros for ReachHuman)."""

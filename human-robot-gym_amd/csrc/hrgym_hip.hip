@@ -667,6 +667,8 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
     else if (lane < 30) v = s.qvel[lane - 24];      // robot0_joint_vel
     else if (lane < 33) v = s.eef_pos[lane - 30];   // robot0_eef_pos
     else if (lane < 39) v = goal[lane - 33];        // desired_goal
+    else if (lane >= 53 && lane < 55) v = s.qpos[NARM + lane - 53];  // robot0_gripper_qpos
+    else if (lane >= 55) v = s.qvel[NARM + lane - 55];               // robot0_gripper_qvel
     else v = 0.0;                                   // PickPlaceHumanCart columns
 #if HRG_BOX
     // PickPlaceHumanCart._setup_observables (pick_place_human_cartesian_env.py:726-841), gripper_aperture (human_env.py:1508-1524)
@@ -719,6 +721,7 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   for (int k = lane; k < (int)(sizeof(hrg_env_state) / sizeof(double)); k += 64) ((double*)&s)[k] = 0.0;
   wave_sync();
   s.episode = episode;
+  s.stream_id = (int32_t)gid;
   if (lane < NARM) s.qpos[lane] = m.init_qpos[lane] + m.init_noise * rng_gauss(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)lane);
   else if (lane < NV) s.qpos[lane] = m.finger_init_qpos[lane - NARM];
   const double ux = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 0), uy = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 1),
@@ -836,12 +839,13 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
-DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, double* __restrict__ action, float* obs, float* term_obs,
+DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_gid, double* __restrict__ action, float* obs, float* term_obs,
                  float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
+  const int64_t gid = s.stream_id;  // in-episode draws follow the state's streams (= own_gid unless the state was copied in)
   int has_collision = 0, collision_type = HRG_COL_NULL, crash = 0;
   STAMP_INIT(lane);
   if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
@@ -932,7 +936,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid,
   }
 #endif
   STAMP(8);
-  if (d) env_reset(dm_, lane, gid, obs);
+  if (d) env_reset(dm_, lane, own_gid, obs);
 #if !HRG_BOX
   else write_obs(dm_, lane, goal, obs);
 #endif
@@ -1266,6 +1270,32 @@ int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t by
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_box_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(b->d_boxes + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
+int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void* states_host, void* boxes_host) {
+  if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  for (int32_t k = 0; k < n; k++) {
+    const int32_t e = envs_host[k];
+    if (e < 0 || e >= b->n_envs) return fail(HRG_ERR_INVALID, "bad env index");
+    HIPCHK(hipMemcpyAsync((hrg_env_state*)states_host + k, b->d_states + e, sizeof(hrg_env_state), hipMemcpyDeviceToHost, 0));
+    if (boxes_host) HIPCHK(hipMemcpyAsync((hrg_box_state*)boxes_host + k, b->d_boxes + e, sizeof(hrg_box_state), hipMemcpyDeviceToHost, 0));
+  }
+  HIPCHK(hipDeviceSynchronize());
+  return HRG_OK;
+}
+
+int hrg_batch_set_states(hrg_batch* b, const int32_t* envs_host, int32_t n, const void* states_host, const void* boxes_host) {
+  if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipDeviceSynchronize());
+  for (int32_t k = 0; k < n; k++) {
+    const int32_t e = envs_host[k];
+    if (e < 0 || e >= b->n_envs) return fail(HRG_ERR_INVALID, "bad env index");
+    HIPCHK(hipMemcpyAsync(b->d_states + e, (const hrg_env_state*)states_host + k, sizeof(hrg_env_state), hipMemcpyHostToDevice, 0));
+    if (boxes_host) HIPCHK(hipMemcpyAsync(b->d_boxes + e, (const hrg_box_state*)boxes_host + k, sizeof(hrg_box_state), hipMemcpyHostToDevice, 0));
+  }
+  HIPCHK(hipDeviceSynchronize());
   return HRG_OK;
 }
 

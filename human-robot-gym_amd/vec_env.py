@@ -76,6 +76,7 @@ OBS_COLUMNS = {
     # PickPlaceHumanCart (pick_place_human_cartesian_env.py:726-841); zero columns for ReachHuman
     "object_gripped": range(39, 40), "vec_eef_to_object": range(40, 43), "vec_eef_to_target": range(43, 46),
     "gripper_aperture": range(46, 47), "object_pos": range(47, 50), "target_pos": range(50, 53),
+    "robot0_gripper_qpos": range(53, 55), "robot0_gripper_qvel": range(55, 57),
 }
 
 
@@ -131,7 +132,8 @@ class HipVecEnv(_VecEnvBase):
     global env id, so sharding does not change results)."""
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
-                 device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None):
+                 device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
+                 expert_obs_keys=None):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
@@ -140,6 +142,12 @@ class HipVecEnv(_VecEnvBase):
         if unknown:
             raise NotImplementedError(f"obs_keys {unknown!r}: available {sorted(OBS_COLUMNS)}")
         self.obs_keys = keys
+        # ExpertObsWrapper (wrappers/expert_obs_wrapper.py:155-184): infos carry the expert's view of the state before and after the step
+        bad = [k for k in (expert_obs_keys or []) if k not in OBS_COLUMNS]
+        if bad:
+            raise NotImplementedError(f"expert_obs_keys {bad!r}: available {sorted(OBS_COLUMNS)}")
+        self.expert_obs_keys = list(expert_obs_keys) if expert_obs_keys is not None else None
+        self._expert_cur = None
         self._cols = np.array([c for k in keys for c in OBS_COLUMNS[k]], dtype=np.int64)  # GymWrapper: concatenate in key order
         kw = dict(env_kwargs or {})
         if seed is not None:
@@ -172,7 +180,10 @@ class HipVecEnv(_VecEnvBase):
     def reset(self):
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
-        return np.asarray(self._backend.reset())[:, self._cols]
+        full = np.asarray(self._backend.reset())
+        if self.expert_obs_keys is not None:
+            self._expert_cur = np.array(full, copy=True)
+        return full[:, self._cols]
 
     def step_async(self, actions):
         if self._ik is not None:  # [dx, dy, dz, gripper] in the first four columns of the 7-wide action rows
@@ -185,13 +196,16 @@ class HipVecEnv(_VecEnvBase):
 
     def step_wait(self):
         obs, term_obs, reward, done, info = self._backend.step_wait()
-        obs, reward = np.asarray(obs)[:, self._cols], np.array(reward, copy=True)
+        full = np.asarray(obs)
+        obs, reward = full[:, self._cols], np.array(reward, copy=True)
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
         self._ep_len += 1
         if (self._cp is not None or self._ik is not None) and self.info_dicts:
             self._actions = np.array(self._backend.executed_actions(), copy=True)
         infos = self._make_infos(info, dones, term_obs) if self.info_dicts else [{} for _ in range(self.num_envs)]
+        if self.expert_obs_keys is not None:
+            self._expert_cur = np.array(full, copy=True)   # after an auto-reset: the new episode's first observation (wrapper reset())
         self._ep_ret[dones] = 0
         self._ep_len[dones] = 0
         return obs, reward, dones, infos
@@ -202,6 +216,10 @@ class HipVecEnv(_VecEnvBase):
         for i in range(self.num_envs):
             d = {k: (bool(info[i, j]) if k in _BOOL_KEYS else int(info[i, j])) for j, k in enumerate(INFO_KEYS)}
             d["action"] = self._actions[i]  # collision_prevention_wrapper.py:42-43: the executed action
+            if self.expert_obs_keys is not None:  # expert_obs_wrapper.py:171-175 (the step's own observation: pre-reset where done)
+                prev, cur = self._expert_cur[i], np.asarray(term_obs[i])
+                d["previous_expert_observation"] = {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in self.expert_obs_keys}
+                d["current_expert_observation"] = {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in self.expert_obs_keys}
             if dones[i]:
                 d["terminal_observation"] = np.asarray(term_obs[i])[self._cols]
                 d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}

@@ -57,12 +57,14 @@ extern "C" {
 #define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
 #define HRG_NHCAP_MAX 64  /* human reach capsules over all three models (fits one wavefront) */
 #define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
-#define HRG_OBS_DIM 53    /* superset of the flat observation; the host selects columns by obs_keys:
+#define HRG_OBS_DIM 57    /* superset of the flat observation; the host selects columns by obs_keys:
                           *  [0:12] object-state  [12:18] goal_difference  [18:24] robot0_joint_pos  [24:30] robot0_joint_vel
                           *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666)
                           *  PickPlaceHumanCart (pick_place_human_cartesian_env.py:726-841; zero for ReachHuman):
                           *  [39] object_gripped  [40:43] vec_eef_to_object  [43:46] vec_eef_to_target  [46] gripper_aperture
-                          *  [47:50] object_pos  [50:53] target_pos */
+                          *  [47:50] object_pos  [50:53] target_pos
+                          *  both tasks: [53:55] robot0_gripper_qpos  [55:57] robot0_gripper_qvel (the scripted experts' inputs,
+                          *  demonstrations/experts/pick_place_human_cart_expert.py:24-41) */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
 #define HRG_INFO_DIM 13
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */
@@ -300,6 +302,10 @@ int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes)
 int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 /* the manipulation object's part of the environment state (hrg_box_state, include/hrgym_state.h):
  * PickPlaceHumanCart.get/set_environment_state, pick_place_human_cartesian_env.py:946-975; zeros for ReachHuman */
+/* batched form for reference-state initialisation (wrappers/dataset_wrapper.py:88-160 resets envs to dataset states):
+ * states_host = n x hrg_env_state, boxes_host = n x hrg_box_state or NULL, for the envs listed in envs_host */
+int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void* states_host, void* boxes_host);
+int hrg_batch_set_states(hrg_batch* b, const int32_t* envs_host, int32_t n, const void* states_host, const void* boxes_host);
 size_t hrg_box_bytes(void);
 int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);

@@ -74,6 +74,8 @@ typedef struct hrg_env_state {
   int32_t prev_pairs[HRG_NPREV_MAX];
   int32_t ncon;                      /* contacts of the last substep (parity hook) */
   int32_t con_pairs[HRG_NCON_MAX][2];
+  int32_t stream_id;                 /* key of the episode's random streams (with `episode`): the env's global id at reset; travels
+                                      * with a copied state so that a restored episode keeps its animation / goal / placement sequence */
 } hrg_env_state;
 
 /* The manipulation object of the tasks that have one (PickPlaceHumanCart).  Kept out of hrg_env_state so that ReachHuman

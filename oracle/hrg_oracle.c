@@ -1083,6 +1083,7 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const h
   for (int j = 0; j < NARM; j++) { obs[18 + j] = (float)s->qpos[j]; obs[24 + j] = (float)s->qvel[j]; obs[33 + j] = (float)goal[j]; }
   for (int a = 0; a < 3; a++) obs[30 + a] = (float)s->eef_pos[a];
   for (int c = 39; c < HRG_OBS_DIM; c++) obs[c] = 0.0f;
+  for (int f = 0; f < HRG_NFINGER; f++) { obs[53 + f] = (float)s->qpos[NARM + f]; obs[55 + f] = (float)s->qvel[NARM + f]; }
   if (bx) { /* PickPlaceHumanCart._setup_observables, pick_place_human_cartesian_env.py:726-841; gripper_aperture human_env.py:1508-1524 */
     for (int j = 0; j < NARM; j++) { obs[12 + j] = 0.0f; obs[33 + j] = 0.0f; }
     obs[39] = (float)bx->gripped;
@@ -1279,6 +1280,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   int episode = s->episode + 1;
   memset(s, 0, sizeof *s);
   s->episode = episode;
+  s->stream_id = (int32_t)gid;
   /* robot.reset: init_qpos + N(0, 0.02^2) (robosuite "default" initialization_noise) */
   for (int j = 0; j < NARM; j++) s->qpos[j] = m->init_qpos[j] + m->init_noise * rng_gauss(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)j);
   for (int j = 0; j < HRG_NFINGER; j++) s->qpos[NARM + j] = m->finger_init_qpos[j];
@@ -1317,7 +1319,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
 static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
   const hrg_model_desc* m = &B->m;
   hrg_env_state* s = &B->st[e];
-  int64_t gid = B->env_id0 + e;
+  int64_t gid = s->stream_id; /* in-episode draws follow the state's streams (= the env's own id unless the state was copied in) */
   const double h = m->timestep;
   if (m->ik_enabled) ik_action(m, s, action); /* IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373) */
   screen_action(B, gid, s, action); /* CollisionPreventionWrapper.step wraps env.step: uses the pre-step state */

@@ -152,3 +152,35 @@ def test_long_run_is_deterministic_and_finite():
         outs.append((acc.cpu(), crashes))
         G.close()
     assert torch.equal(outs[0][0], outs[1][0]) and outs[0][1] == outs[1][1]
+
+
+def test_batched_state_io_reference_state_initialisation():
+    """hrg_batch_get_states / set_states: copying the states of one batch into (permuted) envs of another makes those envs
+    continue identically — the batched form of get/set_environment_state used for reference-state initialisation."""
+    import torch
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd._lib import HipBatch
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+    kw = dict(shield_type="SSM", horizon=50, seed=3)
+    A = HipBatch(hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id="PickPlaceHumanCart"), clips, 8)
+    B = HipBatch(hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id="PickPlaceHumanCart"), clips, 8, env_id0=100)
+    A.reset(); B.reset()
+    g = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        A.step((torch.rand((8, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda())
+    perm = np.array([3, 1, 7, 5], np.int32)
+    st, bx = A.get_states([0, 1, 2, 3])
+    B.set_states(perm, st, bx)
+    st2, bx2 = B.get_states(perm)
+    assert bytes(st2) == bytes(st) and bytes(bx2) == bytes(bx)
+    a = (torch.rand((8, 7), generator=g, dtype=torch.float64) * 2 - 1)
+    aB = a.clone()
+    aB[torch.from_numpy(perm.astype(np.int64))] = a[:4]
+    oA, rA, dA, iA = (x.cpu().numpy().copy() for x in A.step(a.cuda()))
+    oB, rB, dB, iB = (x.cpu().numpy().copy() for x in B.step(aB.cuda()))
+    # human placement / animation are part of the state block; per-env random streams (resets, resampling) are keyed by the env id
+    # and not exercised within this step
+    np.testing.assert_array_equal(oB[perm], oA[:4])
+    np.testing.assert_array_equal(rB[perm], rA[:4])
+    np.testing.assert_array_equal(iB[perm], iA[:4])
+    A.close(); B.close()

@@ -115,3 +115,33 @@ def test_obs_keys_select_and_order_columns_like_the_gym_wrapper():
     np.testing.assert_allclose(np.linalg.norm(of[:, 0:3], axis=1), of[:, 3], rtol=1e-6)
     for e in (full, icra, mixed):
         e.close()
+
+
+def test_expert_observation_side_channel():
+    """ExpertObsWrapper (wrappers/expert_obs_wrapper.py:155-184): infos carry previous / current expert observations as dicts;
+    after an auto-reset the next step's "previous" is the new episode's first observation."""
+    from human_robot_gym_amd.env_util import make_vec_env
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    kw = dict(shield_type="OFF", horizon=3, seed=4)
+    keys = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "robot0_gripper_qpos"]   # PickPlaceHumanCartExpertObservation
+    desc = hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id="PickPlaceHumanCart")
+    back = OracleBackend(desc, clips, 2)
+    env = make_vec_env("PickPlaceHumanCart", type="env", expert_obs_keys=keys, n_envs=2, env_kwargs=kw, vec_env_kwargs=dict(clips=clips, backend=back))
+    env.reset()
+    first = back.B.obs.copy()
+    last_cur = None
+    for k in range(4):
+        obs, rew, done, infos = env.step(np.zeros((2, 7)))
+        prev, cur = infos[0]["previous_expert_observation"], infos[0]["current_expert_observation"]
+        assert set(prev) == set(keys) and prev["vec_eef_to_object"].shape == (3,) and cur["robot0_gripper_qpos"].shape == (2,)
+        if k == 0:
+            np.testing.assert_array_equal(prev["robot0_gripper_qpos"], first[0, 53:55])
+        elif k < 3:
+            np.testing.assert_array_equal(prev["vec_eef_to_object"], last_cur["vec_eef_to_object"])
+        if k == 2:
+            assert done.all()
+            np.testing.assert_array_equal(cur["vec_eef_to_target"], back.B.term_obs[0, 43:46])   # terminal step's own observation
+            after_reset = back.B.obs.copy()
+        if k == 3:
+            np.testing.assert_array_equal(prev["vec_eef_to_object"], after_reset[0, 40:43])
+        last_cur = cur
