@@ -76,15 +76,17 @@
 // ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
 #ifdef HRG_STAMPS
 static __device__ unsigned long long g_stamps[32];
+static __device__ unsigned long long g_envcyc[16384][3];   // per env: start, end timestamp of its last step
+__shared__ unsigned long long g_tbeg;
 __shared__ unsigned long long g_acc[32];   // per-wave accumulators (diagnostic build only: costs one workgroup of occupancy)
 __shared__ unsigned long long g_t0;
 #define STAMP_NOW(var) do { __builtin_amdgcn_sched_barrier(0); asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var) :: "memory"); __builtin_amdgcn_sched_barrier(0); } while (0)
 #define STAMP_DECL
-#define STAMP_INIT(lane) do { if ((lane) < 32) g_acc[lane] = 0; unsigned long long _t; STAMP_NOW(_t); g_t0 = _t; __syncthreads(); } while (0)
+#define STAMP_INIT(lane) do { if ((lane) < 32) g_acc[lane] = 0; unsigned long long _t; STAMP_NOW(_t); g_t0 = _t; g_tbeg = _t; __syncthreads(); } while (0)
 #define STAMP(k) do { unsigned long long _t; STAMP_NOW(_t); if (threadIdx.x == 0) { g_acc[k] += _t - g_t0; g_t0 = _t; } } while (0)
 #define STAMP_FLUSH(lane)
 #define COUNT(k, n) do { if (threadIdx.x == 0) g_acc[k] += (n); } while (0)
-#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); } while (0)
+#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); if ((lane) == 0 && blockIdx.x < 16384) { unsigned long long _t; STAMP_NOW(_t); g_envcyc[blockIdx.x][0] = g_tbeg; g_envcyc[blockIdx.x][1] = _t; unsigned _hw, _xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); g_envcyc[blockIdx.x][2] = ((unsigned long long)_xcc << 32) | _hw; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_INIT(lane)

@@ -1039,6 +1039,9 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
   if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
   return 0;
 }
+#if !HRG_BOX
+extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envcyc), sizeof(unsigned long long) * 3 * n) == hipSuccess ? 0 : -1; }
+#endif
 #endif
 
 #if !HRG_BOX

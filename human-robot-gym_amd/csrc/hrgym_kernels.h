@@ -10,37 +10,42 @@
 DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_on) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
-  if (lane < 3 && (lane == 2 || shield_on)) {
+  // lanes = (configuration, row): row r of a product R A is (row r of R) A and component r of R v is (row r of R) . v, so a
+  // lane that carries one row of the running rotation and one component of the running position needs nothing from the
+  // other rows; 9 lanes walk the chain with a third of the serial work and no hand-offs
+  if (lane < 9 && (lane >= 6 || shield_on)) {
     const auto& m = dm->m;
-    const int cfg = lane;
-    double R[9], p[3];
-#pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = dm->Rbase[k];
-    v3cpy(p, m.base_pos);
+    const int cfg = lane / 3, row = lane - 3 * cfg;
+    double r0 = dm->Rbase[3 * row], r1 = dm->Rbase[3 * row + 1], r2 = dm->Rbase[3 * row + 2];
+    double p = m.base_pos[row];
 #pragma unroll 1
     for (int i = 0; i < NARM; i++) {
-      double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
-      double Rj[9], t[3], sn, cs;
-      m3mulv(t, R, m.body_pos[i]);
-      v3add(p, p, t);
+      const double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
+      double sn, cs;
+      p += r0 * m.body_pos[i][0] + r1 * m.body_pos[i][1] + r2 * m.body_pos[i][2];
       // arm hinges turn about the local z axis (robot.xml:33-58, checked at create): Rq Rz(q) mixes the first two columns
       sincos_small(q, &sn, &cs);
+      double n0 = 0, n1 = 0, n2 = 0;
+      {
+        const double ra[3] = {r0, r1, r2};
 #pragma unroll
-      for (int a = 0; a < 3; a++) {
-        const double c0 = dm->Rq[i][3 * a], c1 = dm->Rq[i][3 * a + 1];
-        Rj[3 * a] = cs * c0 + sn * c1; Rj[3 * a + 1] = cs * c1 - sn * c0; Rj[3 * a + 2] = dm->Rq[i][3 * a + 2];
+        for (int a = 0; a < 3; a++) {
+          const double c0 = dm->Rq[i][3 * a], c1 = dm->Rq[i][3 * a + 1], c2 = dm->Rq[i][3 * a + 2];
+          n0 += ra[a] * (cs * c0 + sn * c1);
+          n1 += ra[a] * (cs * c1 - sn * c0);
+          n2 += ra[a] * c2;
+        }
       }
-      m3mul(R, R, Rj);
+      r0 = n0; r1 = n1; r2 = n2;
       if (cfg == 2) {
-#pragma unroll
-        for (int k = 0; k < 9; k++) L.kR[i][k] = R[k];
-        v3cpy(L.kp[i], p);
+        L.kR[i][3 * row] = r0; L.kR[i][3 * row + 1] = r1; L.kR[i][3 * row + 2] = r2;
+        L.kp[i][row] = p;
       } else {
-        m3mulv(t, R, m.scap_p1[i]); v3add(&L.scap[cfg][i][0], p, t);
-        m3mulv(t, R, m.scap_p2[i]); v3add(&L.scap[cfg][i][3], p, t);
+        L.scap[cfg][i][row] = p + (r0 * m.scap_p1[i][0] + r1 * m.scap_p1[i][1] + r2 * m.scap_p1[i][2]);
+        L.scap[cfg][i][3 + row] = p + (r0 * m.scap_p2[i][0] + r1 * m.scap_p2[i][1] + r2 * m.scap_p2[i][2]);
         if (i == NARM - 1) {
-          m3mulv(t, R, m.scap_p1[NARM]); v3add(&L.scap[cfg][NARM][0], p, t);
-          m3mulv(t, R, m.scap_p2[NARM]); v3add(&L.scap[cfg][NARM][3], p, t);
+          L.scap[cfg][NARM][row] = p + (r0 * m.scap_p1[NARM][0] + r1 * m.scap_p1[NARM][1] + r2 * m.scap_p1[NARM][2]);
+          L.scap[cfg][NARM][3 + row] = p + (r0 * m.scap_p2[NARM][0] + r1 * m.scap_p2[NARM][1] + r2 * m.scap_p2[NARM][2]);
         }
       }
     }
@@ -48,15 +53,19 @@ DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_o
 #pragma unroll 1
       for (int f = 0; f < HRG_NFINGER; f++) {
         const int i = NARM + f;
-        double Rl[9], t[3], pf[3], axw[3];
-        m3mul(Rl, R, dm->Rq[i]);
-        m3mulv(t, R, m.body_pos[i]);
-        v3add(pf, p, t);
-        m3mulv(axw, Rl, m.jnt_axis[i]);
-        v3madd(pf, pf, axw, L.st.qpos[i]);
+        double l[3] = {0, 0, 0};
+        {
+          const double ra[3] = {r0, r1, r2};
 #pragma unroll
-        for (int k = 0; k < 9; k++) L.kR[i][k] = Rl[k];
-        v3cpy(L.kp[i], pf);
+          for (int a = 0; a < 3; a++)
+#pragma unroll
+            for (int b = 0; b < 3; b++) l[b] += ra[a] * dm->Rq[i][3 * a + b];
+        }
+        double pf = p + (r0 * m.body_pos[i][0] + r1 * m.body_pos[i][1] + r2 * m.body_pos[i][2]);
+        const double axw = l[0] * m.jnt_axis[i][0] + l[1] * m.jnt_axis[i][1] + l[2] * m.jnt_axis[i][2];
+        pf += axw * L.st.qpos[i];
+        L.kR[i][3 * row] = l[0]; L.kR[i][3 * row + 1] = l[1]; L.kR[i][3 * row + 2] = l[2];
+        L.kp[i][row] = pf;
       }
     }
   }
