@@ -103,6 +103,8 @@ struct DevModel {
   double Rq[NV][9];          // body_quat as matrices
   int32_t anc_mask[NV];      // bit i set: body i is an ancestor-or-self of body j
   int32_t hb_maxdepth;
+  int32_t hb_njump;                      // rounds of pointer jumping that cover the deepest path
+  int32_t hb_jump[4][HRG_NHB];           // ancestor 2^s levels up (-1: beyond the root)
   int32_t phase_mask;        // timing experiments (HRG_PHASE_MASK); 0xff = everything on
   hrg_path brake_full;       // fail-safe profile from the steady state (s'=1, s''=0): constant per model
   double brake_T, brake_ds;

@@ -1124,6 +1124,12 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   int maxd = 0;
   for (int i = 0; i < HRG_NHB; i++) maxd = desc->hb_depth[i] > maxd ? desc->hb_depth[i] : maxd;
   hm->hb_maxdepth = maxd;
+  if (maxd + 1 > 16) { delete hm; delete b; return fail(HRG_ERR_INVALID, "human tree deeper than 15"); }
+  for (int i = 0; i < HRG_NHB; i++) hm->hb_jump[0][i] = desc->hb_parent[i];
+  for (int s = 1; s < 4; s++)
+    for (int i = 0; i < HRG_NHB; i++) { const int a = hm->hb_jump[s - 1][i]; hm->hb_jump[s][i] = a < 0 ? -1 : hm->hb_jump[s - 1][a]; }
+  hm->hb_njump = 0;
+  while ((1 << hm->hb_njump) < maxd + 1) hm->hb_njump++;
   int n = 0;
   for (int k = 0; k < desc->n_bodypart; k++, n++) { hm->hc_kind[n] = 0; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_a[n] = desc->bp_amax[k]; hm->hc_v[n] = desc->bp_vmax[k]; }
   for (int k = 0; k < desc->n_bodypart; k++, n++) { hm->hc_kind[n] = 1; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_v[n] = desc->bp_vmax[k]; }

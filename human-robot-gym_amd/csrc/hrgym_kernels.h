@@ -200,38 +200,40 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
   Lds& L = g_L;
   const auto& m = dm->m;
   const int b = lane < HRG_NHB ? lane : 0;
-  double R[9], p[3], Rloc[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, anchor[3];
-  v3cpy(anchor, m.hb_anchor[b]);
-  quat2mat(R, mocap_quat);
-  v3cpy(p, mocap_pos);
-  if (lane >= 1 && lane < HRG_NHB) {
-    double qz = 0, qy = 0, qx = 0;
+  // Every body starts with its transform relative to its parent: a rotation Rz Ry Rx about the joint anchor,
+  // (Rloc, anchor - Rloc anchor); the pelvis starts with the mocap pose.  Pointer jumping then composes each body with the
+  // partial product of its 1st, 2nd, 4th, 8th ancestor: log2(depth) rounds of one 12-double shuffle and one rigid compose
+  // instead of one round per tree level.
+  double R[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, p[3] = {0, 0, 0};
+  if (lane == 0) { quat2mat(R, mocap_quat); v3cpy(p, mocap_pos); }
+  else if (lane < HRG_NHB) {
+    double qz = 0, qy = 0, qx = 0, anchor[3], t[3];
+    v3cpy(anchor, m.hb_anchor[b]);
     if (qh) { qz = qh[3 * (b - 1)]; qy = qh[3 * (b - 1) + 1]; qx = qh[3 * (b - 1) + 2]; }
     const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
     double Rz[9], Ry[9], Rx[9];
     axisangle2mat(Rz, ez, qz);
     axisangle2mat(Ry, ey, qy);
     axisangle2mat(Rx, ex, qx);
-    // R_b = ((R_par Rz) Ry) Rx ; keep the oracle's association by deferring the parent factor
-    m3mul(Rloc, Rz, Ry);
-    m3mul(Rloc, Rloc, Rx);
+    m3mul(R, Rz, Ry);
+    m3mul(R, R, Rx);
+    m3mulv(t, R, anchor);
+    v3sub(p, anchor, t);
   }
-  const int par = lane >= 1 && lane < HRG_NHB ? m.hb_parent[b] : 0;
-  const int depth = lane < HRG_NHB ? m.hb_depth[b] : -1;
 #pragma unroll 1
-  for (int level = 1; level <= dm->hb_maxdepth; level++) {
-    double Rp[9], pp[3];
+  for (int s = 0; s < dm->hb_njump; s++) {
+    const int a = lane < HRG_NHB ? dm->hb_jump[s][b] : -1;
+    const int src = a < 0 ? 0 : a;
+    double Ra[9], pa[3];
 #pragma unroll
-    for (int k = 0; k < 9; k++) Rp[k] = __shfl(R[k], par, 64);
+    for (int k = 0; k < 9; k++) Ra[k] = __shfl(R[k], src, 64);
 #pragma unroll
-    for (int k = 0; k < 3; k++) pp[k] = __shfl(p[k], par, 64);
-    if (depth == level) {
-      double t[3], anc[3];
-      m3mul(R, Rp, Rloc);
-      m3mulv(t, Rp, anchor);
-      v3add(anc, pp, t);
-      m3mulv(t, R, anchor);
-      v3sub(p, anc, t);
+    for (int k = 0; k < 3; k++) pa[k] = __shfl(p[k], src, 64);
+    if (a >= 0) {
+      double t[3];
+      m3mulv(t, Ra, p);
+      v3add(p, pa, t);
+      m3mul(R, Ra, R);
     }
   }
   if (lane < HRG_NHB) {
