@@ -1124,6 +1124,16 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   int maxd = 0;
   for (int i = 0; i < HRG_NHB; i++) maxd = desc->hb_depth[i] > maxd ? desc->hb_depth[i] : maxd;
   hm->hb_maxdepth = maxd;
+  for (int c = 0; c < HRG_NRCAP; c++) {
+    double d2 = 0;
+    for (int a = 0; a < 3; a++) d2 += (desc->rcap_p2[c][a] - desc->rcap_p1[c][a]) * (desc->rcap_p2[c][a] - desc->rcap_p1[c][a]);
+    hm->rcap_hl[c] = 0.5 * sqrt(d2);
+  }
+  for (int c = 0; c < HRG_NHB; c++) {
+    double d2 = 0;
+    for (int a = 0; a < 3; a++) d2 += (desc->hcap_p2[c][a] - desc->hcap_p1[c][a]) * (desc->hcap_p2[c][a] - desc->hcap_p1[c][a]);
+    hm->hcap_hl[c] = 0.5 * sqrt(d2);
+  }
   if (maxd + 1 > 16) { delete hm; delete b; return fail(HRG_ERR_INVALID, "human tree deeper than 15"); }
   for (int i = 0; i < HRG_NHB; i++) hm->hb_jump[0][i] = desc->hb_parent[i];
   for (int s = 1; s < 4; s++)

@@ -359,6 +359,7 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   int safe = 1;
   if (shield_on) {
     const double sdiff = se - ps;
+    double rc_hl = 0;  // lane c < 7: half length of robot reach capsule c (read by the verification loop with a scalar readlane)
     if (lane < HRG_NSHIELD_RCAP) {
       const int c = lane;
       double d[3], l1, l2;
@@ -366,6 +367,9 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
       v3sub(d, &L.scap[0][c][3], &L.scap[1][c][3]); l2 = v3norm(d);
       for (int a = 0; a < 6; a++) L.rc[c][a] = 0.5 * (L.scap[0][c][a] + L.scap[1][c][a]);
       L.rc[c][6] = m.scap_r[c] + m.secure_radius + 0.5 * (l1 > l2 ? l1 : l2) + m.scap_alpha[c] * sdiff * sdiff / 8.0;
+      double hv[3];
+      for (int a = 0; a < 3; a++) hv[a] = 0.5 * (L.rc[c][3 + a] - L.rc[c][a]);
+      rc_hl = sqrt(v3dot(hv, hv));
       if (dbg_r) for (int a = 0; a < 7; a++) dbg_r[((size_t)e * HRG_NSHIELD_RCAP + c) * 7 + a] = L.rc[c][a];
     }
     wave_sync();
@@ -405,11 +409,11 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
       const double hl = sqrt(v3dot(hh, hh));
 #pragma unroll 1
       for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
-        double x1[3], x2[3], rcn[3], rh[3], dc[3];
+        double x1[3], x2[3], rcn[3], dc[3];
         const double rr = L.rc[c][6] + r;
-        for (int a = 0; a < 3; a++) { rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]); rh[a] = 0.5 * (L.rc[c][3 + a] - L.rc[c][a]); }
+        for (int a = 0; a < 3; a++) rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]);
         v3sub(dc, rcn, hc);
-        const double reach = sqrt(v3dot(rh, rh)) + hl + rr + 1e-9;
+        const double reach = __shfl(rc_hl, c, 64) + hl + rr + 1e-9;
         if (v3dot(dc, dc) > reach * reach) continue;  // bounding spheres apart: cannot intersect
         if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true;
       }
@@ -512,21 +516,21 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
     if (round <= 4) {
       int i = 0, g2 = 0;
-      double r2 = 0, margin = 0;
+      double r2 = 0, margin = 0, hl2 = 0;
       const double *a1, *a2;
       bool valid;
       if (round == 0) {
         valid = lane < dm->n_self;
         i = valid ? dm->self_i[lane] : 0;
         const int j = valid ? dm->self_j[lane] : 1;
-        g2 = j; a1 = &L.rcapw[j][0]; a2 = &L.rcapw[j][3]; r2 = m.rcap_r[j];
+        g2 = j; a1 = &L.rcapw[j][0]; a2 = &L.rcapw[j][3]; r2 = m.rcap_r[j]; hl2 = dm->rcap_hl[j];
         c.b2 = m.rcap_body[j];
       } else {
         const int pidx = (round - 1) * 64 + lane;
         valid = pidx < HRG_NRCAP * HRG_NHB;
         i = valid ? pidx / HRG_NHB : 0;
         const int hb = valid ? pidx % HRG_NHB : 0;
-        g2 = GEOM_HUMAN0 + hb; a1 = &L.hcap[hb][0]; a2 = &L.hcap[hb][3]; r2 = m.hcap_r[hb];
+        g2 = GEOM_HUMAN0 + hb; a1 = &L.hcap[hb][0]; a2 = &L.hcap[hb][3]; r2 = m.hcap_r[hb]; hl2 = dm->hcap_hl[hb];
         margin = m.contact_margin_human;
         c.b2 = -2;
       }
@@ -534,11 +538,11 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
       // wave skips the narrowphase when no lane survives, which is the common case
       bool near = false;
       if (valid) {
-        double ca[3], cb[3], dc[3], h1[3], h2[3];
-        for (int a = 0; a < 3; a++) { ca[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]); h1[a] = 0.5 * (L.rcapw[i][3 + a] - L.rcapw[i][a]);
-                                      cb[a] = 0.5 * (a1[a] + a2[a]); h2[a] = 0.5 * (a2[a] - a1[a]); }
+        double ca[3], cb[3], dc[3];
+        for (int a = 0; a < 3; a++) { ca[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]); cb[a] = 0.5 * (a1[a] + a2[a]); }
         v3sub(dc, ca, cb);
-        const double reach = sqrt(v3dot(h1, h1)) + sqrt(v3dot(h2, h2)) + m.rcap_r[i] + r2 + margin + 1e-9;
+        // half lengths are model constants (rigid capsules); 1e-9 m of slack covers the rounding of the world-frame end points
+        const double reach = dm->rcap_hl[i] + hl2 + m.rcap_r[i] + r2 + margin + 1e-9;
         near = v3dot(dc, dc) <= reach * reach;
       }
       if (__any(near) && valid && near) {
