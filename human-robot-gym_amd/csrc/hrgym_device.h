@@ -103,6 +103,7 @@ struct DevModel {
   double Rq[NV][9];          // body_quat as matrices
   int32_t anc_mask[NV];      // bit i set: body i is an ancestor-or-self of body j
   int32_t hb_maxdepth;
+  double sol_K, sol_Bd;                  // constraint stiffness / damping of solref (constants of the model)
   double rcap_hl[HRG_NRCAP], hcap_hl[HRG_NHB];  // half lengths of the collision capsules (rigid: constants of the model)
   int32_t hb_njump;                      // rounds of pointer jumping that cover the deepest path
   int32_t hb_jump[4][HRG_NHB];           // ancestor 2^s levels up (-1: beyond the root)

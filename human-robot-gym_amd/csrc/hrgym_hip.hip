@@ -17,7 +17,7 @@
 // semi-implicit Euler with implicit joint damping.  Lanes = constraint rows in fixed slots:
 //   0..7 friction loss of dof r | 8..23 joint limit (dof, lo/hi) | 24..63 contact c, pyramid edge d.
 template <class MD>
-DI void impedance(const MD& m, double x0, double* imp, double* K, double* Bd) {
+DI void impedance(const MD& m, double x0, double* imp) {  // the stiffness / damping of solref are model constants: DevModel.sol_K, sol_Bd
   const double d0 = m.solimp[0], dmax = m.solimp[1], width = m.solimp[2], mid = m.solimp[3], power = m.solimp[4];
   const double x = fabs(x0) / width;
   double y;
@@ -30,27 +30,21 @@ DI void impedance(const MD& m, double x0, double* imp, double* K, double* Bd) {
   else if (x <= mid) y = pow(x / mid, power) * mid;
   else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
   *imp = d0 + y * (dmax - d0);
-  double tc = m.solref[0];
-  const double dr = m.solref[1];
-  if (tc < 2 * m.timestep) tc = 2 * m.timestep;
-  *K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
-  *Bd = 2.0 / (dmax * tc);
 }
 
-DI void row_cost(int type, double D, double floss, double x, double* c, double* g, double* h) {
+// lim = floss / D of a friction row, computed once per row and substep (an FP64 division is a ~30-instruction sequence)
+DI void row_cost(int type, double D, double floss, double lim, double x, double* c, double* g, double* h) {
   if (type == 1) {
     if (x < 0) { *c = 0.5 * D * x * x; *g = D * x; *h = D; } else { *c = 0; *g = 0; *h = 0; }
   } else {
-    const double lim = floss / D;
     if (x <= -lim) { *c = floss * (-x - 0.5 * lim); *g = -floss; *h = 0; }
     else if (x >= lim) { *c = floss * (x - 0.5 * lim); *g = floss; *h = 0; }
     else { *c = 0.5 * D * x * x; *g = D * x; *h = D; }
   }
 }
 
-DI int row_zone(int type, double D, double floss, double x) {  // which quadratic / linear piece of its cost a row is in
+DI int row_zone(int type, double lim, double x) {  // which quadratic / linear piece of its cost a row is in
   if (type == 1) return x < 0;
-  const double lim = floss / D;
   return x <= -lim ? -1 : (x >= lim ? 1 : 0);
 }
 
@@ -168,12 +162,14 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   }
   const bool active = cand && diag > 0;
   const bool is_con = r >= ROW_CON0;
-  double aref = 0, D = 0;
+  double aref = 0, D = 0, flim = 0;
   if (active) {
-    double imp, K, Bd;
-    impedance(m, pos - margin, &imp, &K, &Bd);
+    double imp;
+    const double K = dm->sol_K, Bd = dm->sol_Bd;
+    impedance(m, pos - margin, &imp);
     aref = -Bd * vel - K * imp * (pos - margin);
     D = 1.0 / ((1 - imp) / imp * diag);
+    if (type == 0) flim = floss / D;
   }
   const uint64_t mask = __ballot(active);
   const uint64_t cmask = mask >> ROW_CON0;  // active contact rows
@@ -205,7 +201,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     { // warm start vs unconstrained acceleration: keep the cheaper point
       const double ei = L.qacc[mi] - L.a0[mi], ej = L.qacc[mj] - L.a0[mj];
       double c0 = 0, c1 = 0, g_, h_;
-      if (active) { row_cost(type, D, floss, rowdot(L.qacc) - aref, &c0, &g_, &h_); row_cost(type, D, floss, rowdot(L.a0) - aref, &c1, &g_, &h_); }
+      if (active) { row_cost(type, D, floss, flim, rowdot(L.qacc) - aref, &c0, &g_, &h_); row_cost(type, D, floss, flim, rowdot(L.a0) - aref, &c1, &g_, &h_); }
       double quad = 0.5 * Mij * ei * ej;
 #if HRG_BOX
       if (lane < HRG_NBOXV) { const double eb = L.qacc[NV + lane] - L.a0[NV + lane]; quad += 0.5 * (lane < 3 ? m.box_mass : m.box_inertia) * eb * eb; }
@@ -222,7 +218,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       COUNT(16, 1);  // Newton iterations
       const double y = rowdot(L.qacc) - aref;
       double cc = 0, gg = 0, hh = 0;
-      if (active) row_cost(type, D, floss, y, &cc, &gg, &hh);
+      if (active) row_cost(type, D, floss, flim, y, &cc, &gg, &hh);
       if (r < NROW) { L.rg[r] = gg; L.rh[r] = hh; }
       wave_sync();
       double gm = 0;
@@ -358,7 +354,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       for (int ls = 0; ls < 40; ls++) {
         COUNT(17, 1);  // line-search evaluations
         double c2, g2 = 0, h2 = 0;
-        if (active) row_cost(type, D, floss, y + al * p, &c2, &g2, &h2);
+        if (active) row_cost(type, D, floss, flim, y + al * p, &c2, &g2, &h2);
         const double d1 = gd0 + al * dMd + wave_sum(g2 * p);
         const double d2 = dMd + wave_sum(h2 * p * p);
         if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
@@ -373,7 +369,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       wave_sync();
       // a full Newton step that stayed inside one quadratic piece of every row solved the problem exactly
       bool moved = false;
-      if (active) moved = row_zone(type, D, floss, y) != row_zone(type, D, floss, y + p);
+      if (active) moved = row_zone(type, flim, y) != row_zone(type, flim, y + p);
       if (al == 1.0 && !__any(moved)) break;
     }
   }
@@ -1124,6 +1120,13 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   int maxd = 0;
   for (int i = 0; i < HRG_NHB; i++) maxd = desc->hb_depth[i] > maxd ? desc->hb_depth[i] : maxd;
   hm->hb_maxdepth = maxd;
+  { // mj_makeImpedance constants of solref (the oracle's `impedance`)
+    double tc = desc->solref[0];
+    const double dr = desc->solref[1], dmax = desc->solimp[1];
+    if (tc < 2 * desc->timestep) tc = 2 * desc->timestep;
+    hm->sol_K = 1.0 / (dmax * dmax * tc * tc * dr * dr);
+    hm->sol_Bd = 2.0 / (dmax * tc);
+  }
   for (int c = 0; c < HRG_NRCAP; c++) {
     double d2 = 0;
     for (int a = 0; a < 3; a++) d2 += (desc->rcap_p2[c][a] - desc->rcap_p1[c][a]) * (desc->rcap_p2[c][a] - desc->rcap_p1[c][a]);
