@@ -383,9 +383,10 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
       double c1[3], c2[3], r;
       if (kind == 0) {
         double va[3], vb[3];
+        const double idt = have_vel ? 1.0 / (t - s.meas_prev_t) : 0.0;
         for (int a = 0; a < 3; a++) {
-          va[a] = have_vel ? (s.human_site[j1][a] - s.meas_prev[j1][a]) / (t - s.meas_prev_t) : 0.0;
-          vb[a] = have_vel ? (s.human_site[j2][a] - s.meas_prev[j2][a]) / (t - s.meas_prev_t) : 0.0;
+          va[a] = (s.human_site[j1][a] - s.meas_prev[j1][a]) * idt;   // finite-difference velocity: one reciprocal, six products
+          vb[a] = (s.human_site[j2][a] - s.meas_prev[j2][a]) * idt;
         }
         const double base = 0.5 * dm->hc_a[lane] * Td * Td + m.meas_err_pos + m.meas_err_vel * Td;
         const double r1 = v3norm(va) * Td * 0.5 + base, r2 = v3norm(vb) * Td * 0.5 + base;
