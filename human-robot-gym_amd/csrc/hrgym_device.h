@@ -570,6 +570,23 @@ DI double chol_lanes(double a, int lane, bool* ok) {
   *ok = good;
   return a;
 }
+// two independent factorisations in one pass (M and M + h D of a substep): the two dependency chains (rsqrt, shuffles) interleave
+DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* lb) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const double akk = __shfl(a, k * 9, 64), bkk = __shfl(b, k * 9, 64);
+    if (!(akk > 0) || !(bkk > 0)) good = false;
+    const double inva = rsqrt(akk), da = akk * inva, invb = rsqrt(bkk), db = bkk * invb;
+    const double aik = __shfl(a, i * 8 + k, 64) * inva, bik = __shfl(b, i * 8 + k, 64) * invb;
+    const double ajk = __shfl(a, j * 8 + k, 64) * inva, bjk = __shfl(b, j * 8 + k, 64) * invb;
+    if (j == k) { if (i == k) { a = da; b = db; } else if (i > k) { a = aik; b = bik; } }
+    else if (i > k && j > k) { a -= aik * ajk; b -= bik * bjk; }
+  }
+  *ok = good;
+  *la = a; *lb = b;
+}
 // publish the factor for the wave-uniform solves: lower triangle + reciprocal diagonal
 DI void chol_store(double l, int lane, double* Lm, double* invd) {
   Lm[lane] = l;

@@ -59,8 +59,10 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   // ---- factor M across the wave; unconstrained acceleration a0 = M^-1 (actuation + passive - bias) ----
   bool ok;
   const double Mij = L.M[lane];
+  double l_damp;  // factor of M + h D (mj_Euler's implicit damping), used at the end of the substep
   {
-    const double lm = chol_lanes(Mij, lane, &ok);
+    double lm;
+    chol_lanes2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &lm, &l_damp);
     if (!ok) return 1;
     chol_store(lm, lane, L.H, L.Hinv);
   }
@@ -377,11 +379,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
-  {
-    const double hl = chol_lanes(Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok);
-    if (!ok) return 1;
-    chol_store(hl, lane, L.H, L.Hinv);
-  }
+  chol_store(l_damp, lane, L.H, L.Hinv);
   if (lane < NV) {
     s.qacc_warmstart[lane] = L.qacc[lane];
     double t = 0;
