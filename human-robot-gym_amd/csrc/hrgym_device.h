@@ -570,6 +570,15 @@ DI double chol_lanes(double a, int lane, bool* ok) {
   *ok = good;
   return a;
 }
+// inclusive prefix sum along the robot's kinematic chain for lanes = bodies: lanes 0..5 the serial arm, lanes 6, 7 (fingers,
+// children of link 6) = prefix of lane 5 + own value.  DPP row shifts inside row 0; shifted-in lanes contribute 0.
+DI double chain_prefix(double x, int lane) {
+  double y = lane < NARM ? x : 0.0;
+  y += dpp_f64<0x111, 0xf>(y);  // row_shr:1
+  y += dpp_f64<0x112, 0xf>(y);  // row_shr:2
+  y += dpp_f64<0x114, 0xf>(y);  // row_shr:4
+  return lane < NARM ? y : y + x;
+}
 // two independent factorisations in one pass (M and M + h D of a substep): the two dependency chains (rsqrt, shuffles) interleave
 DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* lb) {
   const int i = lane >> 3, j = lane & 7;

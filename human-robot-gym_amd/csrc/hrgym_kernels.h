@@ -108,25 +108,24 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
   }
   wave_sync();
   if (lane < NV) {
-    const int i = lane, anc = dm->anc_mask[i];
+    const int i = lane;
     // ---- velocity / acceleration of body i: accumulate along the ancestor path (ancestors have smaller indices) ----
-    double vw[3] = {0, 0, 0}, vv[3] = {0, 0, 0}, aw[3] = {0, 0, 0}, av[3];
-    v3scl(av, m.gravity, -1.0);
-#pragma unroll 1
-    for (int k = 0; k < NV; k++) {
-      if (!((anc >> k) & 1)) continue;
-      const double qd = L.st.qvel[k];
-      double jw[3], jv[3], t1[3], t2[3], t3[3];
-      v3scl(jw, L.Sw[k], qd);
-      v3scl(jv, L.Sv[k], qd);
-      v3add(vw, vw, jw);
-      v3add(vv, vv, jv);
+    // The arm is a serial chain and the fingers hang off its last link (checked at create), so the running sums along the
+    // ancestor path are prefix sums over lanes 0..5 (+ the finger's own term): three DPP row-shift steps per component
+    // instead of a loop over up to 7 ancestors.  vw_k, vv_k = body velocity, term_k = the Coriolis terms joint k adds.
+    double vw[3], vv[3], aw[3], av[3], jw[3], jv[3];
+    {
+      const double qd = L.st.qvel[i];
+      v3scl(jw, L.Sw[i], qd);
+      v3scl(jv, L.Sv[i], qd);
+    }
+    for (int a = 0; a < 3; a++) { vw[a] = chain_prefix(jw[a], lane); vv[a] = chain_prefix(jv[a], lane); }
+    {
+      double t1[3], t2[3], t3[3];
       v3cross(t1, vw, jw);
       v3cross(t2, vw, jv);
       v3cross(t3, vv, jw);
-      v3add(aw, aw, t1);
-      v3add(av, av, t2);
-      v3add(av, av, t3);
+      for (int a = 0; a < 3; a++) { aw[a] = chain_prefix(t1[a], lane); av[a] = chain_prefix(t2[a] + t3[a], lane) - m.gravity[a]; }
     }
     v3cpy(L.vw[i], vw);
     v3cpy(L.vv[i], vv);
