@@ -579,15 +579,6 @@ DI double chain_prefix(double x, int lane) {
   y += dpp_f64<0x114, 0xf>(y);  // row_shr:4
   return lane < NARM ? y : y + x;
 }
-// sum over the subtree of body `lane` (self + descendants): lanes 0..5 = bodies lane..5 plus both fingers, lanes 6, 7 = own value
-DI double chain_suffix(double x, int lane) {
-  double y = lane < NARM ? x : 0.0;
-  y += dpp_f64<0x101, 0xf>(y);  // row_shl:1
-  y += dpp_f64<0x102, 0xf>(y);  // row_shl:2
-  y += dpp_f64<0x104, 0xf>(y);  // row_shl:4
-  const double f6 = __shfl(x, NARM, 64), f7 = __shfl(x, NARM + 1, 64);
-  return lane < NARM ? y + (f6 + f7) : x;
-}
 // two independent factorisations in one pass (M and M + h D of a substep): the two dependency chains (rsqrt, shuffles) interleave
 DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* lb) {
   const int i = lane >> 3, j = lane & 7;

@@ -84,17 +84,13 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
   Lds& L = g_L;
   const auto& m = dm->m;
   double bI[10];  // this body's spatial inertia about the world origin (m, h, I)
-  // every lane runs the body code (lanes >= 8 shadow body 0 and store nothing) so that the DPP scans below see all their
-  // source lanes active
-  const bool body_lane = lane < NV;
-  {
-    const int i = body_lane ? lane : 0;
+  if (lane < NV) {
+    const int i = lane;
     const double* R = L.kR[i];
-    double axw[3], t[3], c[3], Swi[3], Svi[3];
+    double axw[3], t[3], c[3];
     m3mulv(axw, R, m.jnt_axis[i]);
-    if (i < NARM) { v3cpy(Swi, axw); v3cross(Svi, L.kp[i], axw); }
-    else { v3set(Swi, 0, 0, 0); v3cpy(Svi, axw); }
-    if (body_lane) { v3cpy(L.Sw[i], Swi); v3cpy(L.Sv[i], Svi); }
+    if (i < NARM) { v3cpy(L.Sw[i], axw); v3cross(L.Sv[i], L.kp[i], axw); }
+    else { v3set(L.Sw[i], 0, 0, 0); v3cpy(L.Sv[i], axw); }
     m3mulv(t, R, m.body_com[i]);
     v3add(c, L.kp[i], t);
     const auto* I = m.body_inertia[i];
@@ -107,6 +103,12 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
     m3mul(W, T, Rt);
     const double Iw[6] = {W[0], W[4], W[8], W[1], W[2], W[5]};
     sinertia_body(bI, m.body_mass[i], c, Iw);
+#pragma unroll
+    for (int a = 0; a < 10; a++) L.cI[i][a] = bI[a];
+  }
+  wave_sync();
+  if (lane < NV) {
+    const int i = lane;
     // ---- velocity / acceleration of body i: accumulate along the ancestor path (ancestors have smaller indices) ----
     // The arm is a serial chain and the fingers hang off its last link (checked at create), so the running sums along the
     // ancestor path are prefix sums over lanes 0..5 (+ the finger's own term): three DPP row-shift steps per component
@@ -114,8 +116,8 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
     double vw[3], vv[3], aw[3], av[3], jw[3], jv[3];
     {
       const double qd = L.st.qvel[i];
-      v3scl(jw, Swi, qd);
-      v3scl(jv, Svi, qd);
+      v3scl(jw, L.Sw[i], qd);
+      v3scl(jv, L.Sv[i], qd);
     }
     for (int a = 0; a < 3; a++) { vw[a] = chain_prefix(jw[a], lane); vv[a] = chain_prefix(jv[a], lane); }
     {
@@ -125,7 +127,8 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
       v3cross(t3, vv, jw);
       for (int a = 0; a < 3; a++) { aw[a] = chain_prefix(t1[a], lane); av[a] = chain_prefix(t2[a] + t3[a], lane) - m.gravity[a]; }
     }
-    if (body_lane) { v3cpy(L.vw[i], vw); v3cpy(L.vv[i], vv); }
+    v3cpy(L.vw[i], vw);
+    v3cpy(L.vv[i], vv);
     // ---- force of body i: f = I a + v x* (I v) ----
     double n1[3], f1[3], n2[3], f2[3], t1[3], t2[3], t3[3];
     sinertia_mul(n1, f1, bI, aw, av);
@@ -133,21 +136,22 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
     v3cross(t1, vw, n2);
     v3cross(t2, vv, f2);
     v3cross(t3, vw, f2);
-    // ---- bias force of joint i = S_i . (sum of the forces of the bodies in its subtree): suffix sums over the chain ----
-    double sn[3], sf[3];
 #pragma unroll
-    for (int a = 0; a < 3; a++) { sn[a] = chain_suffix(n1[a] + t1[a] + t2[a], lane); sf[a] = chain_suffix(f1[a] + t3[a], lane); }
-    if (body_lane) L.bias[i] = v3dot(Swi, sn) + v3dot(Svi, sf);
-    // ---- composite inertia of the subtree rooted at i (same suffix sums), applied to the joint axis ----
+    for (int a = 0; a < 3; a++) { L.fn[i][a] = n1[a] + t1[a] + t2[a]; L.ff[i][a] = f1[a] + t3[a]; }
+    // ---- composite inertia of the subtree rooted at i, applied to the joint axis ----
     double cc[10];
 #pragma unroll
-    for (int a = 0; a < 10; a++) cc[a] = chain_suffix(bI[a], lane);
-    double n[3], f[3];
-    sinertia_mul(n, f, cc, Swi, Svi);
-    if (body_lane) {
+    for (int a = 0; a < 10; a++) cc[a] = bI[a];
+#pragma unroll 1
+    for (int k = i + 1; k < NV; k++) {
+      if (!((dm->anc_mask[k] >> i) & 1)) continue;
 #pragma unroll
-      for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
+      for (int a = 0; a < 10; a++) cc[a] += L.cI[k][a];
     }
+    double n[3], f[3];
+    sinertia_mul(n, f, cc, L.Sw[i], L.Sv[i]);
+#pragma unroll
+    for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
   }
   wave_sync();
   { // mass matrix: lane (i,j)
@@ -157,6 +161,19 @@ HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) 
     else if ((dm->anc_mask[i] >> j) & 1) v = v3dot(L.Sw[j], &L.F[i][0]) + v3dot(L.Sv[j], &L.F[i][3]);
     if (i == j) v += m.jnt_armature[i];
     L.M[lane] = v;
+  }
+  if (lane < NV) { // bias force of joint k = S_k . (sum of the forces of the bodies in its subtree)
+    const int k = lane;
+    double sn[3], sf[3];
+    v3cpy(sn, L.fn[k]);
+    v3cpy(sf, L.ff[k]);
+#pragma unroll 1
+    for (int i = k + 1; i < NV; i++) {
+      if (!((dm->anc_mask[i] >> k) & 1)) continue;
+      v3add(sn, sn, L.fn[i]);
+      v3add(sf, sf, L.ff[i]);
+    }
+    L.bias[k] = v3dot(L.Sw[k], sn) + v3dot(L.Sv[k], sf);
   }
   wave_sync();
 }
