@@ -67,6 +67,7 @@
 #define HRG_BIGPHASE HRG_PHASE
 #endif
 #define HRG_PI 3.14159265358979323846
+#define SIXTH (1.0 / 6.0)   // cubic term of the constant-jerk profiles: a product, not an FP64 division per segment
 
 #define GEOM_HUMAN0 HRG_NRCAP
 #define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
@@ -424,7 +425,7 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
   if (fabs(a0) > 1e-9) { /* below that the ramp is a no-op (and the sign of rounding noise must not matter) */
     double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
     dur[n] = t; jerk[n] = jj; n++;
-    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
+    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t * SIXTH;
     v += a0 * t + 0.5 * jj * t * t;
   } else n++;
   double D = goal - q;
@@ -473,12 +474,12 @@ DI void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double
   for (int i = 0; i < HRG_LTT_NSEG; i++) {
     double d = L->dur[j][i], jj = L->jerk[j][i];
     if (t < d) {
-      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t * SIXTH;
       *v = vv + aa * t + 0.5 * jj * t * t;
       *a = aa + jj * t;
       return;
     }
-    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d * SIXTH;
     vv += aa * d + 0.5 * jj * d * d;
     aa += jj * d;
     t -= d;
@@ -512,12 +513,12 @@ __host__ DI void path_eval(const hrg_path* P, double t, double ve, double* s, do
   for (int i = 0; i < 3; i++) {
     double d = P->dur[i], jj = P->jerk[i];
     if (t < d) {
-      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t * SIXTH;
       *v = vv + aa * t + 0.5 * jj * t * t;
       *a = aa + jj * t;
       return;
     }
-    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d * SIXTH;
     vv += aa * d + 0.5 * jj * d * d;
     aa += jj * d;
     t -= d;

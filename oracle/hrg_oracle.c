@@ -29,6 +29,7 @@
 #define NEFC_MAX 64
 #define BODY_BOX 100   /* body code of the manipulation object in contact_t.b1/b2 */
 #define PI 3.14159265358979323846
+#define SIXTH (1.0 / 6.0) /* cubic term of the constant-jerk profiles */
 
 #include <stdio.h>
 static int g_debug = 0;
@@ -449,7 +450,7 @@ static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, d
   if (fabs(a0) > 1e-9) { /* below that the ramp is a no-op (and the sign of rounding noise must not matter) */
     double t = fabs(a0) / jmax, jj = a0 > 0 ? -jmax : jmax;
     dur[n] = t; jerk[n] = jj; n++;
-    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t / 6;
+    q += v0 * t + 0.5 * a0 * t * t + jj * t * t * t * SIXTH;
     v += a0 * t + 0.5 * jj * t * t;
   } else n++;
   double D = goal - q;
@@ -513,12 +514,12 @@ static void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, do
   for (int i = 0; i < HRG_LTT_NSEG; i++) {
     double d = L->dur[j][i], jj = L->jerk[j][i];
     if (t < d) {
-      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *q = qq + vv * t + 0.5 * aa * t * t + jj * t * t * t * SIXTH;
       *v = vv + aa * t + 0.5 * jj * t * t;
       *a = aa + jj * t;
       return;
     }
-    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d * SIXTH;
     vv += aa * d + 0.5 * jj * d * d;
     aa += jj * d;
     t -= d;
@@ -555,12 +556,12 @@ static void path_eval(const hrg_path* P, double t, double ve, double* s, double*
   for (int i = 0; i < 3; i++) {
     double d = P->dur[i], jj = P->jerk[i];
     if (t < d) {
-      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t / 6;
+      *s = ss + vv * t + 0.5 * aa * t * t + jj * t * t * t * SIXTH;
       *v = vv + aa * t + 0.5 * jj * t * t;
       *a = aa + jj * t;
       return;
     }
-    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d / 6;
+    ss += vv * d + 0.5 * aa * d * d + jj * d * d * d * SIXTH;
     vv += aa * d + 0.5 * jj * d * d;
     aa += jj * d;
     t -= d;
