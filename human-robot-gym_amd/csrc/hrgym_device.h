@@ -487,6 +487,33 @@ DI void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double
   *q = L->qT[j]; *v = 0; *a = 0;
 }
 
+// the same walk for two path positions sa <= sb at once: (q, q', q'') at sa and q at sb; per target the operations are those of
+// ltt_eval, so the results are bitwise the ones of two separate calls
+DI void ltt_eval2(const hrg_ltt* L, int j, double sa, double sb, double* qa, double* va, double* aa_, double* qb) {
+  double qq = L->q0[j], vv = L->v0[j], aa = L->a0[j], ta = sa < 0 ? 0 : sa, tb = sb < 0 ? 0 : sb;
+  bool done_a = false;
+  for (int i = 0; i < HRG_LTT_NSEG; i++) {
+    const double d = L->dur[j][i], jj = L->jerk[j][i];
+    if (!done_a && ta < d) {
+      *qa = qq + vv * ta + 0.5 * aa * ta * ta + jj * ta * ta * ta * SIXTH;
+      *va = vv + aa * ta + 0.5 * jj * ta * ta;
+      *aa_ = aa + jj * ta;
+      done_a = true;
+    }
+    if (tb < d) {
+      *qb = qq + vv * tb + 0.5 * aa * tb * tb + jj * tb * tb * tb * SIXTH;
+      return;
+    }
+    qq += vv * d + 0.5 * aa * d * d + jj * d * d * d * SIXTH;
+    vv += aa * d + 0.5 * jj * d * d;
+    aa += jj * d;
+    ta -= d;
+    tb -= d;
+  }
+  if (!done_a) { *qa = L->qT[j]; *va = 0; *aa_ = 0; }
+  *qb = L->qT[j];
+}
+
 __host__ DI void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, double amax, double jmax) {
   P->s0 = s0; P->v0 = v0; P->a0 = a0; P->k = 0;
   for (int i = 0; i < 3; i++) { P->dur[i] = 0; P->jerk[i] = 0; }

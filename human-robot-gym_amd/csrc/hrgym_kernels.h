@@ -347,9 +347,12 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   }
   STAMP(11);
   if (shield_on && lane < NARM) {
-    double d1, d2, qv;
-    ltt_eval(Lp, lane, se, &qv, &d1, &d2);
+    // configuration at the end of the brake, and in the same walk the Motion of the next cycle for the (usual) case that the
+    // step is verified safe: path state (s1, v1, a1) on this trajectory.  An unsafe verdict re-evaluates it below.
+    double qn, q1, q2, qv;
+    ltt_eval2(Lp, lane, s1, se, &qn, &q1, &q2, &qv);
     L.qe[lane] = qv;
+    s.des_q[lane] = qn; s.des_v[lane] = q1 * v1; s.des_a[lane] = q1 * a1 + q2 * v1 * v1;
   }
   wave_sync();
   STAMP(12);
@@ -466,7 +469,7 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   }
   s.is_safe = safe;
   wave_sync();
-  if (lane < NARM) {
+  if (lane < NARM && !(shield_on && safe)) {
     double qq, q1, q2;
     ltt_eval(&s.ltt, lane, s.path_s, &qq, &q1, &q2);
     s.des_q[lane] = qq; s.des_v[lane] = q1 * s.path_v; s.des_a[lane] = q1 * s.path_a + q2 * s.path_v * s.path_v;
