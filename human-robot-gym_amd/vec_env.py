@@ -61,6 +61,7 @@ INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "action_resamples",
 ]
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
+_BOOL_ITEMS = [(j, k) for j, k in enumerate(INFO_KEYS) if k in _BOOL_KEYS]
 OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human_reach_ppo_parallel.yaml:14-16
 # training/config/run/obs_keys of the pick-place experiments (e.g. PP-SAC): the observables the policy sees
 PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "gripper_aperture", "dist_eef_to_human_head",
@@ -211,20 +212,27 @@ class HipVecEnv(_VecEnvBase):
         return obs, reward, dones, infos
 
     def _make_infos(self, info, dones, term_obs):
-        infos = []
+        # one bulk conversion to Python scalars and one zip per env instead of 13 numpy scalar extractions per env
+        rows = np.asarray(info).tolist()
+        done_l = dones.tolist()
+        acts = self._actions
         now = time.time() - self._t_start
-        for i in range(self.num_envs):
-            d = {k: (bool(info[i, j]) if k in _BOOL_KEYS else int(info[i, j])) for j, k in enumerate(INFO_KEYS)}
-            d["action"] = self._actions[i]  # collision_prevention_wrapper.py:42-43: the executed action
-            if self.expert_obs_keys is not None:  # expert_obs_wrapper.py:171-175 (the step's own observation: pre-reset where done)
+        expert = self.expert_obs_keys
+        infos = []
+        for i, row in enumerate(rows):
+            d = dict(zip(INFO_KEYS, row))
+            for j, k in _BOOL_ITEMS:
+                d[k] = row[j] != 0
+            d["action"] = acts[i]  # collision_prevention_wrapper.py:42-43: the executed action
+            if expert is not None:  # expert_obs_wrapper.py:171-175 (the step's own observation: pre-reset where done)
                 prev, cur = self._expert_cur[i], np.asarray(term_obs[i])
-                d["previous_expert_observation"] = {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in self.expert_obs_keys}
-                d["current_expert_observation"] = {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in self.expert_obs_keys}
-            if dones[i]:
+                d["previous_expert_observation"] = {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in expert}
+                d["current_expert_observation"] = {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in expert}
+            if done_l[i]:
                 d["terminal_observation"] = np.asarray(term_obs[i])[self._cols]
                 d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
             else:
-                d.pop("TimeLimit.truncated")
+                del d["TimeLimit.truncated"]
             infos.append(d)
         return infos
 
