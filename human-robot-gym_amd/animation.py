@@ -62,13 +62,25 @@ class ClipSet:
             t.clip_offset[i] = off
             t.clip_pos_offset[i][:] = [float(x) for x in self.infos[i]["position_offset"]]
             t.clip_quat[i][:] = [float(x) for x in self.infos[i]["orientation_quat"]]
+            info = self.infos[i]
+            if "keyframes" in info:   # animation info of the collaboration tasks (human_object_inspection_cartesian_env.py:447-459, 602-652)
+                amps, speeds = info.get("loop_amplitudes", []), info.get("loop_speeds", [])
+                if isinstance(amps, dict) or len(amps) > CONST["HRG_MAX_LOOP"] or len(amps) != len(speeds) or len(info["keyframes"]) < 2:
+                    raise NotImplementedError("animation info: need two keyframes and up to 4 layered loop sines given as lists")
+                t.clip_keyframes[i][:] = [int(info["keyframes"][0]), int(info["keyframes"][1])]
+                t.clip_target_pos[i][:] = [float(x) for x in info.get("target_pos", [0.0, 0.0, 0.0])]
+                t.clip_n_loop[i] = len(amps)
+                for k in range(len(amps)):
+                    t.clip_loop_amp[i][k], t.clip_loop_speed[i][k] = float(amps[k]), float(speeds[k])
+                t.clip_loop_amp_std[i] = float(info.get("loop_amplitude_std_factor", 1.0))
+                t.clip_loop_speed_std[i] = float(info.get("loop_speed_std_factor", 1.0))
             off += n
         t.frames = self.frames.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         t.total_frames = off
         return t
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2):
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -98,6 +110,9 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         # the clip's info file places the human at the table edge in front of the robot: BVH +z maps to world +x
         # under human_base_quat (human_env.py:373), so 1.2 m along z = 1.2 m in front of the robot base
         info = {"position_offset": [0.0, 0.0, stand_off], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
+        if inspection:  # stand-in for the ObjectInspection/* info files: approach until 30 %, inspect until 70 %, idle loop of two layered sines
+            info.update(keyframes=[int(0.3 * n), int(0.7 * n)], target_pos=[0.55, float(rng.uniform(-0.1, 0.1)), 1.15],
+                        loop_amplitudes=[25.0, 8.0], loop_speeds=[1.0, 0.45], loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
         clips.append((anim, info))
     return ClipSet(clips)
 

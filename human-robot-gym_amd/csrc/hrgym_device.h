@@ -312,7 +312,7 @@ DI double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6, STREAM_LOOP = 7 };
 DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);

@@ -741,6 +741,10 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     double po[3], pt[3];
     placement_of(dm, gid, episode, 0, 0, po);
     placement_of(dm, gid, episode, 0, 1, pt);
+    if (m.task == HRG_TASK_INSPECTION) { // the target comes with the animation (info json), not from a bin
+      const int clip = clip_of(dm, gid, episode, 0);
+      for (int a = 0; a < 3; a++) pt[a] = dm->clips.clip_target_pos[clip][a] + s.human_pos_offset[a];
+    }
     if (lane < 3) { bx.pos[lane] = po[lane]; bx.obs_pos[lane] = po[lane]; bx.target[lane] = pt[lane]; }
     if (lane == 0) bx.quat[0] = 1.0;
     wave_sync();
@@ -863,8 +867,11 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   hrg_box_state& bx = L.bx;
   double e2o = 0, o2t = 0;
   for (int a = 0; a < 3; a++) { e2o += (bx.obs_pos[a] - s.eef_pos[a]) * (bx.obs_pos[a] - s.eef_pos[a]); o2t += (bx.target[a] - bx.obs_pos[a]) * (bx.target[a] - bx.obs_pos[a]); }
-  const int goal_reached = !crash && sqrt(o2t) <= m.goal_dist;
-  double r = goal_reached ? m.task_reward : (bx.gripped ? m.object_gripped_reward : -1.0);
+  const int in_zone = sqrt(o2t) <= m.goal_dist;
+  // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
+  const int inspection = m.task == HRG_TASK_INSPECTION;
+  const int goal_reached = !crash && (inspection ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone);
+  double r = goal_reached ? m.task_reward : ((inspection && in_zone) ? m.object_at_target_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
   const double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
 #else
   double dist2 = 0;
@@ -912,6 +919,29 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #if HRG_BOX
   if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
   wave_sync();
+  if (inspection && !d) {
+    if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_object_inspection_cartesian_env.py:492-505): next placement, next animation
+      const int oi = (bx.obj_index + 1) % m.n_obj_placements;
+      double po[3];
+      placement_of(dm, gid, s.episode, oi, 0, po);
+      const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+      wave_sync();
+      bx.obj_index = oi;
+      if (lane < 3) bx.pos[lane] = po[lane];
+      if (lane < 4) bx.quat[lane] = lane == 0 ? 1.0 : 0.0;
+      s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+      bx.task_phase = HRG_PHASE_APPROACH; bx.n_delayed = 0;
+      wave_sync();
+    }
+    // HumanObjectInspectionCart.step (461-490): READY -> INSPECTION when the object is in the target zone, back when it leaves it
+    const int ph = bx.task_phase;
+    int nph = ph;
+    if (ph == HRG_PHASE_READY && in_zone) nph = HRG_PHASE_INSPECTION;
+    else if (ph == HRG_PHASE_INSPECTION && !(sqrt(o2t) - m.goal_exit_tolerance <= m.goal_dist)) nph = HRG_PHASE_READY;
+    wave_sync();
+    bx.task_phase = nph;
+    wave_sync();
+  } else
   if (goal_reached && !d) { // _on_goal_reached (440-453): next target, object teleported to its next placement (velocity kept)
     const int ti = (bx.tgt_index + 1) % m.n_targets, oi = (bx.obj_index + 1) % m.n_obj_placements;
     double po[3], pt[3];
@@ -1096,10 +1126,14 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task != HRG_TASK_REACH && desc->task != HRG_TASK_PICK_PLACE) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task != HRG_TASK_REACH && desc->task != HRG_TASK_PICK_PLACE && desc->task != HRG_TASK_INSPECTION) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task == HRG_TASK_INSPECTION)
+    for (int c = 0; c < clips->n_clips; c++)
+      if (!(clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP && clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1]))
+        return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");
   if (desc->ik_enabled && !(desc->ik_max_iter >= 1 && desc->ik_max_iter <= 1000 && desc->ik_damping > 0 && desc->ik_action_limit > 0 && desc->ik_residual_threshold >= 0))
     return fail(HRG_ERR_INVALID, "ik: need 1 <= max_iter <= 1000, damping > 0, action_limit > 0, residual_threshold >= 0");
-  if (desc->task == HRG_TASK_PICK_PLACE && !(desc->box_half > 0 && desc->box_mass > 0 && desc->box_inertia > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
+  if (desc->task != HRG_TASK_REACH && !(desc->box_half > 0 && desc->box_mass > 0 && desc->box_inertia > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
     return fail(HRG_ERR_INVALID, "PickPlaceHumanCart needs box_half, box_mass, box_inertia, n_targets, n_obj_placements > 0");
   HIPCHK(hipSetDevice(device));
   hrg_batch* b = new hrg_batch();
@@ -1218,7 +1252,7 @@ void hrg_batch_destroy(hrg_batch* b) {
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
-  if (b->task == HRG_TASK_PICK_PLACE) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   HIPCHK(hipGetLastError());
   return HRG_OK;
@@ -1233,7 +1267,7 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  if (b->task == HRG_TASK_PICK_PLACE)
+  if (b->task != HRG_TASK_REACH)
     hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else

@@ -258,6 +258,17 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
   wave_sync();
 }
 
+#if HRG_BOX
+// amplitude (speed = 0) or speed modifier (1) of layered sine k of the idle loop of animation slot ai in this episode
+// (sample_animation_loop_properties, utils/animation_utils.py:122-176), drawn counter-based on demand
+DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int k, int speed) {
+  const double base = speed ? dm->clips.clip_loop_speed[clip][k] : dm->clips.clip_loop_amp[clip][k];
+  const double sf = speed ? dm->clips.clip_loop_speed_std[clip] : dm->clips.clip_loop_amp_std[clip];
+  const double z = clampd(rng_gauss(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_LOOP, (uint64_t)((ai * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
+  return base * exp(z * log(sf));
+}
+#endif
+
 HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -268,6 +279,31 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
   int at = control_time - s.anim_start_time;
   int anim_index = s.anim_index, anim_start = s.anim_start_time;
   int clip = clip_of(dm, gid, s.episode, anim_index);
+#if HRG_BOX
+  if (m.task == HRG_TASK_INSPECTION) { // HumanObjectInspectionCart._compute_animation_time (human_object_inspection_cartesian_env.py:602-652); wave-uniform
+    hrg_box_state& bx = L.bx;
+    const int classic = control_time - s.anim_start_time, k0 = dm->clips.clip_keyframes[clip][0], k1 = dm->clips.clip_keyframes[clip][1], len = dm->clips.clip_len[clip];
+    int phase = bx.task_phase, nd = bx.n_delayed;
+    at = classic;   // clamped to the clip below: the clip only advances through _on_goal_reached
+    if (at > k0 && phase == HRG_PHASE_APPROACH) phase = HRG_PHASE_READY;
+    if (phase == HRG_PHASE_READY) { // idle loop around the first keyframe: layered_sin_modulations (utils/animation_utils.py:62-119)
+      const int nl = dm->clips.clip_n_loop[clip];
+      double sum = 0;
+      for (int k = 0; k < nl; k++) {
+        const double A = loop_prop(dm, gid, s.episode, s.anim_index, clip, k, 0), S = loop_prop(dm, gid, s.episode, s.anim_index, clip, k, 1);
+        sum += A * sin((double)(classic - k0) / (A / S)) + (double)k0;
+      }
+      at = (int)(sum - (double)k0 * (double)(nl - 1));
+      nd = classic - at;
+    } else at -= nd;
+    if (at > k1) phase = HRG_PHASE_RETREAT;
+    if (at >= len - 1) { phase = HRG_PHASE_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+    wave_sync();
+    bx.task_phase = phase; bx.n_delayed = nd;
+    if (lane < 3) bx.target[lane] = dm->clips.clip_target_pos[clip][lane] + s.human_pos_offset[lane];  // target_pos property (447-459)
+  }
+#endif
   if (at > dm->clips.clip_len[clip] - 1) {
     anim_index = (anim_index + 1) % m.n_anim_ids; // human_env.py:1704-1708
     at = 0;

@@ -69,7 +69,19 @@ PICK_PLACE_ENV_KWARGS = dict(
     n_targets_sampled_per_100_steps=3,
     object_gripped_reward=-0.25,
 )
-ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS}
+# HumanObjectInspectionCart constructor defaults overlaid with config/environment/(default/)human_object_inspection_cart.yaml
+INSPECTION_ENV_KWARGS = dict(
+    PICK_PLACE_ENV_KWARGS,
+    human_rand=[0.0, 0.5, 0.0],
+    n_animations_sampled_per_100_steps=2,
+    n_targets_sampled_per_100_steps=0,      # the target comes with the animation (human_object_inspection_cartesian_env.py:394)
+    object_gripped_reward=-1.0,
+    object_at_target_reward=-1.0,
+    goal_exit_tolerance=0.02,
+)
+ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS,
+                "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
+BOX_TASKS = ("PickPlaceHumanCart", "HumanObjectInspectionCart")
 # RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
 FINGER_QPOS_RANGE = [[-0.0118366, 0.011499], [0.0118366, -0.011499]]
 
@@ -448,14 +460,14 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         raise ValueError("collision_prevention: replace_type in {0,1,2}, n_resamples <= 64")
     d.goal_check = int(bool(goal_check))
     d.self_collision_safety = float(kw["self_collision_safety"])
-    d.obstacle_margin = 0.0 if env_id == "PickPlaceHumanCart" else 0.01   # safety_margin: pick_place_human_cartesian_env.py:696-700 / reach_human_env.py:589-593
+    d.obstacle_margin = 0.0 if env_id in BOX_TASKS else 0.01   # safety_margin: pick_place_human_cartesian_env.py:696-700 / reach_human_env.py:589-593
     d.base_cyl_r, d.base_cyl_z = 0.2, 0.91
     # ---- manipulation object / task (pick_place_human_cartesian_env.py:257-404, 613-708, 843-875)
     for f in range(CONST["HRG_NFINGER"]):
         d.finger_qpos_range[0][f], d.finger_qpos_range[1][f] = FINGER_QPOS_RANGE[0][f], FINGER_QPOS_RANGE[1][f]
     d.task = CONST["HRG_TASK_REACH"]
-    if env_id == "PickPlaceHumanCart":
-        d.task = CONST["HRG_TASK_PICK_PLACE"]
+    if env_id in BOX_TASKS:
+        d.task = CONST["HRG_TASK_PICK_PLACE"] if env_id == "PickPlaceHumanCart" else CONST["HRG_TASK_INSPECTION"]
         d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616
         size = [float(x) for x in kw["object_full_size"]]
         if not (size[0] == size[1] == size[2]):
@@ -468,6 +480,10 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         bx, by = 0.5 * tx - 0.05, 0.5 * ty - 0.05
         d.obj_bin[:] = [bx * 0.35, bx * 0.6, by * 0.25, by * 0.45]
         d.tgt_bin[:] = [bx * 0.35, bx * 0.6, by * -0.45, by * -0.25]
+        if env_id == "HumanObjectInspectionCart":   # human_object_inspection_cartesian_env.py:695-710
+            d.obj_bin[:] = [bx * 0.35, bx * 0.75, -by * 0.15, by * 0.15]
+            d.object_at_target_reward = float(kw["object_at_target_reward"])
+            d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])
         # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]
         d.obj_z = 0.8 + d.box_half
         d.tgt_z = 0.8 + 0.5 * size[2] + d.box_half

@@ -74,6 +74,7 @@ extern "C" {
 #define HRG_NVT (HRG_NV + HRG_NBOXV)
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
+#define HRG_MAX_LOOP 4     /* layered sines of an animation loop (utils/animation_utils.py:91-119) */
 
 /* info columns (human_env.py:752-763 + TimeLimit + sim crash) */
 enum {
@@ -100,7 +101,9 @@ enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 
 /* geom classes used by the contact classifier (human_env.py:948-964) */
 /* tasks: ReachHuman (reach_human_env.py), PickPlaceHumanCart (pick_place_human_cartesian_env.py) */
-enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1 };
+enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */ };
+/* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
+enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
 
 enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
 
@@ -228,6 +231,7 @@ typedef struct hrg_model_desc {
   double obj_bin[4], tgt_bin[4]; /* xmin xmax ymin ymax of the sampling bins (843-875) */
   double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
   double object_gripped_reward;
+  double object_at_target_reward, goal_exit_tolerance; /* HumanObjectInspectionCart, human_object_inspection_cartesian_env.py:318-321 */
   double finger_qpos_range[2][HRG_NFINGER]; /* RethinkValidGripper.qpos_range, rethink_valid_gripper.py:29-42 */
   /* ---- Cartesian action front-end (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py:26-142;
    *      config/wrappers/ik_position_delta/default_ik_position_delta.yaml).  When enabled an action row is
@@ -258,6 +262,14 @@ typedef struct hrg_clip_table {
   double clip_quat[HRG_MAX_CLIPS][4];  /* (x,y,z,w) */
   const double* frames;                /* host pointer, [total_frames][HRG_FRAME_DIM] */
   int64_t total_frames;
+  /* per-clip entries of the animation info files the collaboration tasks read (human_object_inspection_cartesian_env.py:447-459,
+   * 602-652; utils/animation_utils.py:122-176); zero for clips without them */
+  int32_t clip_keyframes[HRG_MAX_CLIPS][2];
+  double clip_target_pos[HRG_MAX_CLIPS][3];
+  int32_t clip_n_loop[HRG_MAX_CLIPS];
+  double clip_loop_amp[HRG_MAX_CLIPS][HRG_MAX_LOOP];
+  double clip_loop_speed[HRG_MAX_CLIPS][HRG_MAX_LOOP];
+  double clip_loop_amp_std[HRG_MAX_CLIPS], clip_loop_speed_std[HRG_MAX_CLIPS];
 } hrg_clip_table;
 
 typedef struct hrg_batch hrg_batch; /* opaque */

@@ -88,6 +88,8 @@ typedef struct hrg_box_state {
   double target[3];
   int32_t obj_index, tgt_index; /* _object_placements_list_index, _target_positions_index */
   int32_t gripped;              /* _check_grasp at the last substep */
+  int32_t task_phase;           /* HRG_PHASE_* (HumanObjectInspectionCart) */
+  int32_t n_delayed;            /* _n_delayed_timesteps: frames the loop phase held the animation back */
   int32_t pad_;
 } hrg_box_state;
 

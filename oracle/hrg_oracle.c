@@ -101,7 +101,7 @@ static double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t st
   h = mix64(h ^ (stream * 0xABC98388FB8FAC03ULL + idx));
   return (double)(h >> 11) * (1.0 / 9007199254740992.0);
 }
-enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6 };
+enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6, STREAM_LOOP = 7 };
 static double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
   return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * PI * u2);
@@ -353,13 +353,42 @@ static int clip_of(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int
   return c >= b->m.n_clips ? b->m.n_clips - 1 : c;
 }
 
-static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, double* mocap_pos, double* mocap_quat, const double** qh) {
+/* amplitude (speed = 0) or speed modifier (1) of layered sine k of the loop of animation slot ai in this episode:
+ * sample_animation_loop_properties (utils/animation_utils.py:122-176): info value x exp(clip(N(0,1), -3, 3) log(std factor)); drawn
+ * counter-based on demand instead of as lists filled at reset */
+static double loop_prop(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int ai, int clip, int k, int speed) {
+  const hrg_clip_table* c = &b->clips;
+  double base = speed ? c->clip_loop_speed[clip][k] : c->clip_loop_amp[clip][k];
+  double sf = speed ? c->clip_loop_speed_std[clip] : c->clip_loop_amp_std[clip];
+  double z = clampd(rng_gauss(b->m.seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_LOOP, (uint64_t)((ai * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
+  return base * exp(z * log(sf));
+}
+
+static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, double* mocap_pos, double* mocap_quat, const double** qh) {
   const hrg_model_desc* m = &b->m;
   /* human_env.py:1719-1731 */
   int control_time = (int)floor((double)s->low_level_time / m->anim_step_length);
   int at = control_time - s->anim_start_time;
-  s->animation_time = at;
   int clip = clip_of(b, gid, s, s->anim_index);
+  if (m->task == HRG_TASK_INSPECTION) { /* HumanObjectInspectionCart._compute_animation_time, human_object_inspection_cartesian_env.py:602-652 */
+    const int classic = at, k0 = b->clips.clip_keyframes[clip][0], k1 = b->clips.clip_keyframes[clip][1], len = b->clips.clip_len[clip];
+    if (at > k0 && bx->task_phase == HRG_PHASE_APPROACH) bx->task_phase = HRG_PHASE_READY;
+    if (bx->task_phase == HRG_PHASE_READY) { /* idle loop around the first keyframe: layered_sin_modulations, utils/animation_utils.py:62-119 */
+      const int nl = b->clips.clip_n_loop[clip];
+      double sum = 0;
+      for (int k = 0; k < nl; k++) {
+        const double A = loop_prop(b, gid, s, s->anim_index, clip, k, 0), S = loop_prop(b, gid, s, s->anim_index, clip, k, 1);
+        sum += A * sin((double)(classic - k0) / (A / S)) + (double)k0;
+      }
+      at = (int)(sum - (double)k0 * (double)(nl - 1));
+      bx->n_delayed = classic - at;
+    } else at -= bx->n_delayed;
+    if (at > k1) bx->task_phase = HRG_PHASE_RETREAT;
+    if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0; /* a loop amplitude larger than the first keyframe must not index before the clip */
+    for (int a = 0; a < 3; a++) bx->target[a] = b->clips.clip_target_pos[clip][a] + s->human_pos_offset[a]; /* target_pos property, 447-459 */
+  }
+  s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
     s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
     s->animation_time = 0;
@@ -1306,11 +1335,15 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   eef_of(m, &k, s->eef_pos);
   shield_reset(m, s, s->qpos); /* FailsafeController.reset, failsafe_controller.py:204-250 */
   for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
-  hrg_box_state* bx = m->task == HRG_TASK_PICK_PLACE ? &B->box[e] : NULL;
+  hrg_box_state* bx = m->task != HRG_TASK_REACH ? &B->box[e] : NULL;
   if (bx) { /* PickPlaceHumanCart._reset_internal: first object placement and target, object at rest */
     memset(bx, 0, sizeof *bx);
     placement_of(B, gid, episode, 0, 0, bx->pos);
     placement_of(B, gid, episode, 0, 1, bx->target);
+    if (m->task == HRG_TASK_INSPECTION) { /* the target comes with the animation (info json), not from a bin */
+      const int clip = clip_of(B, gid, s, 0);
+      for (int a = 0; a < 3; a++) bx->target[a] = B->clips.clip_target_pos[clip][a] + s->human_pos_offset[a];
+    }
     bx->quat[0] = 1;
     v3cpy(bx->obs_pos, bx->pos);
   } else goal_of(B, gid, s, 0, s->cur_goal);
@@ -1329,7 +1362,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   robot_kin k;
   human_kin hk;
   double M[NV * NV], bias[NV];
-  hrg_box_state* bx = m->task == HRG_TASK_PICK_PLACE ? &B->box[e] : NULL;
+  hrg_box_state* bx = m->task != HRG_TASK_REACH ? &B->box[e] : NULL;
   const int nvt = bx ? NVT : NV, ncon_dyn = bx ? HRG_NCON_DYN_BOX : HRG_NCON_DYN;
   for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
     /* ---- sim.forward() #1 (human_env.py:504): positions, M, bias at the current state ---- */
@@ -1368,7 +1401,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     /* ---- _control_human + sim.forward() #2 (human_env.py:516-519) ---- */
     double mp[3], mq[4];
     const double* qh;
-    human_control(B, gid, s, mp, mq, &qh);
+    human_control(B, gid, s, bx, mp, mq, &qh);
     human_fk(m, mp, mq, qh, &hk, s->human_site);
     /* ---- contacts + bookkeeping (human_env.py:522) ---- */
     contact_t con[HRG_NCON_MAX];
@@ -1497,8 +1530,14 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   if (bx) { /* PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611) */
     double e2o = 0, o2t = 0;
     for (int a = 0; a < 3; a++) { e2o += (bx->obs_pos[a] - s->eef_pos[a]) * (bx->obs_pos[a] - s->eef_pos[a]); o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]); }
-    goal_reached = !crash && sqrt(o2t) <= m->goal_dist; /* _check_object_in_target_zone, 550-572 */
-    r = goal_reached ? m->task_reward : (bx->gripped ? m->object_gripped_reward : -1.0); /* _sparse_reward, 471-500 */
+    const int in_zone = sqrt(o2t) <= m->goal_dist; /* _check_object_in_target_zone, 550-572 */
+    if (m->task == HRG_TASK_INSPECTION) { /* success = the inspection animation ran to its end; human_object_inspection_cartesian_env.py:553-600 */
+      goal_reached = !crash && bx->task_phase == HRG_PHASE_COMPLETE;
+      r = goal_reached ? m->task_reward : (in_zone ? m->object_at_target_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
+    } else {
+      goal_reached = !crash && in_zone;
+      r = goal_reached ? m->task_reward : (bx->gripped ? m->object_gripped_reward : -1.0); /* _sparse_reward, 471-500 */
+    }
     dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1; /* _dense_reward, 502-526 */
   } else {
     for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
@@ -1532,7 +1571,24 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   info[HRG_INFO_SIM_CRASH] = crash;
   info[HRG_INFO_TRUNCATED] = 0;
   info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
-  if (goal_reached && bx) { /* _on_goal_reached, pick_place_human_cartesian_env.py:440-453: next target, object teleported to its next placement (velocity kept) */
+  if (bx && m->task == HRG_TASK_INSPECTION) {
+    double o2t = 0;
+    for (int a = 0; a < 3; a++) o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]);
+    if (goal_reached && !m->done_at_success) { /* _on_goal_reached, human_object_inspection_cartesian_env.py:492-505: next placement, next animation */
+      bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
+      placement_of(B, gid, s->episode, bx->obj_index, 0, bx->pos);
+      bx->quat[0] = 1; bx->quat[1] = bx->quat[2] = bx->quat[3] = 0;
+      s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* _progress_to_next_animation, human_env.py:1698-1708 + 663-670 */
+      s->animation_time = 0;
+      s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+      bx->task_phase = HRG_PHASE_APPROACH;
+      bx->n_delayed = 0;
+    }
+    /* HumanObjectInspectionCart.step, 461-490: the inspection starts when the object enters the target zone and is interrupted
+     * when it leaves it by more than goal_exit_tolerance */
+    if (bx->task_phase == HRG_PHASE_READY && sqrt(o2t) <= m->goal_dist) bx->task_phase = HRG_PHASE_INSPECTION;
+    else if (bx->task_phase == HRG_PHASE_INSPECTION && !(sqrt(o2t) - m->goal_exit_tolerance <= m->goal_dist)) bx->task_phase = HRG_PHASE_READY;
+  } else if (goal_reached && bx) { /* _on_goal_reached, pick_place_human_cartesian_env.py:440-453: next target, object teleported to its next placement (velocity kept) */
     bx->tgt_index = (bx->tgt_index + 1) % m->n_targets;
     bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
     placement_of(B, gid, s->episode, bx->tgt_index, 1, bx->target);

@@ -67,7 +67,8 @@ def assert_state_close(so, sg, what=""):
     if hasattr(so, "ltt"):
         keep = np.array([not (nm.startswith("st.ltt.dur") or nm.startswith("st.ltt.jerk")) for nm in names[0]])
         fo, fg, names = fo[keep], fg[keep], ([nm for nm, k in zip(names[0], keep) if k], names[1])
-        np.testing.assert_allclose(_ltt_samples(sg.ltt), _ltt_samples(so.ltt), rtol=RTOL, atol=1e-6, err_msg=f"long-term trajectory differs {what}")
+        # sampled q'' values sit on piecewise-linear ramps of slope j_max = 15 rad/s^3: a 1e-6 s shift of a segment boundary moves them by 1.5e-5
+        np.testing.assert_allclose(_ltt_samples(sg.ltt), _ltt_samples(so.ltt), rtol=1e-4, atol=2e-5, err_msg=f"long-term trajectory differs {what}")
     bad_i = [f"{names[1][k]}: oracle {io[k]} hip {ig[k]}" for k in np.nonzero(io != ig)[0][:12]]
     assert not bad_i, f"integer state differs {what}: {bad_i}"
     # segment durations of a planned profile are square roots of velocity differences: a ramp of ~1e-10 rad/s has a

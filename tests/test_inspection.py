@@ -1,0 +1,111 @@
+"""HumanObjectInspectionCart (environments/manipulation/human_object_inspection_cartesian_env.py): phase state machine, idle loop of the
+human animation (layered sines, utils/animation_utils.py:62-176), rewards, progress to the next animation on success.
+CPU tests run the oracle; the `gpu` test checks the HIP kernel against it.  PARITY UNPINNED (no reference fixtures for this path)."""
+import numpy as np
+import pytest
+
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd._cstruct import CONST
+from pp_scenarios import put_box
+
+INSP = dict(env_id="HumanObjectInspectionCart")
+APPROACH, READY, INSPECTION, RETREAT, COMPLETE = range(5)
+
+
+def _clips():
+    return hrg.synthetic_clips(2, seed=0, min_frames=300, max_frames=400, inspection=True)
+
+
+def _scenario(k, batches, n_envs):
+    """Even envs hold the cube at the target from step 12 to 16 and again from step 30 on; odd envs never deliver it."""
+    if (12 <= k < 17) or k >= 30:
+        for e in range(0, n_envs, 2):
+            bx = batches[0].get_box(e)
+            put_box(batches, e, pos=list(bx.target), vel=[0] * 6, zero_warm=False)
+    elif k == 17:
+        for e in range(0, n_envs, 2):
+            bx = batches[0].get_box(e)
+            put_box(batches, e, pos=[bx.target[0], bx.target[1] + 0.4, 0.845], vel=[0] * 6, zero_warm=False)
+    return np.zeros((n_envs, 7))
+
+
+def test_desc_and_clip_info():
+    clips = _clips()
+    d = hrg.build_model_desc(None, n_clips=clips.n_clips, **INSP)
+    assert d.task == CONST["HRG_TASK_INSPECTION"] and d.n_anim_ids == 20 and d.n_targets == 1 and d.horizon == 1000
+    assert d.object_at_target_reward == -1.0 and d.goal_exit_tolerance == 0.02 and list(d.human_rand) == [0.0, 0.5, 0.0]
+    np.testing.assert_allclose(list(d.obj_bin), [0.7 * 0.35, 0.7 * 0.75, -0.95 * 0.15, 0.95 * 0.15])     # 695-710
+    t = clips.table()
+    assert t.clip_n_loop[0] == 2 and t.clip_keyframes[0][0] == int(0.3 * clips.lengths[0]) and t.clip_loop_amp_std[0] == 1.1
+    staged = hrg.static_clip(10)
+    staged.infos[0] = dict(staged.infos[0], keyframes=[1, 2], loop_amplitudes={"a": [1.0]}, loop_speeds={"a": [1.0]})   # multi-stage loops: other tasks
+    with pytest.raises(NotImplementedError):
+        staged.table()
+
+
+def test_phases_loop_rewards_and_next_animation():
+    from oracle.oracle import OracleBatch
+    clips = _clips()
+    kw = dict(shield_type="OFF", horizon=400, seed=3, object_at_target_reward=-0.5, object_gripped_reward=-0.75)
+    d = hrg.build_model_desc(kw, n_clips=clips.n_clips, **INSP)
+    B = OracleBatch(d, clips, 4)
+    obs = B.reset()
+    for e in range(4):
+        s, bx = B.get_state(e), B.get_box(e)
+        np.testing.assert_allclose(list(bx.target)[1], obs[e, 51], rtol=1e-6)
+        assert abs(bx.target[0] - 0.55) < 1e-12 and abs(bx.target[1] - s.human_pos_offset[1]) <= 0.1 + 1e-12   # info target + human offset
+    hist = []
+    for k in range(70):
+        a = _scenario(k, [B], 4)
+        o, r, dn, info = B.step(a)
+        hist.append(([B.get_box(e).task_phase for e in range(4)], [B.get_state(e).animation_time for e in range(4)], r.copy(), info[:, 9].copy(),
+                     [B.get_state(e).anim_index for e in range(4)]))
+    ph = np.array([h[0] for h in hist]); at = np.array([h[1] for h in hist]); rew = np.array([h[2] for h in hist]); goals = np.array([h[3] for h in hist])
+    anim = np.array([h[4] for h in hist])
+    # odd envs: approach, then idle for ever around the first keyframe, playing back and forth
+    assert (ph[:8, 1] == APPROACH).all() and (ph[12:, 1] == READY).all() and (rew[:, 1] == -1).all()
+    idle = at[12:, 1]
+    k0s = [int(0.3 * n) for n in clips.lengths]          # whichever clip the env drew: amplitudes (25 + 8) x at most 1.1^3
+    assert any(idle.max() <= k0 + 45 and idle.min() >= k0 - 45 for k0 in k0s) and (np.diff(idle) < 0).any() and (np.diff(idle) > 0).any()
+    # even envs: the cube in the zone starts the inspection, pays object_at_target_reward; taking it out returns to READY
+    assert (ph[13:17, 0] == INSPECTION).all() and (rew[13:17, 0] == -0.5).all()
+    assert (ph[18:29, 0] == READY).all() and (rew[19:29, 0] == -1).all()
+    # delivered again: inspection resumes where the idle loop left the animation, runs through RETREAT to COMPLETE -> success
+    done_step = int(np.argmax(goals[:, 0] > 0))
+    assert done_step > 30 and rew[done_step, 0] == 1.0 and RETREAT in ph[31:done_step, 0]
+    assert np.all(np.diff(at[31:done_step - 1, 0]) > 0)
+    assert anim[done_step, 0] == 1 and ph[done_step, 0] in (APPROACH, READY) and at[done_step + 1, 0] < 40   # next animation from its start
+    bx = B.get_box(0)
+    assert bx.obj_index == 1 and not (goals[:, 1] > 0).any()
+    B.close()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_on_the_inspection_task():
+    import torch
+    from helpers import ATOL, RTOL, assert_state_close, make_pair
+    clips = _clips()
+    kw = dict(shield_type="SSM", horizon=400, seed=3, object_at_target_reward=-0.5)
+    O, G = make_pair(6, kw, clips=clips, **INSP)
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    rng = np.random.RandomState(0)
+    successes = 0
+    for k in range(70):
+        a = _scenario(k, [O, G], 6)
+        a[:, :6] = rng.uniform(-0.3, 0.3, (6, 6))
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=1e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=1e-6, err_msg=f"step {k}")
+        successes += int((r_o > 0).sum())
+        for e in range(6):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+            assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
+            if k % 8 == 7:   # re-synchronise now and then: second-derivative quantities (des_a) sit on jerk ramps and drift apart at 1e-5 after ~60 free steps
+                G.set_state(e, O.get_state(e))
+                G.set_box(e, O.get_box(e))
+    assert successes >= 3
+    O.close(); G.close()
