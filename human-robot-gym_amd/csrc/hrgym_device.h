@@ -296,6 +296,15 @@ DI double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) { double t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
   return v;
 }
+// maximum over each row of 16 lanes on the DPP network (every lane of the row receives it)
+DI double row16_max(double v) {
+  double t;
+  t = dpp_f64<0xB1, 0xf>(v); v = t > v ? t : v;    // quad_perm [1,0,3,2]
+  t = dpp_f64<0x4E, 0xf>(v); v = t > v ? t : v;    // quad_perm [2,3,0,1]
+  t = dpp_f64<0x141, 0xf>(v); v = t > v ? t : v;   // row_half_mirror
+  t = dpp_f64<0x140, 0xf>(v); v = t > v ? t : v;   // row_mirror
+  return v;
+}
 DI void wave_sync() { __syncthreads(); }  // workgroup == one wave: orders LDS traffic between lane roles
 
 // ------------------------------------------------------------------------------------------------ RNG

@@ -545,11 +545,36 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
     v3add(L.rcen[c], p, t);
   }
   wave_sync();
+  // Whole-robot cull of the 240 robot-human pairs: the box around all robot capsules, each inflated by its radius and the human
+  // contact margin, against the bounding sphere of every human capsule.  No sphere touching the box = no pair can be a contact
+  // (conservative), and the four robot-human rounds are skipped; the human usually stands clear of the arm.
+  bool human_near;
+  {
+    double bl[3], bh[3];
+    if (lane < HRG_NRCAP) {
+      const double rr = m.rcap_r[lane] + m.contact_margin_human + 1e-9;
+      for (int a = 0; a < 3; a++) {
+        const double p1 = L.rcapw[lane][a], p2 = L.rcapw[lane][3 + a];
+        bl[a] = (p1 < p2 ? p1 : p2) - rr; bh[a] = (p1 > p2 ? p1 : p2) + rr;
+      }
+    } else for (int a = 0; a < 3; a++) { bl[a] = 1e300; bh[a] = -1e300; }
+    double d2 = 0;
+    const int hb = lane < HRG_NHB ? lane : 0;
+    for (int a = 0; a < 3; a++) {
+      const double hi = __shfl(row16_max(bh[a]), 0, 64), lo = -__shfl(row16_max(-bl[a]), 0, 64);
+      const double c = 0.5 * (L.hcap[hb][a] + L.hcap[hb][3 + a]);
+      const double e = c < lo ? lo - c : (c > hi ? c - hi : 0.0);
+      d2 += e * e;
+    }
+    const double rad = dm->hcap_hl[hb] + m.hcap_r[hb] + 1e-9;
+    human_near = __any(lane < HRG_NHB && d2 <= rad * rad);
+  }
   int base = 0;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
   // rounds: 0 = robot-robot, 1..4 = robot-human (240 pairs), 5 = planes
 #pragma unroll 1
   for (int round = 0; round < 6; round++) {
+    if (round >= 1 && round <= 4 && !human_near) continue;
     bool hit = false;
     Contact c;
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
