@@ -63,6 +63,7 @@ class ClipSet:
             t.clip_pos_offset[i][:] = [float(x) for x in self.infos[i]["position_offset"]]
             t.clip_quat[i][:] = [float(x) for x in self.infos[i]["orientation_quat"]]
             info = self.infos[i]
+            t.clip_pointing_hand[i] = int(info.get("pointing_hand", "right") == "left")   # pick_place_pointing_human_cartesian_env.py:344-347
             if "keyframes" in info:   # animation info of the collaboration tasks (human_object_inspection_cartesian_env.py:447-459, 602-652)
                 amps, speeds = info.get("loop_amplitudes", []), info.get("loop_speeds", [])
                 if isinstance(amps, dict) or len(amps) > CONST["HRG_MAX_LOOP"] or len(amps) != len(speeds) or len(info["keyframes"]) < 2:

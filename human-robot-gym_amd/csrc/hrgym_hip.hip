@@ -860,6 +860,20 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   // ---- observation / success / info / reward / done ----
   double goal[NARM];
   for (int j = 0; j < NARM; j++) goal[j] = s.cur_goal[j];
+#if HRG_BOX
+  if (m.task == HRG_TASK_POINTING) { // target_pos property: the elbow -> hand ray extended to the table (pick_place_pointing_human_cartesian_env.py:336-360)
+    const int left = dm->clips.clip_pointing_hand[clip_of(dm, gid, s.episode, s.anim_index)];
+    const int sh = left ? m.site_lhand : m.site_rhand, se = left ? m.site_lelbow : m.site_relbow;
+    double dz = s.human_site[sh][2] - s.human_site[se][2];
+    if (dz == 0) dz += 1e-6;
+    const double scaling = (s.human_site[sh][2] - m.table_top_z) / dz;
+    double tv = 0;
+    if (lane < 3) { const double dl = lane == 2 ? dz : s.human_site[sh][lane] - s.human_site[se][lane]; tv = s.human_site[sh][lane] - scaling * dl; }
+    wave_sync();
+    if (lane < 3) L.bx.target[lane] = tv;
+    wave_sync();
+  }
+#endif
   write_obs(dm_, lane, goal, term_obs);
 #if HRG_BOX
   // PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611);
@@ -1126,7 +1140,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task != HRG_TASK_REACH && desc->task != HRG_TASK_PICK_PLACE && desc->task != HRG_TASK_INSPECTION) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_POINTING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
   if (desc->task == HRG_TASK_INSPECTION)
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP && clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1]))

@@ -79,9 +79,16 @@ INSPECTION_ENV_KWARGS = dict(
     object_at_target_reward=-1.0,
     goal_exit_tolerance=0.02,
 )
+# PickPlaceCloseHumanCart: PickPlaceHumanCart with clips recorded at 60 Hz (pick_place_close_human_cartesian_env.py:219-285)
+PICK_PLACE_CLOSE_ENV_KWARGS = dict(PICK_PLACE_ENV_KWARGS, human_animation_freq=60, object_gripped_reward=-1.0)
+# PickPlacePointingHumanCart + config/environment/pick_place_pointing_human_cart.yaml
+POINTING_ENV_KWARGS = dict(PICK_PLACE_ENV_KWARGS, horizon=500, object_gripped_reward=-1.0)
 ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS,
+                "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
                 "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
-BOX_TASKS = ("PickPlaceHumanCart", "HumanObjectInspectionCart")
+BOX_TASKS = ("PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart")
+_TASK_OF = {"PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
+            "PickPlacePointingHumanCart": "HRG_TASK_POINTING", "HumanObjectInspectionCart": "HRG_TASK_INSPECTION"}
 # RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
 FINGER_QPOS_RANGE = [[-0.0118366, 0.011499], [0.0118366, -0.011499]]
 
@@ -363,6 +370,8 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     d.site_lhand = HUMAN_JOINT_ELEMENTS.index("L_Hand")
     d.site_rhand = HUMAN_JOINT_ELEMENTS.index("R_Hand")
     d.site_head = HUMAN_JOINT_ELEMENTS.index("Head")
+    d.site_lelbow = HUMAN_JOINT_ELEMENTS.index("L_Elbow")
+    d.site_relbow = HUMAN_JOINT_ELEMENTS.index("R_Elbow")
     d.human_base_quat[:] = [0.5, 0.5, 0.5, 0.5]  # scipy (x,y,z,w)=(.5,.5,.5,.5) -> (w,x,y,z), human_env.py:373
     d.base_human_pos_offset[:] = [float(x) for x in kw["base_human_pos_offset"]]
     d.human_rand[:] = [float(x) for x in kw["human_rand"]]
@@ -467,7 +476,7 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.finger_qpos_range[0][f], d.finger_qpos_range[1][f] = FINGER_QPOS_RANGE[0][f], FINGER_QPOS_RANGE[1][f]
     d.task = CONST["HRG_TASK_REACH"]
     if env_id in BOX_TASKS:
-        d.task = CONST["HRG_TASK_PICK_PLACE"] if env_id == "PickPlaceHumanCart" else CONST["HRG_TASK_INSPECTION"]
+        d.task = CONST[_TASK_OF[env_id]]
         d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616
         size = [float(x) for x in kw["object_full_size"]]
         if not (size[0] == size[1] == size[2]):
@@ -480,8 +489,9 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         bx, by = 0.5 * tx - 0.05, 0.5 * ty - 0.05
         d.obj_bin[:] = [bx * 0.35, bx * 0.6, by * 0.25, by * 0.45]
         d.tgt_bin[:] = [bx * 0.35, bx * 0.6, by * -0.45, by * -0.25]
-        if env_id == "HumanObjectInspectionCart":   # human_object_inspection_cartesian_env.py:695-710
+        if env_id in ("HumanObjectInspectionCart", "PickPlacePointingHumanCart"):   # human_object_inspection_cartesian_env.py:695-710, pick_place_pointing_human_cartesian_env.py:419-434
             d.obj_bin[:] = [bx * 0.35, bx * 0.75, -by * 0.15, by * 0.15]
+        if env_id == "HumanObjectInspectionCart":
             d.object_at_target_reward = float(kw["object_at_target_reward"])
             d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])
         # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]

@@ -66,7 +66,7 @@ OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human
 # training/config/run/obs_keys of the pick-place experiments (e.g. PP-SAC): the observables the policy sees
 PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "gripper_aperture", "dist_eef_to_human_head",
                        "dist_eef_to_human_lh", "dist_eef_to_human_rh"]
-DEFAULT_OBS_KEYS = {"ReachHuman": OBS_KEYS, "PickPlaceHumanCart": PICK_PLACE_OBS_KEYS, "HumanObjectInspectionCart": PICK_PLACE_OBS_KEYS}
+DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else PICK_PLACE_OBS_KEYS) for k in ENV_DEFAULTS}
 # columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
 OBS_COLUMNS = {
     "object-state": range(0, 12), "goal_difference": range(12, 18), "robot0_joint_pos": range(18, 24),

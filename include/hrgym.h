@@ -101,7 +101,8 @@ enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 
 /* geom classes used by the contact classifier (human_env.py:948-964) */
 /* tasks: ReachHuman (reach_human_env.py), PickPlaceHumanCart (pick_place_human_cartesian_env.py) */
-enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */ };
+enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */,
+       HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */ };
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
 
@@ -170,6 +171,7 @@ typedef struct hrg_model_desc {
   double hcap_r[HRG_NHB];
   int32_t meas_body[HRG_NHJ];   /* measured joint k -> human body index (human.py:57-81 order) */
   int32_t site_lhand, site_rhand, site_head; /* indices into the measured-joint list */
+  int32_t site_lelbow, site_relbow;
   double human_base_quat[4];    /* (w,x,y,z) of Rotation.from_quat([.5,.5,.5,.5]) human_env.py:373 */
   double base_human_pos_offset[3];
   double human_rand[3];
@@ -270,6 +272,8 @@ typedef struct hrg_clip_table {
   double clip_loop_amp[HRG_MAX_CLIPS][HRG_MAX_LOOP];
   double clip_loop_speed[HRG_MAX_CLIPS][HRG_MAX_LOOP];
   double clip_loop_amp_std[HRG_MAX_CLIPS], clip_loop_speed_std[HRG_MAX_CLIPS];
+  int32_t clip_pointing_hand[HRG_MAX_CLIPS]; /* 0 right, 1 left ("pointing_hand" of the info file) */
+  int32_t pad_;
 } hrg_clip_table;
 
 typedef struct hrg_batch hrg_batch; /* opaque */

@@ -1523,6 +1523,16 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   /* ---- observation, success, info, reward, done (human_env.py:561-581) ---- */
   double goal[NARM];
   memcpy(goal, s->cur_goal, sizeof goal);
+  if (bx && m->task == HRG_TASK_POINTING) { /* target_pos property: the elbow -> hand ray extended to the table (pick_place_pointing_human_cartesian_env.py:336-360) */
+    const int left = B->clips.clip_pointing_hand[clip_of(B, gid, s, s->anim_index)];
+    const double* hand = s->human_site[left ? m->site_lhand : m->site_rhand];
+    const double* elbow = s->human_site[left ? m->site_lelbow : m->site_relbow];
+    double dir[3];
+    v3sub(dir, hand, elbow);
+    if (dir[2] == 0) dir[2] += 1e-6;
+    const double scaling = (hand[2] - m->table_top_z) / dir[2];
+    for (int a = 0; a < 3; a++) bx->target[a] = hand[a] - scaling * dir[a];
+  }
   compute_obs(m, s, bx, goal, term_obs);
   double dist2 = 0, dense;
   int goal_reached;

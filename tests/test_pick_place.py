@@ -192,3 +192,39 @@ def test_vec_env_serves_the_pp_sac_observation_layout():
     env2 = HipVecEnv(2, env_id="PickPlaceHumanCart", env_kwargs=kw, clips=clips, obs_keys=["object_pos", "target_pos", "robot0_eef_pos"],
                      backend=OracleBackend(hrg.build_model_desc(kw, n_clips=clips.n_clips, **PP), clips, 2))
     assert env2.reset().shape == (2, 9)
+
+
+def test_pick_place_variants_close_and_pointing():
+    """PickPlaceCloseHumanCart = the same task on 60 Hz clips; PickPlacePointingHumanCart takes its target from the human: the
+    elbow -> hand ray of the pointing arm extended to the table (pick_place_pointing_human_cartesian_env.py:336-360)."""
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    for c in range(2):
+        clips.infos[c]["pointing_hand"] = "left" if c else "right"
+    dc = hrg.build_model_desc(None, n_clips=2, env_id="PickPlaceCloseHumanCart")
+    assert dc.task == CONST["HRG_TASK_PICK_PLACE"] and abs(dc.anim_step_length - 250 / 60) < 1e-12
+    kw = dict(shield_type="OFF", seed=5, human_rand=[0.2, 0.2, 0.5])
+    d = hrg.build_model_desc(kw, n_clips=2, env_id="PickPlacePointingHumanCart")
+    assert d.task == CONST["HRG_TASK_POINTING"] and d.horizon == 500
+    np.testing.assert_allclose(list(d.obj_bin), [0.7 * 0.35, 0.7 * 0.75, -0.95 * 0.15, 0.95 * 0.15])
+    t = clips.table()
+    assert [t.clip_pointing_hand[0], t.clip_pointing_hand[1]] == [0, 1]
+    B = OracleBatch(d, clips, 6)
+    B.reset()
+    seen = set()
+    for k in range(4):
+        obs, r, dn, info = B.step(np.zeros((6, 7)))
+        for e in range(6):
+            s = B.get_state(e)
+            best = None
+            for left in (0, 1):
+                hand = np.array(s.human_site[d.site_lhand if left else d.site_rhand])
+                elbow = np.array(s.human_site[d.site_lelbow if left else d.site_relbow])
+                dirv = hand - elbow
+                tgt = hand - (hand[2] - d.table_top_z) / dirv[2] * dirv
+                if np.allclose(obs[e, 50:53], tgt, rtol=1e-5, atol=1e-6):
+                    best = left
+            assert best is not None and abs(obs[e, 52] - d.table_top_z) < 1e-6
+            seen.add(best)
+            np.testing.assert_allclose(obs[e, 43:46], obs[e, 50:53] - np.array(s.eef_pos), rtol=1e-5, atol=1e-6)
+    assert seen == {0, 1}                       # both pointing hands occur over the envs' clips
+    B.close()
