@@ -27,8 +27,6 @@ def make_vec_env(
     wrapper_kwargs: Optional[Dict[str, Any]] = None,
 ) -> HipVecEnv:
     assert type in ["env", "goal_env"], "The type of environment must be either 'env' or 'goal_env'."
-    if type == "goal_env":
-        raise NotImplementedError("GoalEnvironmentGymWrapper (HER) is outside this round's scope (SURVEY.md §2 #20)")
     if wrapper_class is not None:
         raise NotImplementedError("per-env gym wrappers cannot wrap a batched env; pass vec_env_kwargs=dict(collision_prevention="
                                   "dict(replace_type=0, n_resamples=20)) for the CollisionPreventionWrapper of config/wrappers/safe.yaml")
@@ -36,4 +34,4 @@ def make_vec_env(
         raise NotImplementedError("monitor csv files are not written; episode stats are in infos[i]['episode']")
     kw = dict(vec_env_kwargs or {})
     # SB3 seeds env rank r with seed + r; here streams are keyed by (seed, global env id), ids start at start_index
-    return HipVecEnv(n_envs=n_envs, env_id=env_id, env_kwargs=env_kwargs, obs_keys=obs_keys, seed=seed, env_id0=start_index, expert_obs_keys=expert_obs_keys, **kw)
+    return HipVecEnv(n_envs=n_envs, env_id=env_id, env_kwargs=env_kwargs, obs_keys=obs_keys, seed=seed, env_id0=start_index, expert_obs_keys=expert_obs_keys, goal_env=(type == "goal_env"), **kw)

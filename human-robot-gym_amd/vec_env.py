@@ -55,6 +55,16 @@ except Exception:  # noqa: BLE001
             x = np.asarray(x)
             return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
 
+try:  # pragma: no cover
+    _DictSpace = _spaces.Dict
+except Exception:  # noqa: BLE001
+    class _DictSpace:
+        def __init__(self, spaces):
+            self.spaces = dict(spaces)
+
+        def __getitem__(self, k):
+            return self.spaces[k]
+
 INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "collision", "collision_type", "n_collisions", "n_collisions_static", "n_collisions_robot", "n_collisions_human",
     "n_collisions_critical", "timeout", "failsafe_interventions", "n_goal_reached", "TimeLimit.truncated", "sim_crash",
@@ -134,10 +144,21 @@ class HipVecEnv(_VecEnvBase):
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
-                 expert_obs_keys=None):
+                 expert_obs_keys=None, goal_env=False):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
+        # GoalEnvironmentGymWrapper (wrappers/goal_env_wrapper.py): dict observations {observation, achieved_goal, desired_goal} and an
+        # externalised reward for hindsight relabelling.  Goals per task: ReachHuman joint angles (reach_human_env.py:477-507),
+        # the cube tasks [eef_pos, object_pos, object_gripped] vs target_pos (pick_place_human_cartesian_env.py:574-611)
+        self.goal_env = bool(goal_env)
+        if self.goal_env:
+            if env_id == "HumanObjectInspectionCart":
+                raise NotImplementedError("goal_env: the inspection task's success is a task phase, not a function of the goals")
+            if obs_keys is None:  # goal_env_wrapper.py:62-71
+                obs_keys = ["object-state", "robot0_proprio-state", "desired_goal"]
+            self._ag_cols = np.array(list(range(18, 24)) if env_id == "ReachHuman" else [30, 31, 32, 47, 48, 49, 39], dtype=np.int64)
+            self._dg_cols = np.array(list(range(33, 39)) if env_id == "ReachHuman" else [50, 51, 52], dtype=np.int64)
         keys = list(obs_keys) if obs_keys is not None else DEFAULT_OBS_KEYS[env_id]
         unknown = [k for k in keys if k not in OBS_COLUMNS]
         if unknown:
@@ -149,7 +170,10 @@ class HipVecEnv(_VecEnvBase):
             raise NotImplementedError(f"expert_obs_keys {bad!r}: available {sorted(OBS_COLUMNS)}")
         self.expert_obs_keys = list(expert_obs_keys) if expert_obs_keys is not None else None
         self._expert_cur = None
-        self._cols = np.array([c for k in keys for c in OBS_COLUMNS[k]], dtype=np.int64)  # GymWrapper: concatenate in key order
+        cols_of = dict(OBS_COLUMNS)
+        if env_id != "ReachHuman":
+            cols_of["desired_goal"] = OBS_COLUMNS["target_pos"]   # _get_desired_goal_from_obs of the cube tasks
+        self._cols = np.array([c for k in keys for c in cols_of[k]], dtype=np.int64)  # GymWrapper: concatenate in key order
         kw = dict(env_kwargs or {})
         if seed is not None:
             kw["seed"] = int(seed)
@@ -164,6 +188,10 @@ class HipVecEnv(_VecEnvBase):
         self._device, self._env_id0 = device, env_id0
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
         obs_space = _Box(-np.inf, np.inf, shape=(len(self._cols),), dtype=np.float32)
+        if self.goal_env:
+            goal_space = _Box(-np.inf, np.inf, shape=(len(self._dg_cols),), dtype=np.float32)
+            ag_space = _Box(-np.inf, np.inf, shape=(len(self._ag_cols),), dtype=np.float32)
+            obs_space = _DictSpace({"observation": obs_space, "desired_goal": goal_space, "achieved_goal": ag_space})
         if ik_position_delta is None:
             act_space = _Box(-1.0, 1.0, shape=(CONST["HRG_ACT_DIM"],), dtype=np.float32)
         else:  # ik_position_delta_wrapper.py:84-88: position delta limits + one gripper dof
@@ -184,7 +212,7 @@ class HipVecEnv(_VecEnvBase):
         full = np.asarray(self._backend.reset())
         if self.expert_obs_keys is not None:
             self._expert_cur = np.array(full, copy=True)
-        return full[:, self._cols]
+        return self._view(full)
 
     def step_async(self, actions):
         if self._ik is not None:  # [dx, dy, dz, gripper] in the first four columns of the 7-wide action rows
@@ -198,7 +226,7 @@ class HipVecEnv(_VecEnvBase):
     def step_wait(self):
         obs, term_obs, reward, done, info = self._backend.step_wait()
         full = np.asarray(obs)
-        obs, reward = full[:, self._cols], np.array(reward, copy=True)
+        obs, reward = self._view(full), np.array(reward, copy=True)
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
         self._ep_len += 1
@@ -229,7 +257,7 @@ class HipVecEnv(_VecEnvBase):
                 d["previous_expert_observation"] = {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in expert}
                 d["current_expert_observation"] = {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in expert}
             if done_l[i]:
-                d["terminal_observation"] = np.asarray(term_obs[i])[self._cols]
+                d["terminal_observation"] = self._view(np.asarray(term_obs[i]))
                 d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
             else:
                 del d["TimeLimit.truncated"]
@@ -262,7 +290,40 @@ class HipVecEnv(_VecEnvBase):
     def set_attr(self, attr_name, value, indices=None):
         raise NotImplementedError("per-env attributes are fixed at construction (hrg_model_desc)")
 
+    def _view(self, full):
+        """Policy view of rows of the observation superset: flat array, or the goal-env dict."""
+        full = np.asarray(full)
+        if not self.goal_env:
+            return full[..., self._cols]
+        return {"observation": full[..., self._cols], "achieved_goal": full[..., self._ag_cols], "desired_goal": full[..., self._dg_cols]}
+
+    def compute_reward(self, achieved_goal, desired_goal, info):
+        """GoalEnvironmentGymWrapper.compute_reward -> HumanEnv._compute_reward (human_env.py:629-664, 766-792), vectorised: sparse task
+        reward (+ 1 + dense reward when shaping), collision penalty from info["collision_type"], reward scale.  `info` is one dict or a
+        sequence of dicts (as SB3's HerReplayBuffer passes them)."""
+        if not self.goal_env:
+            raise NotImplementedError("compute_reward: construct with goal_env=True / make_vec_env(type='goal_env')")
+        d = self._desc
+        ag, dg = np.atleast_2d(np.asarray(achieved_goal, np.float64)), np.atleast_2d(np.asarray(desired_goal, np.float64))
+        infos = [info] if isinstance(info, dict) else list(info)
+        ctype = np.array([int(i.get("collision_type", 0)) for i in infos])
+        if self.env_id == "ReachHuman":
+            dist = np.linalg.norm(ag - dg, axis=-1)
+            r = np.where(dist <= d.goal_dist, d.task_reward, -1.0)
+            dense = -0.1 * dist
+        else:
+            e2o, o2t = np.linalg.norm(ag[:, 3:6] - ag[:, 0:3], axis=-1), np.linalg.norm(dg - ag[:, 3:6], axis=-1)
+            r = np.where(o2t <= d.goal_dist, d.task_reward, np.where(ag[:, 6] != 0, d.object_gripped_reward, -1.0))
+            dense = -(e2o * 0.2 + o2t) * 0.1
+        if d.reward_shaping:
+            r = r + 1.0 + dense
+        illegal = (ctype & (CONST["HRG_COL_STATIC"] | CONST["HRG_COL_ROBOT"] | CONST["HRG_COL_HUMAN_CRIT"])) != 0
+        r = (r + np.where(illegal, d.collision_reward, 0.0)) * d.reward_scale
+        return float(r[0]) if isinstance(info, dict) and np.ndim(achieved_goal) == 1 else r.astype(np.float32)
+
     def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        if method_name == "compute_reward":   # SB3 HerReplayBuffer: env_method("compute_reward", achieved, desired, infos, indices=[0])
+            return [self.compute_reward(*method_args, **method_kwargs) for _ in self._indices(indices)]
         raise NotImplementedError(f"env_method({method_name!r}) is not available on the batched stepper")
 
     def env_is_wrapped(self, wrapper_class, indices=None):

@@ -68,7 +68,7 @@ def test_unsupported_configurations_fail_loudly():
     with pytest.raises(NotImplementedError):
         HipVecEnv(2, obs_keys=["robot0_eef_quat"], backend=object())
     with pytest.raises(NotImplementedError):
-        make_vec_env("ReachHuman", type="goal_env")
+        make_vec_env("HumanObjectInspectionCart", type="goal_env", vec_env_kwargs=dict(backend=object()))
     with pytest.raises(AssertionError):
         make_vec_env("ReachHuman", type="bogus")
     assert INFO_KEYS[8] == "failsafe_interventions"
@@ -145,3 +145,36 @@ def test_expert_observation_side_channel():
         if k == 3:
             np.testing.assert_array_equal(prev["vec_eef_to_object"], after_reset[0, 40:43])
         last_cur = cur
+
+
+@pytest.mark.parametrize("env_id", ["ReachHuman", "PickPlaceHumanCart"])
+@pytest.mark.parametrize("shaping", [False, True])
+def test_goal_env_type_serves_her(env_id, shaping):
+    """make_vec_env(type="goal_env") = GoalEnvironmentGymWrapper (wrappers/goal_env_wrapper.py): dict observations and the invariant
+    reward == compute_reward(achieved_goal, desired_goal, info) (goal_env_wrapper.py:172-190), also after relabelling."""
+    from human_robot_gym_amd.env_util import make_vec_env
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    kw = dict(shield_type="OFF", horizon=12, seed=6, reward_shaping=shaping, collision_reward=-3.0, goal_dist=0.5)
+    desc = hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=env_id)
+    env = make_vec_env(env_id, type="goal_env", n_envs=6, env_kwargs=kw, vec_env_kwargs=dict(clips=clips, backend=OracleBackend(desc, clips, 6)))
+    gdim, adim = (6, 6) if env_id == "ReachHuman" else (3, 7)
+    obs = env.reset()
+    assert set(obs) == {"observation", "achieved_goal", "desired_goal"}
+    assert obs["desired_goal"].shape == (6, gdim) and obs["achieved_goal"].shape == (6, adim)
+    assert obs["observation"].shape == (6, 12 + 15 + gdim)                       # object-state, robot0_proprio-state, desired_goal
+    assert env.observation_space["desired_goal"].shape == (gdim,)
+    rng = np.random.RandomState(0)
+    for k in range(12):
+        prev = obs
+        obs, rew, done, infos = env.step(rng.uniform(-1, 1, (6, 7)))
+        term = {key: np.stack([infos[i]["terminal_observation"][key] if done[i] else obs[key][i] for i in range(6)]) for key in obs}
+        r2 = env.compute_reward(term["achieved_goal"], term["desired_goal"], infos)
+        np.testing.assert_allclose(r2, rew, rtol=1e-5, atol=1e-6)
+        assert env.env_method("compute_reward", term["achieved_goal"][:2], term["desired_goal"][:2], infos[:2], indices=[0])[0].shape == (2,)
+    # hindsight relabelling: the achieved goal as the desired one is a success
+    ag = term["achieved_goal"]
+    relabeled = ag if env_id == "ReachHuman" else ag[:, 3:6]
+    r3 = env.compute_reward(ag, relabeled, [dict(collision_type=0)] * 6)
+    assert np.allclose(r3, 1.0 + (1.0 + (0.0 if env_id == "ReachHuman" else -0.02 * np.linalg.norm(ag[:, 3:6] - ag[:, :3], axis=1)) if shaping else 0.0), atol=1e-6)
+    assert isinstance(env.compute_reward(ag[0], relabeled[0], dict(collision_type=8)), float)
+    assert abs(env.compute_reward(ag[0], relabeled[0], dict(collision_type=8)) - (r3[0] - 3.0)) < 1e-6   # static collision penalty
