@@ -5,7 +5,8 @@ tag = sys.argv[1]
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 go, pr = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
 os.makedirs(pr, exist_ok=True)
-lines = [f"# rocprofv3 summary `{tag}` — `python3 bench.py --steps N --warmup W --no-cpu-baseline` (1 x MI355X, 4096 envs, SSM)", ""]
+what = sys.argv[2] if len(sys.argv) > 2 else "`python3 bench.py --steps N --warmup W --no-cpu-baseline` (1 x MI355X, ReachHuman, 4096 envs, SSM)"
+lines = [f"# rocprofv3 summary `{tag}` — {what}", ""]
 f = sorted(glob.glob(f"{go}/{tag}_trace/*/*_kernel_stats.csv"), key=os.path.getmtime, reverse=True)
 if f:
     lines += ["## `--kernel-trace --stats` (kernel_stats.csv)", "", "| kernel | calls | total ns | average ns | % | min ns | max ns |", "|---|---|---|---|---|---|---|"]
