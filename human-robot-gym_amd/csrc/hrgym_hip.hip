@@ -94,7 +94,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   const int r = lane;
   int type = 1, rdof = 0;
   bool cand = false;
-  bool rpart = true, bpart = false;  // row acts on the robot tree / on the cube
+  [[maybe_unused]] bool rpart = true, bpart = false;  // row acts on the robot tree / on the cube
   double rsgn = 0, pos = 0, margin = 0, floss = 0, diag = 0, vel = 0;
   if (r < NV) {
     if (m.jnt_frictionloss[r] > 0) {
@@ -1011,6 +1011,7 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const De
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs,
                                                      hrg_box_state* __restrict__ boxes) {
   Lds& L = g_L;
+  (void)boxes;  // the cube's state array: only the HRG_BOX variant streams it
   const int e = blockIdx.x, lane = threadIdx.x;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
@@ -1034,6 +1035,7 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const De
 __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
                                                       float* __restrict__ obs, int64_t env_id0, hrg_box_state* __restrict__ boxes) {
   Lds& L = g_L;
+  (void)boxes;
   const int e = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[e]) return;
   const double* src = (const double*)(states + e);

@@ -514,8 +514,7 @@ HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e,
   STAMP(15);
 }
 
-DI void shield_reset(const DevModel* __restrict__ dm_, int lane) {
-  const ModelPtr dm = uniform_model(dm_);
+DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
   Lds& L = g_L;
   hrg_env_state& s = L.st;
   // ltt_const + zero paths: the state block was zeroed by the caller
