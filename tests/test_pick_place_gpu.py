@@ -187,3 +187,37 @@ def test_pointing_variant_parity():
         for e in range(8):
             assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
     O.close(); G.close()
+
+
+def test_long_run_stays_finite_and_on_the_table():
+    """Soak: 2048 envs x 300 policy steps of random joint + gripper actions with auto-resets (horizon 120).  The cube must stay a
+    rigid body on or above the table (or in the gripper, or on the floor once knocked off), nothing may turn non-finite,
+    simulation crashes must stay rare."""
+    import torch
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd._lib import HipBatch
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+    n = 2048
+    d = hrg.build_model_desc(dict(shield_type="SSM", horizon=120, seed=21), n_clips=clips.n_clips, **PP)
+    G = HipBatch(d, clips, n)
+    G.reset()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    crashes = dones = 0
+    for k in range(300):
+        a = (torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda()
+        obs, r, dn, info = G.step(a)
+        if k % 25 == 24:
+            torch.cuda.synchronize()
+            o = obs.cpu().numpy()
+            assert np.isfinite(o).all() and np.isfinite(r.cpu().numpy()).all()
+            z = o[:, 49]
+            on_floor = np.abs(z - (d.floor_z + d.box_half)) < 5e-3          # knocked off the table: rests on the floor
+            odd = ~(on_floor | (z > d.table_top_z + d.box_half - 5e-3))
+            assert odd.sum() <= 2 and (z < 2.0).all(), (k, np.sort(z[odd])[:20], o[odd][:6, 47:50], int(odd.sum()))   # a cube in free fall at the sampling instant
+            assert on_floor.mean() < 0.05
+        crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item())
+    st, bx = G.get_states(np.arange(0, n, 64))
+    for b in bx:
+        assert abs(np.linalg.norm(list(b.quat)) - 1.0) < 1e-9 and np.isfinite(list(b.vel)).all()
+    assert dones >= 2 * n and crashes <= 0.002 * n * 300, (dones, crashes)
+    G.close()
