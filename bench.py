@@ -100,6 +100,7 @@ def main():
     import human_robot_gym_amd as hrg
     from human_robot_gym_amd._cstruct import CONST as C
     from human_robot_gym_amd._lib import HipBatch, load_library
+    from human_robot_gym_amd.dist import OverlappedGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -134,7 +135,18 @@ def main():
         for a in pool:
             a[:, :3] *= 0.15
     fresh = [torch.empty_like(pool[0]) for _ in range(2)]  # the kernel rewrites action rows in place when wrappers are on
-    gathered = torch.empty(world * G.packed.numel(), dtype=torch.uint8, device=dev) if world > 1 else None
+    # N > 1: every rank's packed outputs are published to all ranks with one RCCL all-gather per step on the compute stream.
+    # HRG_BENCH_GATHER_MODE=overlap moves it to a side stream (dist.OverlappedGather); measured on one MI355X that is SLOWER: the
+    # step kernel fills every workgroup slot of the chip (4096 = 256 CUs x 16), so a concurrent copy / RCCL kernel pushes part of it
+    # into a second round (2.31 instead of 1.96 ms).  HRG_BENCH_FORCE_GATHER=1 rehearses the gather path on one GPU (world size 1)
+    force = os.environ.get("HRG_BENCH_FORCE_GATHER") == "1"
+    if force and world == 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+    serial = os.environ.get("HRG_BENCH_GATHER_MODE", "serial") != "overlap"
+    gather = (True if serial else OverlappedGather(G.packed, world)) if (world > 1 or force) else None
+    gathered = torch.empty(world * G.packed.numel(), dtype=torch.uint8, device=dev) if (gather is not None and serial) else None
 
     def one_step(k):
         if args.ik:
@@ -143,8 +155,10 @@ def main():
             G.step(a)
         else:
             G.step(pool[k % len(pool)])
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, G.packed)  # one fused RCCL all-gather of obs/reward/done/info
+        if gather is not None and serial:
+            dist.all_gather_into_tensor(gathered, G.packed)
+        elif gather is not None:
+            gather.publish(G.packed, k)  # one fused RCCL all-gather of obs/reward/done/info on a side stream
 
     for k in range(args.warmup):
         one_step(k)
@@ -155,6 +169,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
+    if gather is not None and not serial:
+        gather.finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -193,7 +209,7 @@ def main():
                                    + ("Cartesian random actions through the IK front-end + collision prevention, " if args.ik else "random actions U(-1,1)^7, ")
                                    + "13 synthetic human clips, auto-reset",
                        "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
-                       "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" if world > 1 else "")},
+                       "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if serial else " on a side stream") if gather is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "hrg_step_kernel_box" if pick_place else "hrg_step_kernel", "kernel_ms": kernel_ms, "launches": n_launch,
@@ -205,6 +221,7 @@ def main():
     G.close()
     if world > 1:
         dist.barrier()
+    if world > 1 or force:
         dist.destroy_process_group()
 
 

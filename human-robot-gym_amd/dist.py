@@ -61,3 +61,59 @@ def gather_global(packed, n_local, group=None):
     g = all_gather_packed(packed, group).cpu().numpy()
     parts = [unpack(g[r], n_local) for r in range(g.shape[0])]
     return {k: np.concatenate([p[k] for p in parts], 0) for k in parts[0]}
+
+
+class OverlappedGather:
+    """Publishes every rank's packed output block to all ranks WITHOUT stalling the step kernel: the block is copied to one of two
+    staging buffers on the compute stream (2 MB device-to-device), and the RCCL all-gather of that copy runs on a side stream while
+    the next step's kernel is already executing.  xGMI is point-to-point (ring all-gather, per-link bound), so the ~2 MB per rank
+    cost about as much as 10 % of a step when serialised; overlapped they cost nothing but their HBM traffic.
+
+        og = OverlappedGather(batch.packed, world)
+        for k in ...:
+            batch.step(actions)              # compute stream
+            og.publish(batch.packed, k)      # staging copy + all-gather on the side stream
+            blocks = og.result(k - 1)        # [world, total] block of the previous step, gathered while this step ran
+    On CPU tensors (gloo tests) the same calls run synchronously."""
+
+    def __init__(self, packed, world, group=None):
+        import torch
+        self.torch, self.group, self.world = torch, group, world
+        self.cuda = packed.is_cuda
+        self.stage = [torch.empty_like(packed) for _ in range(2)]
+        self.out = [torch.empty((world, packed.numel()), dtype=torch.uint8, device=packed.device) for _ in range(2)]
+        if self.cuda:
+            self.side = torch.cuda.Stream(device=packed.device)
+            self.copied = [torch.cuda.Event() for _ in range(2)]
+            self.gathered = [torch.cuda.Event() for _ in range(2)]
+            self.used = [False, False]
+
+    def publish(self, packed, k):
+        import torch.distributed as dist
+        b = k & 1
+        if not self.cuda:
+            self.stage[b].copy_(packed)
+            self.out[b] = all_gather_packed(self.stage[b], self.group)
+            return
+        torch = self.torch
+        main = torch.cuda.current_stream(packed.device)
+        if self.used[b]:
+            main.wait_event(self.gathered[b])      # the gather of step k-2 has finished reading this staging buffer
+        self.stage[b].copy_(packed, non_blocking=True)
+        self.copied[b].record(main)
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.copied[b])
+            dist.all_gather_into_tensor(self.out[b].view(-1), self.stage[b], group=self.group)
+            self.gathered[b].record(self.side)
+        self.used[b] = True
+
+    def result(self, k):
+        """[world, total] uint8 block of step k (k or k-1 relative to the last publish); waits for that gather only."""
+        b = k & 1
+        if self.cuda:
+            self.torch.cuda.current_stream(self.out[b].device).wait_event(self.gathered[b])
+        return self.out[b]
+
+    def finish(self):
+        if self.cuda:
+            self.side.synchronize()

@@ -52,6 +52,7 @@ def _worker(rank, world, port, steps, q):
     lo, hi = hdist.shard_range(N_GLOBAL, rank, world)
     n = hi - lo
     lay = hdist.packed_layout(n)
+    og = hdist.OverlappedGather(torch.zeros(lay["total"], dtype=torch.uint8), world)
     res = []
     for obs, rew, done, info, tobs in _rollout(lo, hi, steps):
         blk = np.zeros(lay["total"], np.uint8)
@@ -59,6 +60,13 @@ def _worker(rank, world, port, steps, q):
         u["obs"][:], u["term_obs"][:], u["reward"][:], u["info"][:], u["done"][:] = obs, tobs, rew, info, done
         g = hdist.gather_global(torch.from_numpy(blk), n)
         res.append(g)
+        og.publish(torch.from_numpy(blk), len(res) - 1)     # the overlapped publisher (synchronous on CPU) must deliver the same blocks
+        blocks = og.result(len(res) - 1).numpy()
+        for r_ in range(world):
+            u2 = hdist.unpack(blocks[r_], n)
+            lo2, hi2 = hdist.shard_range(N_GLOBAL, r_, world)
+            np.testing.assert_array_equal(u2["obs"], g["obs"][lo2:hi2])
+            np.testing.assert_array_equal(u2["done"], g["done"][lo2:hi2])
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
