@@ -145,8 +145,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
     serial = os.environ.get("HRG_BENCH_GATHER_MODE", "serial") != "overlap"
-    gather = (True if serial else OverlappedGather(G.packed, world)) if (world > 1 or force) else None
-    gathered = torch.empty(world * G.packed.numel(), dtype=torch.uint8, device=dev) if (gather is not None and serial) else None
+    gather = (True if serial else OverlappedGather(G.packed_head, world)) if (world > 1 or force) else None
+    gathered = torch.empty(world * G.packed_head.numel(), dtype=torch.uint8, device=dev) if (gather is not None and serial) else None
 
     def one_step(k):
         if args.ik:
@@ -156,9 +156,9 @@ def main():
         else:
             G.step(pool[k % len(pool)])
         if gather is not None and serial:
-            dist.all_gather_into_tensor(gathered, G.packed)
+            dist.all_gather_into_tensor(gathered, G.packed_head)  # obs, reward, info, done of every rank (1.0 MB per rank)
         elif gather is not None:
-            gather.publish(G.packed, k)  # one fused RCCL all-gather of obs/reward/done/info on a side stream
+            gather.publish(G.packed_head, k)  # one fused RCCL all-gather of obs/reward/done/info on a side stream
 
     for k in range(args.warmup):
         one_step(k)

@@ -103,15 +103,15 @@ class HipBatch:
         with torch.cuda.device(self.device):
             _check(self.lib, self.lib.hrg_batch_create(ctypes.byref(desc), ctypes.byref(table), self.n, int(env_id0), device, ctypes.byref(self.h)))
             C = CONST
-            # one contiguous SoA output block so that multi-GPU runs need ONE all-gather per step:
-            # [obs f32 n*18 | term_obs f32 n*18 | reward f32 n | info i32 n*12 | done u8 n (padded)]
+            # one contiguous SoA output block so that multi-GPU runs need ONE all-gather per step (dist.packed_layout):
+            # [obs f32 n*57 | reward f32 n | info i32 n*13 | done u8 n | term_obs f32 n*57]; `packed_head` (everything but the terminal
+            # observations) is the part a step publishes to the other ranks
+            from .dist import packed_layout
             n, od, idim = self.n, C["HRG_OBS_DIM"], C["HRG_INFO_DIM"]
-            sizes = [4 * n * od, 4 * n * od, 4 * n, 4 * n * idim, n]
-            offs, tot = [], 0
-            for sz in sizes:
-                offs.append(tot)
-                tot += (sz + 255) // 256 * 256
+            lay = packed_layout(n)
+            offs, sizes, tot = lay["offsets"], lay["sizes"], lay["total"]
             self.packed = torch.zeros(tot, dtype=torch.uint8, device=self.device)
+            self.packed_head = self.packed[:lay["head"]]
             self.packed_layout = dict(offsets=offs, sizes=sizes)
             self.obs = self.packed[offs[0]:offs[0] + sizes[0]].view(torch.float32).view(n, od)
             self.term_obs = self.packed[offs[1]:offs[1] + sizes[1]].view(torch.float32).view(n, od)

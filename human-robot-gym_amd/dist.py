@@ -17,28 +17,32 @@ def shard_range(n_global, rank, world):
 
 
 def packed_layout(n):
-    """Byte layout of one rank's output block (mirrors HipBatch.packed)."""
+    """Byte layout of one rank's output block (HipBatch.packed).  Items are indexed [obs, term_obs, reward, info, done]; physically the
+    terminal observations come LAST, so that the prefix of `head` bytes (obs, reward, info, done) is what a step publishes to the other
+    ranks — terminal observations matter for the few envs that finished and stay on their rank."""
     od, idim = CONST["HRG_OBS_DIM"], CONST["HRG_INFO_DIM"]
     sizes = [4 * n * od, 4 * n * od, 4 * n, 4 * n * idim, n]
-    offs, tot = [], 0
-    for sz in sizes:
-        offs.append(tot)
-        tot += (sz + 255) // 256 * 256
-    return dict(offsets=offs, sizes=sizes, total=tot)
+    offs, tot = [0] * 5, 0
+    for item in (0, 2, 3, 4, 1):
+        offs[item] = tot
+        tot += (sizes[item] + 255) // 256 * 256
+    return dict(offsets=offs, sizes=sizes, total=tot, head=offs[1])
 
 
 def unpack(block, n):
-    """uint8 numpy block of one rank -> dict of typed views."""
+    """uint8 numpy block of one rank (whole, or only its published head) -> dict of typed views."""
     lay = packed_layout(n)
     o, s = lay["offsets"], lay["sizes"]
     od, idim = CONST["HRG_OBS_DIM"], CONST["HRG_INFO_DIM"]
-    return dict(
+    out = dict(
         obs=block[o[0]:o[0] + s[0]].view(np.float32).reshape(n, od),
-        term_obs=block[o[1]:o[1] + s[1]].view(np.float32).reshape(n, od),
         reward=block[o[2]:o[2] + s[2]].view(np.float32),
         info=block[o[3]:o[3] + s[3]].view(np.int32).reshape(n, idim),
         done=block[o[4]:o[4] + s[4]],
     )
+    if block.shape[0] >= lay["total"]:
+        out["term_obs"] = block[o[1]:o[1] + s[1]].view(np.float32).reshape(n, od)
+    return out
 
 
 def all_gather_packed(packed, group=None):

@@ -30,6 +30,10 @@ def test_packed_layout_matches_hip_batch_layout():
     blk = np.arange(lay["total"], dtype=np.uint32).astype(np.uint8)
     u = hdist.unpack(blk, 4096)
     assert u["obs"].shape == (4096, od) and u["info"].shape == (4096, CONST["HRG_INFO_DIM"]) and u["done"].shape == (4096,)
+    # the terminal observations come last: the head (obs, reward, info, done) is what a step publishes to the other ranks
+    assert lay["head"] == lay["offsets"][1] and lay["offsets"][1] > max(lay["offsets"][i] for i in (0, 2, 3, 4))
+    head = hdist.unpack(blk[:lay["head"]], 4096)
+    assert "term_obs" not in head and (head["info"] == u["info"]).all() and (head["done"] == u["done"]).all() and u["term_obs"].shape == (4096, od)
 
 
 def _rollout(lo, hi, steps, env_id="ReachHuman"):
