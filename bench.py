@@ -79,6 +79,23 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="
             "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} of {avail} host threads"}
 
 
+class _stdout_to_stderr:
+    """RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line on stdout, so the file
+    descriptor is pointed at stderr while the process group initialises and the warm-up steps run."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -109,6 +126,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     torch.cuda.set_device(local_rank)
     dist = None
+    quiet = _stdout_to_stderr()
+    quiet.__enter__()   # until the warm-up is over (RCCL banner)
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -162,6 +181,10 @@ def main():
 
     for k in range(args.warmup):
         one_step(k)
+    if gather is not None and args.warmup == 0:
+        one_step(0)      # the first collective brings the communicator up: never inside the timed region
+    torch.cuda.synchronize()
+    quiet.__exit__(None, None, None)
     G.kernel_time()  # arm + clear the HIP-event kernel timer
     if world > 1:
         dist.barrier()
