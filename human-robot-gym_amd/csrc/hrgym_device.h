@@ -145,12 +145,25 @@ struct Lds {
 #if HRG_BOX
   hrg_box_state bx;                      // the cube (streamed from its own HBM array)
   double bR[9];                          // its rotation matrix at the current substep
-  double Hb[NVT][NVT + 1];               // Newton Hessian / Cholesky factor of the 14-DoF system
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators
+#if HRG_BOX
+  union {
+    struct {  // collide -> classify / constraint-row set-up
+      double rcen[HRG_NRCAP][3];
+      Contact con[NCON_DYN];
+    };
+    // after the row set-up: Newton Hessian / Cholesky factor of the coupled 14-DoF system, packed lower triangle + reciprocal
+    // diagonal (the uncoupled fast path keeps the 8x8-padded factor of the cube block in its first 72 doubles)
+    double hbp[NVT * (NVT + 1) / 2 + NVT];
+  };
+#define HB(i, j) g_L.hbp[(i) * ((i) + 1) / 2 + (j)]
+#define HBI(k) g_L.hbp[NVT * (NVT + 1) / 2 + (k)]
+#else
   double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];
+#endif
   union {
     struct {  // shield_step
       double cq[NARM], cv[NARM], ca[NARM], qe[NARM];
@@ -639,7 +652,7 @@ DI void chol_store(double l, int lane, double* Lm, double* invd) {
   if ((lane >> 3) == (lane & 7)) invd[lane & 7] = 1.0 / l;
 }
 #if HRG_BOX
-// Cholesky of the 14x14 Newton Hessian held in g_L.Hb (lower triangle, in place; column NVT of row k receives 1 / L_kk).
+// Cholesky of the 14x14 Newton Hessian held packed in g_L.hbp (lower triangle, in place; HBI(k) receives 1 / L_kk).
 // Right-looking: the pivot column is scaled by lanes = rows, the trailing update runs over lanes = (i, j) entries (4 per
 // lane).  Same subtraction order per entry as a left-looking scalar factorisation.
 DI bool chol_box(int lane) {
@@ -653,17 +666,17 @@ DI bool chol_box(int lane) {
   }
 #pragma unroll 1
   for (int k = 0; k < NVT; k++) {
-    const double dkk = L.Hb[k][k];
+    const double dkk = HB(k, k);
     if (!(dkk > 0)) return false;
     const double piv = sqrt(dkk);
     wave_sync();
-    if (lane == k) { L.Hb[k][k] = piv; L.Hb[k][NVT] = 1.0 / piv; }
-    else if (lane > k && lane < NVT) L.Hb[lane][k] = L.Hb[lane][k] / piv;
+    if (lane == k) { HB(k, k) = piv; HBI(k) = 1.0 / piv; }
+    else if (lane > k && lane < NVT) HB(lane, k) = HB(lane, k) / piv;
     wave_sync();
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       const int i = ei[t], j = ej[t];
-      if (i >= 0 && j > k && j <= i) L.Hb[i][j] = L.Hb[i][j] - L.Hb[i][k] * L.Hb[j][k];
+      if (i >= 0 && j > k && j <= i) HB(i, j) = HB(i, j) - HB(i, k) * HB(j, k);
     }
     wave_sync();
   }
@@ -675,15 +688,15 @@ DI double chol_box_solve(double b, int lane) {
   double x = b;
 #pragma unroll 1
   for (int k = 0; k < NVT; k++) {
-    const double xk = __shfl(x, k, 64) * L.Hb[k][NVT];
+    const double xk = __shfl(x, k, 64) * HBI(k);
     if (lane == k) x = xk;
-    else if (lane > k && lane < NVT) x -= L.Hb[lane][k] * xk;
+    else if (lane > k && lane < NVT) x -= HB(lane, k) * xk;
   }
 #pragma unroll 1
   for (int k = NVT - 1; k >= 0; k--) {
-    const double xk = __shfl(x, k, 64) * L.Hb[k][NVT];
+    const double xk = __shfl(x, k, 64) * HBI(k);
     if (lane == k) x = xk;
-    else if (lane < k) x -= L.Hb[k][lane] * xk;
+    else if (lane < k) x -= HB(k, lane) * xk;
   }
   return x;
 }

@@ -271,7 +271,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
           h_is_m = false;
           wave_sync();
         }
-        double* Hs = &L.Hb[0][0];   // factor of the cube block: 64 + 8 doubles of the (idle) 14x14 buffer
+        double* Hs = L.hbp;         // factor of the cube block: 64 + 8 doubles of the (idle) Hessian buffer
         {
           const double sl = chol_lanes(sval, lane, &ok);
           if (!ok) break;
@@ -295,7 +295,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
           const double hq = L.rh[ROW_CON0 + q];
           if (hq != 0) hv += hq * L.Jc[q][i] * L.Jc[q][j];
         }
-        L.Hb[i][j] = hv;
+        if (j <= i) HB(i, j) = hv;
       }
       wave_sync();
       STAMP(23);
