@@ -64,8 +64,17 @@ class ClipSet:
             t.clip_quat[i][:] = [float(x) for x in self.infos[i]["orientation_quat"]]
             info = self.infos[i]
             t.clip_pointing_hand[i] = int(info.get("pointing_hand", "right") == "left")   # pick_place_pointing_human_cartesian_env.py:344-347
+            t.clip_holding_hand[i] = int(info.get("object_holding_hand", "right") == "left")   # human_robot_handover_cartesian_env.py:459-463
             if "keyframes" in info:   # animation info of the collaboration tasks (human_object_inspection_cartesian_env.py:447-459, 602-652)
                 amps, speeds = info.get("loop_amplitudes", []), info.get("loop_speeds", [])
+                if isinstance(amps, dict) and set(amps) == {"present", "wait"}:   # handover clips: two loop stages (440-457)
+                    a2, s2 = amps["wait"], speeds["wait"]
+                    if len(a2) > CONST["HRG_MAX_LOOP"] or len(a2) != len(s2):
+                        raise NotImplementedError("animation info: up to 4 layered loop sines per stage")
+                    t.clip_n_loop2[i] = len(a2)
+                    for k in range(len(a2)):
+                        t.clip_loop2_amp[i][k], t.clip_loop2_speed[i][k] = float(a2[k]), float(s2[k])
+                    amps, speeds = amps["present"], speeds["present"]
                 if isinstance(amps, dict) or len(amps) > CONST["HRG_MAX_LOOP"] or len(amps) != len(speeds) or len(info["keyframes"]) < 2:
                     raise NotImplementedError("animation info: need two keyframes and up to 4 layered loop sines given as lists")
                 t.clip_keyframes[i][:] = [int(info["keyframes"][0]), int(info["keyframes"][1])]
@@ -81,7 +90,7 @@ class ClipSet:
         return t
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False):
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -114,6 +123,10 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         if inspection:  # stand-in for the ObjectInspection/* info files: approach until 30 %, inspect until 70 %, idle loop of two layered sines
             info.update(keyframes=[int(0.3 * n), int(0.7 * n)], target_pos=[0.55, float(rng.uniform(-0.1, 0.1)), 1.15],
                         loop_amplitudes=[25.0, 8.0], loop_speeds=[1.0, 0.45], loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        if handover:    # stand-in for the HumanRobotHandover/* info files: present from 30 %, wait at 60 %, two loop stages
+            info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
+                        loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
+                        loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
         clips.append((anim, info))
     return ClipSet(clips)
 

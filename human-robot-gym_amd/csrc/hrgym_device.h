@@ -132,7 +132,12 @@ struct Contact {
 
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
-#define NROW (ROW_CON0 + 4 * NCON_DYN)
+#define ROW_WELD0 (ROW_CON0 + 4 * NCON_DYN)   // 6 equality rows of the object <-> hand weld (cube variant: lanes 56..61)
+#if HRG_BOX
+#define NROW (ROW_WELD0 + 6)
+#else
+#define NROW ROW_WELD0
+#endif
 
 // per-workgroup (= per-env) LDS image.  Sized to <= 10 KB so that 16 envs (4 waves/SIMD) are resident per CU:
 // 4096 envs on 256 CUs then run in one round.  Phase-local scratch shares one union.
@@ -145,6 +150,7 @@ struct Lds {
 #if HRG_BOX
   hrg_box_state bx;                      // the cube (streamed from its own HBM array)
   double bR[9];                          // its rotation matrix at the current substep
+  double hand_q[4];                      // orientation of the hand mocap body computed with the human tree (handover tasks)
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators

@@ -34,7 +34,8 @@ DI void impedance(const MD& m, double x0, double* imp) {  // the stiffness / dam
 
 // lim = floss / D of a friction row, computed once per row and substep (an FP64 division is a ~30-instruction sequence)
 DI void row_cost(int type, double D, double floss, double lim, double x, double* c, double* g, double* h) {
-  if (type == 1) {
+  if (type == 2) { *c = 0.5 * D * x * x; *g = D * x; *h = D; }  // equality (weld) row: quadratic on both sides
+  else if (type == 1) {
     if (x < 0) { *c = 0.5 * D * x * x; *g = D * x; *h = D; } else { *c = 0; *g = 0; *h = 0; }
   } else {
     if (x <= -lim) { *c = floss * (-x - 0.5 * lim); *g = -floss; *h = 0; }
@@ -44,6 +45,7 @@ DI void row_cost(int type, double D, double floss, double lim, double x, double*
 }
 
 DI int row_zone(int type, double lim, double x) {  // which quadratic / linear piece of its cost a row is in
+  if (type == 2) return 0;
   if (type == 1) return x < 0;
   return x <= -lim ? -1 : (x >= lim ? 1 : 0);
 }
@@ -108,7 +110,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       cand = true; pos = dist; diag = m.dof_invweight0[dof];
       rdof = dof; rsgn = side ? -1.0 : 1.0; vel = rsgn * s.qvel[dof];
     }
-  } else if (r < NROW) {
+  } else if (r < ROW_WELD0) {
     const int c = (r - ROW_CON0) >> 2, d = (r - ROW_CON0) & 3;
     if (c < ncon && c < NCON_DYN) {
       const Contact& cc = L.con[c];
@@ -162,8 +164,26 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       cand = nz > 0;
     }
   }
+#if HRG_BOX
+  else if (r < NROW && bx.weld_active) { // weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
+                                         // [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; unit rows on the cube's own DoF, the mocap body has no velocity
+    const int a = r - ROW_WELD0;
+    if (a < 3) pos = bx.pos[a] - bx.mocap_pos[a];
+    else {
+      const double qc[4] = {bx.mocap_quat[0], -bx.mocap_quat[1], -bx.mocap_quat[2], -bx.mocap_quat[3]}, qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]};
+      double qe[4];
+      quatmul(qe, qo, qc);
+      if (qe[0] < 0) for (int k = 0; k < 4; k++) qe[k] = -qe[k];
+      const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+      pos = sn > 1e-12 ? qe[1 + (a - 3)] / sn * ang : 0.0;
+    }
+    cand = true; type = 2; rpart = false;
+    diag = a < 3 ? 1.0 / m.box_mass : 1.0 / m.box_inertia;
+    rdof = NV + a; rsgn = 1.0; vel = bx.vel[a];
+  }
+#endif
   const bool active = cand && diag > 0;
-  const bool is_con = r >= ROW_CON0;
+  const bool is_con = r >= ROW_CON0 && r < ROW_WELD0;
   double aref = 0, D = 0, flim = 0;
   if (active) {
     double imp;
@@ -240,6 +260,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         double t = -L.Ma0[lane] + mdiag * L.qacc[lane];
         gm = t;
         for (uint64_t mm = bmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+        t += L.rg[ROW_WELD0 + lane - NV];   // weld row of this DoF (0 when the weld is off)
         L.g[lane] = t;
       }
       wave_sync();
@@ -257,6 +278,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
           if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
         }
         double sval = mi == mj ? (mi < 3 ? m.box_mass : (mi < HRG_NBOXV ? m.box_inertia : 1.0)) : 0.0;
+        if (mi == mj && mi < HRG_NBOXV) sval += L.rh[ROW_WELD0 + mi];
         if (mi < HRG_NBOXV && mj < HRG_NBOXV)
           for (uint64_t mm = bmask; mm;) {
             const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
@@ -290,6 +312,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         const int i = e / NVT, j = e - i * NVT;
         double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j ? (i - NV < 3 ? m.box_mass : m.box_inertia) : 0.0);
         if (i == j && i < NV) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; }
+        if (i == j && i >= NV) hv += L.rh[ROW_WELD0 + i - NV];
         for (uint64_t mm = cmask; mm;) {
           const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
           const double hq = L.rh[ROW_CON0 + q];
@@ -683,6 +706,23 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
 }
 
 #if HRG_BOX
+// The human takes the object: pose of the holding hand at the current animation frame -> mocap body, object teleported into it, weld
+// on (_control_human + _human_pickup_object, human_robot_handover_cartesian_env.py:598-633, 700-711).  The reference teleports to the stale
+// mocap pose first and lets the weld drag the object over; here the fresh hand pose is used directly.
+DI void handover_pickup(const DevModel* __restrict__ dm_, int lane, int64_t gid, bool at_reset) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  human_control(dm_, lane, gid);   // human pose + L.hand_q
+  const int hl = dm->clips.clip_holding_hand[clip_of(dm, gid, L.st.episode, L.st.anim_index)];
+  const int site = hl ? m.site_lhand : m.site_rhand;
+  wave_sync();
+  hrg_box_state& bx = L.bx;
+  if (lane < 3) { const double p = L.st.human_site[site][lane]; bx.mocap_pos[lane] = p; bx.pos[lane] = p; if (at_reset) bx.obs_pos[lane] = p; }
+  if (lane < 4) { const double q = L.hand_q[lane]; bx.mocap_quat[lane] = q; bx.quat[lane] = q; }
+  bx.weld_active = 1;
+  wave_sync();
+}
 // i-th object placement / target of an episode (UniformRandomSampler over the bins, pick_place_human_cartesian_env.py:613-635,
 // 843-875), counter-based; wave-uniform
 DI void placement_of(ModelPtr dm, int64_t gid, int episode, int idx, int target, double* p) {
@@ -748,6 +788,7 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     if (lane < 3) { bx.pos[lane] = po[lane]; bx.obs_pos[lane] = po[lane]; bx.target[lane] = pt[lane]; }
     if (lane == 0) bx.quat[0] = 1.0;
     wave_sync();
+    if (m.task == HRG_TASK_HANDOVER_H2R) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (635-647, 686-711)
   }
 #else
   goal_sample(dm_, lane, gid, 0);
@@ -816,15 +857,43 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
   STAMP(4);
   int ncon = 0;
+  int crash = 0;
+#if HRG_BOX
+  // HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human pose
+  // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
+  // One loop body for both passes keeps a single inlined copy of the contact and solver code.
+#pragma unroll 1
+  for (int pass = m.task == HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
+    collide(dm_, lane, &ncon);
+    if (pass == 1) {
+      int hc = L.acc_has_collision, ct = L.acc_collision_type;
+      classify(dm_, ncon, &hc, &ct);
+      L.acc_has_collision = hc; L.acc_collision_type = ct;
+    }
+    crash = dynamics_step(dm_, lane, ncon);
+    if (pass == 0 && !crash) {
+      s.time = s.time + m.timestep;
+      eef_update(dm_);
+      const int hl = dm->clips.clip_holding_hand[clip_of(dm, gid, s.episode, s.anim_index)];
+      const int site = hl ? m.site_lhand : m.site_rhand;
+      wave_sync();
+      if (lane < 3) L.bx.mocap_pos[lane] = s.human_site[site][lane];
+      if (lane < 4) L.bx.mocap_quat[lane] = L.hand_q[lane];
+      wave_sync();
+      robot_chain_fk(dm_, lane, false);
+      robot_dynamics_terms(dm_, lane);
+    }
+  }
+#else
   if (pm & 8) collide(dm_, lane, &ncon);
   STAMP(5);
   int hc = L.acc_has_collision, ct = L.acc_collision_type;
   classify(dm_, ncon, &hc, &ct);
   L.acc_has_collision = hc; L.acc_collision_type = ct;
   STAMP(6);
-  int crash = 0;
   if (pm & 16) crash = dynamics_step(dm_, lane, ncon);
   STAMP(7);
+#endif
   if (!crash) {
     s.time = s.time + m.timestep;
     eef_update(dm_);
@@ -883,7 +952,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   for (int a = 0; a < 3; a++) { e2o += (bx.obs_pos[a] - s.eef_pos[a]) * (bx.obs_pos[a] - s.eef_pos[a]); o2t += (bx.target[a] - bx.obs_pos[a]) * (bx.target[a] - bx.obs_pos[a]); }
   const int in_zone = sqrt(o2t) <= m.goal_dist;
   // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
-  const int inspection = m.task == HRG_TASK_INSPECTION;
+  const int inspection = m.task == HRG_TASK_INSPECTION || m.task == HRG_TASK_HANDOVER_H2R;   // success = the task's animation ran to its end
   const int goal_reached = !crash && (inspection ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone);
   double r = goal_reached ? m.task_reward : ((inspection && in_zone) ? m.object_at_target_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
   const double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
@@ -925,6 +994,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
       case HRG_INFO_TRUNCATED: v = truncated; break;
       case HRG_INFO_SIM_CRASH: v = crash; break;
       case HRG_INFO_ACTION_RESAMPLES: v = s.action_resamples; break;
+#if HRG_BOX
+      case HRG_INFO_N_OBJECT_HANDED_OVER: v = L.bx.n_handed_over; break;
+#endif
     }
     info[lane] = v;
   }
@@ -933,6 +1005,27 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #if HRG_BOX
   if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
   wave_sync();
+  if (m.task == HRG_TASK_HANDOVER_H2R && !d) {
+    if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_robot_handover_cartesian_env.py:649-668): next target, next animation, the human picks the object up again
+      const int ti = (bx.tgt_index + 1) % m.n_targets;
+      double pt[3];
+      placement_of(dm, gid, s.episode, ti, 1, pt);
+      const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+      wave_sync();
+      bx.tgt_index = ti;
+      if (lane < 3) bx.target[lane] = pt[lane];
+      s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+      bx.task_phase = HRG_PHASE_APPROACH; bx.n_delayed = 0; bx.n_delayed2 = 0;
+      wave_sync();
+      handover_pickup(dm_, lane, gid, false);   // body_xpos (the observed object position) is refreshed by the next forward pass
+    }
+    // HumanRobotHandoverCart.step (465-483): the human lets go once the robot has gripped the object; the retreat starts when it is placed
+    const int ph = bx.task_phase;
+    wave_sync();
+    if (ph == HRG_PHASE_PRESENT && bx.gripped) { bx.weld_active = 0; bx.task_phase = HRG_PHASE_WAIT; bx.n_handed_over = bx.n_handed_over + 1; }
+    else if (ph == HRG_PHASE_WAIT && in_zone) bx.task_phase = HRG_PHASE_RETREAT;
+    wave_sync();
+  } else
   if (inspection && !d) {
     if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_object_inspection_cartesian_env.py:492-505): next placement, next animation
       const int oi = (bx.obj_index + 1) % m.n_obj_placements;
@@ -1142,8 +1235,11 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_POINTING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
-  if (desc->task == HRG_TASK_INSPECTION)
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_HANDOVER_H2R) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task == HRG_TASK_HANDOVER_H2R)
+    for (int c = 0; c < clips->n_clips; c++)
+      if (!(clips->clip_n_loop2[c] >= 0 && clips->clip_n_loop2[c] <= HRG_MAX_LOOP)) return fail(HRG_ERR_INVALID, "HumanRobotHandoverCart: at most 4 loop sines per stage");
+  if (desc->task == HRG_TASK_INSPECTION || desc->task == HRG_TASK_HANDOVER_H2R)
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP && clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1]))
         return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");

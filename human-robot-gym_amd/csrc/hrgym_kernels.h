@@ -194,7 +194,9 @@ DI int clip_of(ModelPtr dm, int64_t gid, int episode, int anim_index) {
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
 }
 
-DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/) {
+DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double* mocap_pos, const double* mocap_quat, const double* qh /*global or null*/,
+                       int hold_body = -1, int hold_left = 0) {
+  (void)hold_body; (void)hold_left;
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -240,6 +242,20 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     m3mulv(t, R, m.hcap_p1[b]); v3add(&L.hcap[b][0], p, t);
     m3mulv(t, R, m.hcap_p2[b]); v3add(&L.hcap[b][3], p, t);
   }
+#if HRG_BOX
+  if (hold_body >= 0 && lane == hold_body) { // _update_mocap_body_transform (human_robot_handover_cartesian_env.py:609-633): hand rotation turned -+90 deg about its y axis
+    const double ang = hold_left ? 0.5 * HRG_PI : -0.5 * HRG_PI, c = cos(ang), sn = sin(ang);
+    const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
+    double Rm[9], q[4];
+    m3mul(Rm, R, Ry);
+    const double tr = Rm[0] + Rm[4] + Rm[8];
+    if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+    else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+    else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+    else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+    for (int a = 0; a < 4; a++) L.hand_q[a] = q[a];
+  }
+#endif
   // sites of the measured joints: site k sits at the anchor of body meas_body[k]
   {
     const int k = lane < HRG_NHJ ? lane : 0;
@@ -262,10 +278,20 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
 // amplitude (speed = 0) or speed modifier (1) of layered sine k of the idle loop of animation slot ai in this episode
 // (sample_animation_loop_properties, utils/animation_utils.py:122-176), drawn counter-based on demand
 DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int k, int speed) {
-  const double base = speed ? dm->clips.clip_loop_speed[clip][k] : dm->clips.clip_loop_amp[clip][k];
+  double base = speed ? dm->clips.clip_loop_speed[clip][k % HRG_MAX_LOOP] : dm->clips.clip_loop_amp[clip][k % HRG_MAX_LOOP];
+  if (k >= HRG_MAX_LOOP) base = speed ? dm->clips.clip_loop2_speed[clip][k - HRG_MAX_LOOP] : dm->clips.clip_loop2_amp[clip][k - HRG_MAX_LOOP];  // second loop stage ("wait")
   const double sf = speed ? dm->clips.clip_loop_speed_std[clip] : dm->clips.clip_loop_amp_std[clip];
-  const double z = clampd(rng_gauss(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_LOOP, (uint64_t)((ai * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
+  const double z = clampd(rng_gauss(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_LOOP, (uint64_t)((ai * 2 * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
   return base * exp(z * log(sf));
+}
+// layered_sin_modulations (utils/animation_utils.py:91-119) over loop sines kfirst..kfirst+n-1 of the clip
+DI double layered_sines(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int kfirst, int n, double t, double start) {
+  double sum = 0;
+  for (int k = 0; k < n; k++) {
+    const double A = loop_prop(dm, gid, episode, ai, clip, kfirst + k, 0), S = loop_prop(dm, gid, episode, ai, clip, kfirst + k, 1);
+    sum += A * sin((t - start) / (A / S)) + start;
+  }
+  return sum - start * (double)(n - 1);
 }
 #endif
 
@@ -303,6 +329,27 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
     bx.task_phase = phase; bx.n_delayed = nd;
     if (lane < 3) bx.target[lane] = dm->clips.clip_target_pos[clip][lane] + s.human_pos_offset[lane];  // target_pos property (447-459)
   }
+  int hold_body = -1, hold_left = 0;
+  if (m.task == HRG_TASK_HANDOVER_H2R) { // HumanRobotHandoverCart._compute_animation_time (human_robot_handover_cartesian_env.py:530-596); wave-uniform
+    hrg_box_state& bx = L.bx;
+    const int classic = at, k0 = dm->clips.clip_keyframes[clip][0], k1 = dm->clips.clip_keyframes[clip][1], len = dm->clips.clip_len[clip];
+    int phase = bx.task_phase, nd = bx.n_delayed, nd2 = bx.n_delayed2;
+    if (at > k0 && phase == HRG_PHASE_APPROACH) phase = HRG_PHASE_PRESENT;
+    else if ((double)at > (double)k0 + (double)(k1 - k0) / 2.0 && phase == HRG_PHASE_PRESENT) {
+      at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, 0, dm->clips.clip_n_loop[clip], (double)classic, (double)(k0 + k1) / 2.0);
+      nd = classic - at; nd2 = 0;
+    } else if (phase == HRG_PHASE_WAIT) {
+      at = classic - nd;
+      if (at >= k1) at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, HRG_MAX_LOOP, dm->clips.clip_n_loop2[clip], (double)at, (double)k1);
+      nd2 = classic - at;
+    } else if (phase == HRG_PHASE_RETREAT) at -= nd2;
+    if (at >= len - 1) { phase = HRG_PHASE_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+    wave_sync();
+    bx.task_phase = phase; bx.n_delayed = nd; bx.n_delayed2 = nd2;
+    hold_left = dm->clips.clip_holding_hand[clip];
+    hold_body = m.meas_body[hold_left ? m.site_lhand : m.site_rhand];
+  }
 #endif
   if (at > dm->clips.clip_len[clip] - 1) {
     anim_index = (anim_index + 1) % m.n_anim_ids; // human_env.py:1704-1708
@@ -323,7 +370,11 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
   double qa[4] = {fr[6], fr[3], fr[4], fr[5]};
   quatmul(q1, s.human_rot_offset, qbi);
   quatmul(mq, q1, qa);
+#if HRG_BOX
+  human_fk_lanes(dm_, lane, mp, mq, fr + 7, hold_body, hold_left);
+#else
   human_fk_lanes(dm_, lane, mp, mq, fr + 7);
+#endif
 }
 
 // ================================================================================================ shield

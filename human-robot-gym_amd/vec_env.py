@@ -68,7 +68,7 @@ except Exception:  # noqa: BLE001
 INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "collision", "collision_type", "n_collisions", "n_collisions_static", "n_collisions_robot", "n_collisions_human",
     "n_collisions_critical", "timeout", "failsafe_interventions", "n_goal_reached", "TimeLimit.truncated", "sim_crash",
-    "action_resamples",
+    "action_resamples", "n_object_handed_over",
 ]
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
 _BOOL_ITEMS = [(j, k) for j, k in enumerate(INFO_KEYS) if k in _BOOL_KEYS]

@@ -66,7 +66,7 @@ extern "C" {
                           *  both tasks: [53:55] robot0_gripper_qpos  [55:57] robot0_gripper_qvel (the scripted experts' inputs,
                           *  demonstrations/experts/pick_place_human_cart_expert.py:24-41) */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
-#define HRG_INFO_DIM 13
+#define HRG_INFO_DIM 14
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */
 #define HRG_NCON_DYN 6    /* contacts that enter the constraint solve (4 pyramid rows each) */
 #define HRG_NCON_DYN_BOX 8 /* ... for tasks with the manipulation object (rows 24 + 32 still fit one wavefront) */
@@ -90,7 +90,8 @@ enum {
   HRG_INFO_N_GOAL_REACHED = 9,
   HRG_INFO_TRUNCATED = 10, /* TimeLimit.truncated (time_limit.py:42) */
   HRG_INFO_SIM_CRASH = 11,
-  HRG_INFO_ACTION_RESAMPLES = 12 /* CollisionPreventionWrapper.action_resamples */
+  HRG_INFO_ACTION_RESAMPLES = 12, /* CollisionPreventionWrapper.action_resamples */
+  HRG_INFO_N_OBJECT_HANDED_OVER = 13 /* human_robot_handover_cartesian_env.py:507-511 */
 };
 
 /* COLLISION_TYPE flag values, human_env.py:55-77 */
@@ -102,9 +103,12 @@ enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 /* geom classes used by the contact classifier (human_env.py:948-964) */
 /* tasks: ReachHuman (reach_human_env.py), PickPlaceHumanCart (pick_place_human_cartesian_env.py) */
 enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */,
-       HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */ };
+       HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */,
+       HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */ };
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
+/* HumanRobotHandoverPhase, human_robot_handover_cartesian_env.py:50-56 (same numbering) */
+enum { HRG_PHASE_PRESENT = 1, HRG_PHASE_WAIT = 2 };
 
 enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
 
@@ -273,7 +277,12 @@ typedef struct hrg_clip_table {
   double clip_loop_speed[HRG_MAX_CLIPS][HRG_MAX_LOOP];
   double clip_loop_amp_std[HRG_MAX_CLIPS], clip_loop_speed_std[HRG_MAX_CLIPS];
   int32_t clip_pointing_hand[HRG_MAX_CLIPS]; /* 0 right, 1 left ("pointing_hand" of the info file) */
-  int32_t pad_;
+  /* handover clips: two loop stages ("present" uses clip_loop_*, "wait" the arrays below) and the hand that holds the object
+   * (human_robot_handover_cartesian_env.py:440-463) */
+  int32_t clip_holding_hand[HRG_MAX_CLIPS];  /* 0 right, 1 left ("object_holding_hand") */
+  int32_t clip_n_loop2[HRG_MAX_CLIPS];
+  double clip_loop2_amp[HRG_MAX_CLIPS][HRG_MAX_LOOP];
+  double clip_loop2_speed[HRG_MAX_CLIPS][HRG_MAX_LOOP];
 } hrg_clip_table;
 
 typedef struct hrg_batch hrg_batch; /* opaque */

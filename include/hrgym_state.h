@@ -90,7 +90,10 @@ typedef struct hrg_box_state {
   int32_t gripped;              /* _check_grasp at the last substep */
   int32_t task_phase;           /* HRG_PHASE_* (HumanObjectInspectionCart) */
   int32_t n_delayed;            /* _n_delayed_timesteps: frames the loop phase held the animation back */
-  int32_t pad_;
+  int32_t n_delayed2;           /* second entry of _n_delayed_timesteps (handover: delay accumulated in the WAIT loop) */
+  int32_t weld_active;          /* eq_active of the object <-> hand mocap weld (handover tasks) */
+  int32_t n_handed_over;        /* _n_object_handed_over */
+  double mocap_pos[3], mocap_quat[4]; /* pose of the mocap body at the human's holding hand (set once per cycle) */
 } hrg_box_state;
 
 #ifdef __cplusplus

@@ -358,10 +358,21 @@ static int clip_of(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int
  * counter-based on demand instead of as lists filled at reset */
 static double loop_prop(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int ai, int clip, int k, int speed) {
   const hrg_clip_table* c = &b->clips;
-  double base = speed ? c->clip_loop_speed[clip][k] : c->clip_loop_amp[clip][k];
+  double base = speed ? c->clip_loop_speed[clip][k % HRG_MAX_LOOP] : c->clip_loop_amp[clip][k % HRG_MAX_LOOP];
+  if (k >= HRG_MAX_LOOP) base = speed ? c->clip_loop2_speed[clip][k - HRG_MAX_LOOP] : c->clip_loop2_amp[clip][k - HRG_MAX_LOOP]; /* second loop stage ("wait") */
   double sf = speed ? c->clip_loop_speed_std[clip] : c->clip_loop_amp_std[clip];
-  double z = clampd(rng_gauss(b->m.seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_LOOP, (uint64_t)((ai * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
+  double z = clampd(rng_gauss(b->m.seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_LOOP, (uint64_t)((ai * 2 * HRG_MAX_LOOP + k) * 2 + speed)), -3.0, 3.0);
   return base * exp(z * log(sf));
+}
+
+/* layered_sin_modulations (utils/animation_utils.py:91-119) over loop sines k0..k0+n-1 of the clip */
+static double layered_sines(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, int clip, int kfirst, int n, double t, double start) {
+  double sum = 0;
+  for (int k = 0; k < n; k++) {
+    const double A = loop_prop(b, gid, s, s->anim_index, clip, kfirst + k, 0), S = loop_prop(b, gid, s, s->anim_index, clip, kfirst + k, 1);
+    sum += A * sin((t - start) / (A / S)) + start;
+  }
+  return sum - start * (double)(n - 1);
 }
 
 static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, double* mocap_pos, double* mocap_quat, const double** qh) {
@@ -387,6 +398,20 @@ static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hr
     if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
     if (at < 0) at = 0; /* a loop amplitude larger than the first keyframe must not index before the clip */
     for (int a = 0; a < 3; a++) bx->target[a] = b->clips.clip_target_pos[clip][a] + s->human_pos_offset[a]; /* target_pos property, 447-459 */
+  }
+  if (m->task == HRG_TASK_HANDOVER_H2R) { /* HumanRobotHandoverCart._compute_animation_time, human_robot_handover_cartesian_env.py:530-596 */
+    const int classic = at, k0 = b->clips.clip_keyframes[clip][0], k1 = b->clips.clip_keyframes[clip][1], len = b->clips.clip_len[clip];
+    if (at > k0 && bx->task_phase == HRG_PHASE_APPROACH) bx->task_phase = HRG_PHASE_PRESENT;
+    else if ((double)at > (double)k0 + (double)(k1 - k0) / 2.0 && bx->task_phase == HRG_PHASE_PRESENT) { /* present the object: loop around the middle of the two keyframes */
+      at = (int)layered_sines(b, gid, s, clip, 0, b->clips.clip_n_loop[clip], (double)classic, (double)(k0 + k1) / 2.0);
+      bx->n_delayed = classic - at; bx->n_delayed2 = 0;
+    } else if (bx->task_phase == HRG_PHASE_WAIT) { /* wait at the second keyframe until the object is placed */
+      at = classic - bx->n_delayed;
+      if (at >= k1) at = (int)layered_sines(b, gid, s, clip, HRG_MAX_LOOP, b->clips.clip_n_loop2[clip], (double)at, (double)k1);
+      bx->n_delayed2 = classic - at;
+    } else if (bx->task_phase == HRG_PHASE_RETREAT) at -= bx->n_delayed2;
+    if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
   }
   s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
@@ -960,7 +985,7 @@ static void classify(const hrg_model_desc* m, const robot_kin* k, hrg_env_state*
  * pyramidal frictional contacts) solved by a primal Newton method with exact line search on MuJoCo's convex
  * objective  1/2 (a-a0)' M (a-a0) + sum_i s_i(J_i a - aref_i), then semi-implicit Euler with implicit joint
  * damping. */
-enum { ROW_FRICTION = 0, ROW_UNILATERAL = 1 };
+enum { ROW_FRICTION = 0, ROW_UNILATERAL = 1, ROW_EQUALITY = 2 /* weld rows: quadratic on both sides */ };
 typedef struct {
   int n;
   int type[NEFC_MAX];
@@ -1006,7 +1031,8 @@ static void efc_add(const hrg_model_desc* m, efc_t* E, const double* J, const do
 /* cost pieces of one row at x = J a - aref: value, first and second derivative */
 static void row_cost(const efc_t* E, int r, double x, double* c, double* g, double* h) {
   double D = E->D[r];
-  if (E->type[r] == ROW_UNILATERAL) {
+  if (E->type[r] == ROW_EQUALITY) { *c = 0.5 * D * x * x; *g = D * x; *h = D; }
+  else if (E->type[r] == ROW_UNILATERAL) {
     if (x < 0) { *c = 0.5 * D * x * x; *g = D * x; *h = D; } else { *c = 0; *g = 0; *h = 0; }
   } else {
     double f = E->floss[r], lim = f / D;
@@ -1018,6 +1044,7 @@ static void row_cost(const efc_t* E, int r, double x, double* c, double* g, doub
 
 /* which quadratic / linear piece of its cost a row is in at x */
 static int row_zone(const efc_t* E, int r, double x) {
+  if (E->type[r] == ROW_EQUALITY) return 0;
   if (E->type[r] == ROW_UNILATERAL) return x < 0;
   double lim = E->floss[r] / E->D[r];
   return x <= -lim ? -1 : (x >= lim ? 1 : 0);
@@ -1297,6 +1324,32 @@ static void screen_action(const hrgo_batch* B, int64_t gid, hrg_env_state* s, do
   for (int j = 0; j < HRG_ACT_DIM; j++) act[j] = found ? best[j] : 0.0;
 }
 
+/* HumanRobotHandoverCart._update_mocap_body_transform (human_robot_handover_cartesian_env.py:609-633): the mocap body sits at the site of the
+ * holding hand, rotated like the hand body turned by -+90 deg about its y axis */
+static void handover_mocap(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, hrg_box_state* bx, const human_kin* hk) {
+  const hrg_model_desc* m = &B->m;
+  const int left = B->clips.clip_holding_hand[clip_of(B, gid, s, s->anim_index)];
+  const int site = left ? m->site_lhand : m->site_rhand, body = m->meas_body[site];
+  const double ang = left ? 0.5 * PI : -0.5 * PI, c = cos(ang), sn = sin(ang);
+  const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
+  double R[9];
+  m3mul(R, hk->R[body], Ry);
+  /* rotation matrix -> quaternion (w,x,y,z), w >= 0 branch-free enough for proper rotations: Shepperd's method */
+  double q[4], tr = R[0] + R[4] + R[8];
+  if (tr > 0) { double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (R[7] - R[5]) / S; q[2] = (R[2] - R[6]) / S; q[3] = (R[3] - R[1]) / S; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double S = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / S; q[1] = 0.25 * S; q[2] = (R[1] + R[3]) / S; q[3] = (R[2] + R[6]) / S; }
+  else if (R[4] > R[8]) { double S = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / S; q[1] = (R[1] + R[3]) / S; q[2] = 0.25 * S; q[3] = (R[5] + R[7]) / S; }
+  else { double S = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / S; q[1] = (R[2] + R[6]) / S; q[2] = (R[5] + R[7]) / S; q[3] = 0.25 * S; }
+  for (int a = 0; a < 4; a++) bx->mocap_quat[a] = q[a];
+  v3cpy(bx->mocap_pos, s->human_site[site]);
+}
+/* _human_pickup_object (700-711): the object jumps into the hand and the weld is switched on */
+static void handover_pickup(hrg_box_state* bx) {
+  v3cpy(bx->pos, bx->mocap_pos);
+  for (int a = 0; a < 4; a++) bx->quat[a] = bx->mocap_quat[a];
+  bx->weld_active = 1;
+}
+
 static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
   double t[3];
   m3mulv(t, k->R[NARM - 1], m->eef_pos);
@@ -1345,6 +1398,17 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
       for (int a = 0; a < 3; a++) bx->target[a] = B->clips.clip_target_pos[clip][a] + s->human_pos_offset[a];
     }
     bx->quat[0] = 1;
+    if (m->task == HRG_TASK_HANDOVER_H2R) { /* _reset_animation + _control_human (human_robot_handover_cartesian_env.py:635-647, 686-711): the human starts
+                                             * with the object welded into the holding hand.  The reference teleports it to the stale mocap pose first
+                                             * and lets the weld drag it over; here the hand pose of the first animation frame is used directly */
+      human_kin hk;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk, s->human_site);
+      handover_mocap(B, gid, s, bx, &hk);
+      handover_pickup(bx);
+    }
     v3cpy(bx->obs_pos, bx->pos);
   } else goal_of(B, gid, s, 0, s->cur_goal);
   if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
@@ -1403,6 +1467,9 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     const double* qh;
     human_control(B, gid, s, bx, mp, mq, &qh);
     human_fk(m, mp, mq, qh, &hk, s->human_site);
+    /* HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human
+     * pose before it re-poses the hand mocap body: pass 0 = that step (no bookkeeping), pass 1 = the cycle's regular step */
+    for (int pass = m->task == HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
     /* ---- contacts + bookkeeping (human_env.py:522) ---- */
     contact_t con[HRG_NCON_MAX];
     int ncon = collide(m, &k, &hk, bx, con);
@@ -1420,9 +1487,11 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       m3mulv(t, b < 0 ? Rb : k.R[b], mid);
       v3add(rc[c], b < 0 ? m->base_pos : k.p[b], t);
     }
-    classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
-    s->ncon = ncon;
-    for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
+    if (pass == 1) {
+      classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
+      s->ncon = ncon;
+      for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
+    }
     /* ---- sim.step() (human_env.py:523): smooth acceleration, constraints, Euler ---- */
     double LM[NV * NV], a0[NVT], frc[NV], qd[NVT], Mt[NVT * NVT];
     memcpy(LM, M, sizeof LM);
@@ -1482,6 +1551,17 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
         efc_add(m, &E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
       }
     }
+    if (bx && bx->weld_active) { /* weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
+                                  * [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; the mocap body has no velocity; relpose = identity */
+      double epos[3], erot[3], qc[4] = {bx->mocap_quat[0], -bx->mocap_quat[1], -bx->mocap_quat[2], -bx->mocap_quat[3]}, qe[4];
+      v3sub(epos, bx->pos, bx->mocap_pos);
+      quatmul(qe, bx->quat, qc);
+      if (qe[0] < 0) for (int a = 0; a < 4; a++) qe[a] = -qe[a];
+      const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+      for (int a = 0; a < 3; a++) erot[a] = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
+      for (int a = 0; a < 3; a++) { double J[NVT] = {0}; J[NV + a] = 1; efc_add(m, &E, J, qd, ROW_EQUALITY, epos[a], 0, 0, 1.0 / m->box_mass); }
+      for (int a = 0; a < 3; a++) { double J[NVT] = {0}; J[NV + 3 + a] = 1; efc_add(m, &E, J, qd, ROW_EQUALITY, erot[a], 0, 0, 1.0 / m->box_inertia); }
+    }
     double qacc[NVT];
     memcpy(qacc, s->qacc_warmstart, sizeof(double) * NV);
     if (bx) memcpy(qacc + NV, bx->acc_warmstart, sizeof(double) * HRG_NBOXV);
@@ -1518,6 +1598,14 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     }
     s->time += h;
     eef_of(m, &k, s->eef_pos); /* site_xpos of the forward pass inside mj_step (pre-integration) */
+    if (pass == 0) { /* _update_mocap_body_transform (609-633) + sim.forward() (human_env.py:519) */
+      handover_mocap(B, gid, s, bx, &hk);
+      robot_fk(m, s->qpos, &k);
+      robot_crba(m, &k, M);
+      robot_bias(m, &k, s->qvel, bias);
+    }
+    } /* pass */
+    if (crash) break;
     s->low_level_time += 1; /* human_env.py:526 */
   }
   /* ---- observation, success, info, reward, done (human_env.py:561-581) ---- */
@@ -1541,7 +1629,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     double e2o = 0, o2t = 0;
     for (int a = 0; a < 3; a++) { e2o += (bx->obs_pos[a] - s->eef_pos[a]) * (bx->obs_pos[a] - s->eef_pos[a]); o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]); }
     const int in_zone = sqrt(o2t) <= m->goal_dist; /* _check_object_in_target_zone, 550-572 */
-    if (m->task == HRG_TASK_INSPECTION) { /* success = the inspection animation ran to its end; human_object_inspection_cartesian_env.py:553-600 */
+    if (m->task == HRG_TASK_INSPECTION || m->task == HRG_TASK_HANDOVER_H2R) { /* success = the animation ran to its end; human_object_inspection_cartesian_env.py:553-600, human_robot_handover_cartesian_env.py:485-528 */
       goal_reached = !crash && bx->task_phase == HRG_PHASE_COMPLETE;
       r = goal_reached ? m->task_reward : (in_zone ? m->object_at_target_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
     } else {
@@ -1581,7 +1669,29 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   info[HRG_INFO_SIM_CRASH] = crash;
   info[HRG_INFO_TRUNCATED] = 0;
   info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
-  if (bx && m->task == HRG_TASK_INSPECTION) {
+  info[HRG_INFO_N_OBJECT_HANDED_OVER] = bx ? bx->n_handed_over : 0;
+  if (bx && m->task == HRG_TASK_HANDOVER_H2R) {
+    double o2t = 0;
+    for (int a = 0; a < 3; a++) o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]);
+    if (goal_reached && !m->done_at_success) { /* _on_goal_reached (649-668): next target, next animation, the human picks the object up again */
+      bx->tgt_index = (bx->tgt_index + 1) % m->n_targets;
+      placement_of(B, gid, s->episode, bx->tgt_index, 1, bx->target);
+      s->anim_index = (s->anim_index + 1) % m->n_anim_ids;
+      s->animation_time = 0;
+      s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+      bx->task_phase = HRG_PHASE_APPROACH; bx->n_delayed = 0; bx->n_delayed2 = 0;
+      human_kin hk2;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk2, s->human_site);
+      handover_mocap(B, gid, s, bx, &hk2);
+      handover_pickup(bx);
+    }
+    /* HumanRobotHandoverCart.step (465-483): the human lets go once the robot has gripped the object; the retreat starts when it is placed */
+    if (bx->task_phase == HRG_PHASE_PRESENT && bx->gripped) { bx->weld_active = 0; bx->task_phase = HRG_PHASE_WAIT; bx->n_handed_over++; }
+    else if (bx->task_phase == HRG_PHASE_WAIT && sqrt(o2t) <= m->goal_dist) bx->task_phase = HRG_PHASE_RETREAT;
+  } else if (bx && m->task == HRG_TASK_INSPECTION) {
     double o2t = 0;
     for (int a = 0; a < 3; a++) o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]);
     if (goal_reached && !m->done_at_success) { /* _on_goal_reached, human_object_inspection_cartesian_env.py:492-505: next placement, next animation */
