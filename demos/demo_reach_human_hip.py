@@ -18,12 +18,12 @@ from human_robot_gym_amd.vec_env import HipVecEnv  # noqa: E402
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart", "PickPlaceCloseHumanCart",
-                                                             "PickPlacePointingHumanCart", "HumanObjectInspectionCart"])
+                                                             "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart"])
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--n-envs", type=int, default=4)
     ap.add_argument("--cartesian", action="store_true", help="[dx, dy, dz, gripper] actions through the in-kernel IK (config/wrappers/safe_ik.yaml)")
     args = ap.parse_args()
-    clips = hrg.synthetic_clips(4, seed=0, inspection=args.env == "HumanObjectInspectionCart")
+    clips = hrg.synthetic_clips(4, seed=0, inspection=args.env == "HumanObjectInspectionCart", handover=args.env == "HumanRobotHandoverCart")
     wrappers = dict(collision_prevention=dict(replace_type=0, n_resamples=20))
     if args.cartesian:
         wrappers["ik_position_delta"] = dict(action_limit=0.15)

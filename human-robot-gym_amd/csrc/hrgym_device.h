@@ -26,6 +26,11 @@
 #ifndef HRG_BOX
 #define HRG_BOX 0
 #endif
+// HRG_HANDOVER=1 (with HRG_BOX=1, hrgym_handover.hip): the cube variant plus what only the handover tasks need -- the object <-> hand
+// weld rows, a second physics step per cycle, the hand mocap pose.  A third translation unit, so the pick-place kernels stay lean.
+#ifndef HRG_HANDOVER
+#define HRG_HANDOVER 0
+#endif
 #define NVT HRG_NVT
 #if HRG_BOX
 #define NVS NVT                 // DoF of the constrained system: robot tree + free joint of the cube
@@ -133,7 +138,7 @@ struct Contact {
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
 #define ROW_WELD0 (ROW_CON0 + 4 * NCON_DYN)   // 6 equality rows of the object <-> hand weld (cube variant: lanes 56..61)
-#if HRG_BOX
+#if HRG_BOX && HRG_HANDOVER
 #define NROW (ROW_WELD0 + 6)
 #else
 #define NROW ROW_WELD0

@@ -1,0 +1,7 @@
+// hrgym_handover.hip — the cube variant compiled once more with what only the handover tasks need (HumanRobotHandoverCart,
+// environments/manipulation/human_robot_handover_cartesian_env.py): the weld equality between the object and the mocap body at the
+// human's holding hand (6 equality rows), the second physics step per cycle of its _control_human, the hand mocap pose, the
+// handover phase machine.  A third translation unit, so the pick-place / inspection kernels carry none of it.
+#define HRG_BOX 1
+#define HRG_HANDOVER 1
+#include "hrgym_hip.hip"

@@ -164,7 +164,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       cand = nz > 0;
     }
   }
-#if HRG_BOX
+#if HRG_HANDOVER
   else if (r < NROW && bx.weld_active) { // weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
                                          // [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; unit rows on the cube's own DoF, the mocap body has no velocity
     const int a = r - ROW_WELD0;
@@ -260,7 +260,9 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         double t = -L.Ma0[lane] + mdiag * L.qacc[lane];
         gm = t;
         for (uint64_t mm = bmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+#if HRG_HANDOVER
         t += L.rg[ROW_WELD0 + lane - NV];   // weld row of this DoF (0 when the weld is off)
+#endif
         L.g[lane] = t;
       }
       wave_sync();
@@ -278,7 +280,9 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
           if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
         }
         double sval = mi == mj ? (mi < 3 ? m.box_mass : (mi < HRG_NBOXV ? m.box_inertia : 1.0)) : 0.0;
+#if HRG_HANDOVER
         if (mi == mj && mi < HRG_NBOXV) sval += L.rh[ROW_WELD0 + mi];
+#endif
         if (mi < HRG_NBOXV && mj < HRG_NBOXV)
           for (uint64_t mm = bmask; mm;) {
             const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
@@ -312,7 +316,9 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         const int i = e / NVT, j = e - i * NVT;
         double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j ? (i - NV < 3 ? m.box_mass : m.box_inertia) : 0.0);
         if (i == j && i < NV) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; }
+#if HRG_HANDOVER
         if (i == j && i >= NV) hv += L.rh[ROW_WELD0 + i - NV];
+#endif
         for (uint64_t mm = cmask; mm;) {
           const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
           const double hq = L.rh[ROW_CON0 + q];
@@ -705,7 +711,7 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
   }
 }
 
-#if HRG_BOX
+#if HRG_HANDOVER
 // The human takes the object: pose of the holding hand at the current animation frame -> mocap body, object teleported into it, weld
 // on (_control_human + _human_pickup_object, human_robot_handover_cartesian_env.py:598-633, 700-711).  The reference teleports to the stale
 // mocap pose first and lets the weld drag the object over; here the fresh hand pose is used directly.
@@ -723,6 +729,8 @@ DI void handover_pickup(const DevModel* __restrict__ dm_, int lane, int64_t gid,
   bx.weld_active = 1;
   wave_sync();
 }
+#endif
+#if HRG_BOX
 // i-th object placement / target of an episode (UniformRandomSampler over the bins, pick_place_human_cartesian_env.py:613-635,
 // 843-875), counter-based; wave-uniform
 DI void placement_of(ModelPtr dm, int64_t gid, int episode, int idx, int target, double* p) {
@@ -788,7 +796,9 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     if (lane < 3) { bx.pos[lane] = po[lane]; bx.obs_pos[lane] = po[lane]; bx.target[lane] = pt[lane]; }
     if (lane == 0) bx.quat[0] = 1.0;
     wave_sync();
+#if HRG_HANDOVER
     if (m.task == HRG_TASK_HANDOVER_H2R) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (635-647, 686-711)
+#endif
   }
 #else
   goal_sample(dm_, lane, gid, 0);
@@ -858,7 +868,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   STAMP(4);
   int ncon = 0;
   int crash = 0;
-#if HRG_BOX
+#if HRG_HANDOVER
   // HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human pose
   // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
   // One loop body for both passes keeps a single inlined copy of the contact and solver code.
@@ -1005,6 +1015,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #if HRG_BOX
   if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
   wave_sync();
+#if HRG_HANDOVER
   if (m.task == HRG_TASK_HANDOVER_H2R && !d) {
     if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_robot_handover_cartesian_env.py:649-668): next target, next animation, the human picks the object up again
       const int ti = (bx.tgt_index + 1) % m.n_targets;
@@ -1026,6 +1037,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
     else if (ph == HRG_PHASE_WAIT && in_zone) bx.task_phase = HRG_PHASE_RETREAT;
     wave_sync();
   } else
+#endif
   if (inspection && !d) {
     if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_object_inspection_cartesian_env.py:492-505): next placement, next animation
       const int oi = (bx.obj_index + 1) % m.n_obj_placements;
@@ -1076,9 +1088,16 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 }
 
 // ================================================================================================ kernels
-#if HRG_BOX
+#if HRG_BOX && HRG_HANDOVER
+#define hrg_step_kernel hrg_step_kernel_ho
+#define hrg_reset_kernel hrg_reset_kernel_ho
+#define hrg_box_launch_step hrg_ho_launch_step
+#define hrg_box_launch_reset hrg_ho_launch_reset
+#elif HRG_BOX
 #define hrg_step_kernel hrg_step_kernel_box
 #define hrg_reset_kernel hrg_reset_kernel_box
+#endif
+#if HRG_BOX
 #ifndef HRG_BOX_WAVES
 #define HRG_BOX_WAVES 3
 #endif
@@ -1151,6 +1170,14 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_
                                                                            float* scratch_obs, hrg_box_state* boxes);
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                             int64_t env_id0, hrg_box_state* boxes);
+#if !HRG_BOX
+// the same shims of the handover variant (hrgym_handover.hip)
+extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                          float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                          float* scratch_obs, hrg_box_state* boxes);
+extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                           int64_t env_id0, hrg_box_state* boxes);
+#endif
 #if HRG_BOX
 extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
                                     int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes) {
@@ -1364,7 +1391,8 @@ void hrg_batch_destroy(hrg_batch* b) {
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
-  if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  if (b->task == HRG_TASK_HANDOVER_H2R) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   HIPCHK(hipGetLastError());
   return HRG_OK;
@@ -1379,7 +1407,10 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  if (b->task != HRG_TASK_REACH)
+  if (b->task == HRG_TASK_HANDOVER_H2R)
+    hrg_ho_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+  else if (b->task != HRG_TASK_REACH)
     hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else

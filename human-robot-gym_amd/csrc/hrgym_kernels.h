@@ -242,7 +242,7 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     m3mulv(t, R, m.hcap_p1[b]); v3add(&L.hcap[b][0], p, t);
     m3mulv(t, R, m.hcap_p2[b]); v3add(&L.hcap[b][3], p, t);
   }
-#if HRG_BOX
+#if HRG_HANDOVER
   if (hold_body >= 0 && lane == hold_body) { // _update_mocap_body_transform (human_robot_handover_cartesian_env.py:609-633): hand rotation turned -+90 deg about its y axis
     const double ang = hold_left ? 0.5 * HRG_PI : -0.5 * HRG_PI, c = cos(ang), sn = sin(ang);
     const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
@@ -330,6 +330,7 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
     if (lane < 3) bx.target[lane] = dm->clips.clip_target_pos[clip][lane] + s.human_pos_offset[lane];  // target_pos property (447-459)
   }
   int hold_body = -1, hold_left = 0;
+#if HRG_HANDOVER
   if (m.task == HRG_TASK_HANDOVER_H2R) { // HumanRobotHandoverCart._compute_animation_time (human_robot_handover_cartesian_env.py:530-596); wave-uniform
     hrg_box_state& bx = L.bx;
     const int classic = at, k0 = dm->clips.clip_keyframes[clip][0], k1 = dm->clips.clip_keyframes[clip][1], len = dm->clips.clip_len[clip];
@@ -350,6 +351,7 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
     hold_left = dm->clips.clip_holding_hand[clip];
     hold_body = m.meas_body[hold_left ? m.site_lhand : m.site_rhand];
   }
+#endif
 #endif
   if (at > dm->clips.clip_len[clip] - 1) {
     anim_index = (anim_index + 1) % m.n_anim_ids; // human_env.py:1704-1708
