@@ -123,7 +123,10 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         if inspection:  # stand-in for the ObjectInspection/* info files: approach until 30 %, inspect until 70 %, idle loop of two layered sines
             info.update(keyframes=[int(0.3 * n), int(0.7 * n)], target_pos=[0.55, float(rng.uniform(-0.1, 0.1)), 1.15],
                         loop_amplitudes=[25.0, 8.0], loop_speeds=[1.0, 0.45], loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
-        if handover:    # stand-in for the HumanRobotHandover/* info files: present from 30 %, wait at 60 %, two loop stages
+        if handover == "r2h":   # stand-in for the RobotHumanHandover/* info files: the hand is held out between 30 % and 60 %
+            info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
+                        loop_amplitudes=[15.0, 5.0], loop_speeds=[1.0, 0.5], loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        elif handover:  # stand-in for the HumanRobotHandover/* info files: present from 30 %, wait at 60 %, two loop stages
             info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)

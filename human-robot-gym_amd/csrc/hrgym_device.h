@@ -155,7 +155,8 @@ struct Lds {
 #if HRG_BOX
   hrg_box_state bx;                      // the cube (streamed from its own HBM array)
   double bR[9];                          // its rotation matrix at the current substep
-  double hand_q[4];                      // orientation of the hand mocap body computed with the human tree (handover tasks)
+  double hand_q[4], hand_off[3];         // orientation of the hand mocap body / its offset from the hand site, computed with the human tree (handover tasks)
+  int palm_hit, palm_pad;                // the cube touches the palm of the holding hand (RobotHumanHandoverCart)
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators

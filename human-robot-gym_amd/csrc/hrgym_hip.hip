@@ -168,10 +168,18 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   else if (r < NROW && bx.weld_active) { // weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
                                          // [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; unit rows on the cube's own DoF, the mocap body has no velocity
     const int a = r - ROW_WELD0;
-    if (a < 3) pos = bx.pos[a] - bx.mocap_pos[a];
-    else {
-      const double qc[4] = {bx.mocap_quat[0], -bx.mocap_quat[1], -bx.mocap_quat[2], -bx.mocap_quat[3]}, qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]};
-      double qe[4];
+    const double qm[4] = {bx.mocap_quat[0], bx.mocap_quat[1], bx.mocap_quat[2], bx.mocap_quat[3]};
+    if (a < 3) { // where the weld wants the object: mocap frame o relative pose (identity for the human's own pickup)
+      double Rm[9], tp[3];
+      const double wo[3] = {bx.weld_off[0], bx.weld_off[1], bx.weld_off[2]};
+      quat2mat(Rm, qm);
+      m3mulv(tp, Rm, wo);
+      pos = bx.pos[a] - (tp[a] + bx.mocap_pos[a]);
+    } else {
+      const double wr[4] = {bx.weld_rel[0], bx.weld_rel[1], bx.weld_rel[2], bx.weld_rel[3]}, qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]};
+      double qt[4], qe[4];
+      quatmul(qt, qm, wr);
+      const double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
       quatmul(qe, qo, qc);
       if (qe[0] < 0) for (int k = 0; k < 4; k++) qe[k] = -qe[k];
       const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
@@ -724,9 +732,19 @@ DI void handover_pickup(const DevModel* __restrict__ dm_, int lane, int64_t gid,
   const int site = hl ? m.site_lhand : m.site_rhand;
   wave_sync();
   hrg_box_state& bx = L.bx;
-  if (lane < 3) { const double p = L.st.human_site[site][lane]; bx.mocap_pos[lane] = p; bx.pos[lane] = p; if (at_reset) bx.obs_pos[lane] = p; }
-  if (lane < 4) { const double q = L.hand_q[lane]; bx.mocap_quat[lane] = q; bx.quat[lane] = q; }
-  bx.weld_active = 1;
+  const bool r2h = m.task == HRG_TASK_HANDOVER_R2H;   // there the human starts empty-handed: only the mocap body (= the target) is posed
+  if (lane < 3) {
+    const double p = L.st.human_site[site][lane] + L.hand_off[lane];
+    bx.mocap_pos[lane] = p;
+    if (r2h) bx.target[lane] = p;
+    else { bx.pos[lane] = p; if (at_reset) bx.obs_pos[lane] = p; bx.weld_off[lane] = 0.0; }
+  }
+  if (lane < 4) {
+    const double q = L.hand_q[lane];
+    bx.mocap_quat[lane] = q;
+    if (!r2h) { bx.quat[lane] = q; bx.weld_rel[lane] = lane == 0 ? 1.0 : 0.0; }
+  }
+  bx.weld_active = r2h ? 0 : 1;
   wave_sync();
 }
 #endif
@@ -797,7 +815,7 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     if (lane == 0) bx.quat[0] = 1.0;
     wave_sync();
 #if HRG_HANDOVER
-    if (m.task == HRG_TASK_HANDOVER_H2R) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (635-647, 686-711)
+    if (m.task >= HRG_TASK_HANDOVER_H2R) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (H2R 635-647, 686-711; R2H 650-660, 700-706)
 #endif
   }
 #else
@@ -873,7 +891,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
   // One loop body for both passes keeps a single inlined copy of the contact and solver code.
 #pragma unroll 1
-  for (int pass = m.task == HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
+  for (int pass = m.task >= HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
     collide(dm_, lane, &ncon);
     if (pass == 1) {
       int hc = L.acc_has_collision, ct = L.acc_collision_type;
@@ -887,11 +905,17 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
       const int hl = dm->clips.clip_holding_hand[clip_of(dm, gid, s.episode, s.anim_index)];
       const int site = hl ? m.site_lhand : m.site_rhand;
       wave_sync();
-      if (lane < 3) L.bx.mocap_pos[lane] = s.human_site[site][lane];
+      if (lane < 3) {
+        const double mp = s.human_site[site][lane] + L.hand_off[lane];
+        L.bx.mocap_pos[lane] = mp;
+        if (m.task == HRG_TASK_HANDOVER_R2H) L.bx.target[lane] = mp;   // target_pos property: the hand the object has to reach (448-450)
+      }
       if (lane < 4) L.bx.mocap_quat[lane] = L.hand_q[lane];
       wave_sync();
       robot_chain_fk(dm_, lane, false);
       robot_dynamics_terms(dm_, lane);
+      // the human capsules share their LDS with the solver scratch of the step above: lay them out again for the second collision phase
+      human_pose_fk(dm_, lane, clip_of(dm, gid, s.episode, s.anim_index), s.animation_time);
     }
   }
 #else
@@ -963,8 +987,12 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   const int in_zone = sqrt(o2t) <= m.goal_dist;
   // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
   const int inspection = m.task == HRG_TASK_INSPECTION || m.task == HRG_TASK_HANDOVER_H2R;   // success = the task's animation ran to its end
-  const int goal_reached = !crash && (inspection ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone);
+  const int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : (inspection ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
   double r = goal_reached ? m.task_reward : ((inspection && in_zone) ? m.object_at_target_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
+#if HRG_HANDOVER
+  if (m.task == HRG_TASK_HANDOVER_R2H)   // robot_human_handover_cartesian_env.py:507-555
+    r = goal_reached ? m.task_reward : (bx.task_phase == HRG_R2H_RETREAT ? m.object_in_human_hand_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
+#endif
   const double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
 #else
   double dist2 = 0;
@@ -1016,6 +1044,40 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
   wave_sync();
 #if HRG_HANDOVER
+  if (m.task == HRG_TASK_HANDOVER_R2H && !d) {
+    if (goal_reached && !m.done_at_success) { // _on_goal_reached (robot_human_handover_cartesian_env.py:662-676): next placement, next animation, the human lets go
+      const int oi = (bx.obj_index + 1) % m.n_obj_placements;
+      double po[3];
+      placement_of(dm, gid, s.episode, oi, 0, po);
+      const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+      wave_sync();
+      bx.obj_index = oi;
+      if (lane < 3) bx.pos[lane] = po[lane];
+      if (lane < 4) bx.quat[lane] = lane == 0 ? 1.0 : 0.0;
+      s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+      bx.task_phase = HRG_R2H_APPROACH; bx.n_delayed = 0;
+      wave_sync();
+      handover_pickup(dm_, lane, gid, false);   // poses the mocap body / target, weld off
+    }
+    // RobotHumanHandoverCart.step (452-474): the human takes the object when it touches the palm of the extended hand; the weld keeps the
+    // pose the object has relative to the hand mocap body at that moment (730-748)
+    const int ph = bx.task_phase;
+    wave_sync();
+    if (ph == HRG_R2H_REACH_OUT && L.palm_hit) {
+      double Rm[9], dv[3], off[3], wr[4];
+      const double qm[4] = {bx.mocap_quat[0], bx.mocap_quat[1], bx.mocap_quat[2], bx.mocap_quat[3]}, qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]};
+      const double qc[4] = {qm[0], -qm[1], -qm[2], -qm[3]};
+      quat2mat(Rm, qm);
+      for (int a = 0; a < 3; a++) dv[a] = bx.pos[a] - bx.mocap_pos[a];
+      for (int a = 0; a < 3; a++) off[a] = Rm[a] * dv[0] + Rm[3 + a] * dv[1] + Rm[6 + a] * dv[2];
+      quatmul(wr, qc, qo);
+      wave_sync();
+      if (lane < 3) bx.weld_off[lane] = off[lane];
+      if (lane < 4) bx.weld_rel[lane] = wr[lane];
+      bx.weld_active = 1; bx.task_phase = HRG_R2H_RETREAT; bx.n_handed_over = bx.n_handed_over + 1;
+    }
+    wave_sync();
+  } else
   if (m.task == HRG_TASK_HANDOVER_H2R && !d) {
     if (goal_reached && !m.done_at_success) { // _on_goal_reached (human_robot_handover_cartesian_env.py:649-668): next target, next animation, the human picks the object up again
       const int ti = (bx.tgt_index + 1) % m.n_targets;
@@ -1262,11 +1324,11 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_HANDOVER_H2R) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
-  if (desc->task == HRG_TASK_HANDOVER_H2R)
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_HANDOVER_R2H) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task >= HRG_TASK_HANDOVER_H2R)
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop2[c] >= 0 && clips->clip_n_loop2[c] <= HRG_MAX_LOOP)) return fail(HRG_ERR_INVALID, "HumanRobotHandoverCart: at most 4 loop sines per stage");
-  if (desc->task == HRG_TASK_INSPECTION || desc->task == HRG_TASK_HANDOVER_H2R)
+  if (desc->task == HRG_TASK_INSPECTION || desc->task >= HRG_TASK_HANDOVER_H2R)
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP && clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1]))
         return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");
@@ -1391,7 +1453,7 @@ void hrg_batch_destroy(hrg_batch* b) {
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
-  if (b->task == HRG_TASK_HANDOVER_H2R) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  if (b->task >= HRG_TASK_HANDOVER_H2R) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   HIPCHK(hipGetLastError());
@@ -1407,7 +1469,7 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  if (b->task == HRG_TASK_HANDOVER_H2R)
+  if (b->task >= HRG_TASK_HANDOVER_H2R)
     hrg_ho_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else if (b->task != HRG_TASK_REACH)

@@ -244,7 +244,8 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
   }
 #if HRG_HANDOVER
   if (hold_body >= 0 && lane == hold_body) { // _update_mocap_body_transform (human_robot_handover_cartesian_env.py:609-633): hand rotation turned -+90 deg about its y axis
-    const double ang = hold_left ? 0.5 * HRG_PI : -0.5 * HRG_PI, c = cos(ang), sn = sin(ang);
+    const int r2h = m.task == HRG_TASK_HANDOVER_R2H;  // robot_human_handover_cartesian_env.py:615-648: opposite turn, offset towards the thumb
+    const double ang = (hold_left != r2h) ? 0.5 * HRG_PI : -0.5 * HRG_PI, c = cos(ang), sn = sin(ang);
     const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
     double Rm[9], q[4];
     m3mul(Rm, R, Ry);
@@ -254,6 +255,10 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
     else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
     for (int a = 0; a < 4; a++) L.hand_q[a] = q[a];
+    const double off[3] = {r2h ? (hold_left ? 0.02 : -0.02) : 0.0, r2h ? -0.03 : 0.0, r2h ? -0.03 : 0.0};
+    double to[3];
+    m3mulv(to, Rm, off);
+    for (int a = 0; a < 3; a++) L.hand_off[a] = to[a];
   }
 #endif
   // sites of the measured joints: site k sits at the anchor of body meas_body[k]
@@ -272,6 +277,26 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     }
   }
   wave_sync();
+}
+
+// pose of the human at frame `at` of clip `clip`: root pose chain (human_env.py:1736-1763) + tree kinematics -> L.hcap, human_site
+DI void human_pose_fk(const DevModel* __restrict__ dm_, int lane, int clip, int at, int hold_body = -1, int hold_left = 0) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  const double* fr = dm->clips.frames + (dm->clips.clip_offset[clip] + at) * HRG_FRAME_DIM;
+  double qi[4] = {dm->clips.clip_quat[clip][3], dm->clips.clip_quat[clip][0], dm->clips.clip_quat[clip][1], dm->clips.clip_quat[clip][2]};
+  double qbi[4], Rbi[9], pa[3], pr[3], mp[3], mq[4], q1[4];
+  quatmul(qbi, m.human_base_quat, qi);
+  quat2mat(Rbi, qbi);
+  for (int a = 0; a < 3; a++) pa[a] = fr[a] + dm->clips.clip_pos_offset[clip][a];
+  m3mulv(pr, Rbi, pa);
+  v3add(mp, pr, s.human_pos_offset);
+  double qa[4] = {fr[6], fr[3], fr[4], fr[5]};
+  quatmul(q1, s.human_rot_offset, qbi);
+  quatmul(mq, q1, qa);
+  human_fk_lanes(dm_, lane, mp, mq, fr + 7, hold_body, hold_left);
 }
 
 #if HRG_BOX
@@ -351,6 +376,23 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
     hold_left = dm->clips.clip_holding_hand[clip];
     hold_body = m.meas_body[hold_left ? m.site_lhand : m.site_rhand];
   }
+  if (m.task == HRG_TASK_HANDOVER_R2H) { // RobotHumanHandoverCart._compute_animation_time (robot_human_handover_cartesian_env.py:556-606); wave-uniform
+    hrg_box_state& bx = L.bx;
+    const int classic = at, k0 = dm->clips.clip_keyframes[clip][0], k1 = dm->clips.clip_keyframes[clip][1], len = dm->clips.clip_len[clip];
+    int phase = bx.task_phase, nd = bx.n_delayed;
+    if (at > k0 && phase == HRG_R2H_APPROACH) phase = HRG_R2H_REACH_OUT;
+    if ((double)at > (double)k0 + (double)(k1 - k0) / 2.0 && phase == HRG_R2H_REACH_OUT) {
+      at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, 0, dm->clips.clip_n_loop[clip], (double)classic, (double)(k0 + k1) / 2.0);
+      nd = classic - at;
+    }
+    if (phase == HRG_R2H_RETREAT) at -= nd;
+    if (at >= len - 1) { phase = HRG_R2H_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+    wave_sync();
+    bx.task_phase = phase; bx.n_delayed = nd;
+    hold_left = dm->clips.clip_holding_hand[clip];
+    hold_body = m.meas_body[hold_left ? m.site_lhand : m.site_rhand];
+  }
 #endif
 #endif
   if (at > dm->clips.clip_len[clip] - 1) {
@@ -360,22 +402,10 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
     clip = clip_of(dm, gid, s.episode, anim_index);
   }
   s.anim_index = anim_index; s.anim_start_time = anim_start; s.animation_time = at;
-  const double* fr = dm->clips.frames + (dm->clips.clip_offset[clip] + at) * HRG_FRAME_DIM;
-  // human_env.py:1736-1763
-  double qi[4] = {dm->clips.clip_quat[clip][3], dm->clips.clip_quat[clip][0], dm->clips.clip_quat[clip][1], dm->clips.clip_quat[clip][2]};
-  double qbi[4], Rbi[9], pa[3], pr[3], mp[3], mq[4], q1[4];
-  quatmul(qbi, m.human_base_quat, qi);
-  quat2mat(Rbi, qbi);
-  for (int a = 0; a < 3; a++) pa[a] = fr[a] + dm->clips.clip_pos_offset[clip][a];
-  m3mulv(pr, Rbi, pa);
-  v3add(mp, pr, s.human_pos_offset);
-  double qa[4] = {fr[6], fr[3], fr[4], fr[5]};
-  quatmul(q1, s.human_rot_offset, qbi);
-  quatmul(mq, q1, qa);
 #if HRG_BOX
-  human_fk_lanes(dm_, lane, mp, mq, fr + 7, hold_body, hold_left);
+  human_pose_fk(dm_, lane, clip, at, hold_body, hold_left);
 #else
-  human_fk_lanes(dm_, lane, mp, mq, fr + 7);
+  human_pose_fk(dm_, lane, clip, at);
 #endif
 }
 
@@ -742,6 +772,18 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
         c.g1 = pl ? GEOM_FLOOR : GEOM_TABLE; c.g2 = GEOM_BOX; c.b1 = -1; c.b2 = BODY_BOX; c.dist = dist;
       }
     }
+#if HRG_HANDOVER
+    { // RobotHumanHandoverCart._get_object_palm_contact_pos (476-505): does the cube touch the palm (= the collision capsule of the holding hand's body)?
+      bool palm = false;
+      if (m.task == HRG_TASK_HANDOVER_R2H && lane == 32) {
+        const int hl = dm->clips.clip_holding_hand[clip_of(dm, (int64_t)L.st.stream_id, L.st.episode, L.st.anim_index)];
+        const int body = m.meas_body[hl ? m.site_lhand : m.site_rhand];
+        double cs[3], cb[3];
+        palm = sqrt(seg_box(&L.hcap[body][0], &L.hcap[body][3], bx.pos, L.bR, hb, cs, cb)) - m.hcap_r[body] < 0;
+      }
+      L.palm_hit = __any(palm);
+    }
+#endif
     const uint64_t mask = __ballot(hit);
     if (hit) {
       const int idx = base + __popcll(mask & lt);

@@ -98,13 +98,30 @@ HANDOVER_H2R_ENV_KWARGS = dict(
     goal_exit_tolerance=0.0,
     done_at_success=True,
 )
+# RobotHumanHandoverCart constructor defaults overlaid with config/environment/(default/)robot_human_handover_cart.yaml
+HANDOVER_R2H_ENV_KWARGS = dict(
+    PICK_PLACE_ENV_KWARGS,
+    shield_type="PFL",
+    table_full_size=[1.0, 2.0, 0.05],
+    human_animation_freq=90,
+    human_rand=[0.0, 0.2, 0.1],
+    n_animations_sampled_per_100_steps=2,
+    n_targets_sampled_per_100_steps=0,
+    goal_dist=0.06,
+    object_in_human_hand_reward=0.0,
+    object_gripped_reward=-0.25,
+    collision_reward=-1.0,
+    done_at_success=True,
+)
 ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
+                "RobotHumanHandoverCart": HANDOVER_R2H_ENV_KWARGS,
                 "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
                 "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
-BOX_TASKS = ("PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart")
+BOX_TASKS = ("PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart",
+             "RobotHumanHandoverCart")
 _TASK_OF = {"PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
             "PickPlacePointingHumanCart": "HRG_TASK_POINTING", "HumanObjectInspectionCart": "HRG_TASK_INSPECTION",
-            "HumanRobotHandoverCart": "HRG_TASK_HANDOVER_H2R"}
+            "HumanRobotHandoverCart": "HRG_TASK_HANDOVER_H2R", "RobotHumanHandoverCart": "HRG_TASK_HANDOVER_R2H"}
 # RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
 FINGER_QPOS_RANGE = [[-0.0118366, 0.011499], [0.0118366, -0.011499]]
 
@@ -507,6 +524,9 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.tgt_bin[:] = [bx * 0.35, bx * 0.6, by * -0.45, by * -0.25]
         if env_id in ("HumanObjectInspectionCart", "PickPlacePointingHumanCart"):   # human_object_inspection_cartesian_env.py:695-710, pick_place_pointing_human_cartesian_env.py:419-434
             d.obj_bin[:] = [bx * 0.35, bx * 0.75, -by * 0.15, by * 0.15]
+        if env_id == "RobotHumanHandoverCart":      # robot_human_handover_cartesian_env.py:750-765
+            d.obj_bin[:] = [bx * 0.45, bx * 0.75, -by * 0.15, by * 0.15]
+            d.object_in_human_hand_reward = float(kw["object_in_human_hand_reward"])
         if env_id == "HumanRobotHandoverCart":      # human_robot_handover_cartesian_env.py:713-730
             d.tgt_bin[:] = [bx * 0.45, bx * 0.85, -by * 0.15, by * 0.15]
         if env_id in ("HumanObjectInspectionCart", "HumanRobotHandoverCart"):

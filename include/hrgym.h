@@ -104,11 +104,14 @@ enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 /* tasks: ReachHuman (reach_human_env.py), PickPlaceHumanCart (pick_place_human_cartesian_env.py) */
 enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */,
        HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */,
-       HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */ };
+       HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */,
+       HRG_TASK_HANDOVER_R2H = 5 /* RobotHumanHandoverCart (robot_human_handover_cartesian_env.py) */ };
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
 /* HumanRobotHandoverPhase, human_robot_handover_cartesian_env.py:50-56 (same numbering) */
 enum { HRG_PHASE_PRESENT = 1, HRG_PHASE_WAIT = 2 };
+/* RobotHumanHandoverPhase, robot_human_handover_cartesian_env.py:49-55 */
+enum { HRG_R2H_APPROACH = 0, HRG_R2H_REACH_OUT = 1, HRG_R2H_RETREAT = 2, HRG_R2H_COMPLETE = 3 };
 
 enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
 
@@ -238,6 +241,7 @@ typedef struct hrg_model_desc {
   double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
   double object_gripped_reward;
   double object_at_target_reward, goal_exit_tolerance; /* HumanObjectInspectionCart, human_object_inspection_cartesian_env.py:318-321 */
+  double object_in_human_hand_reward; /* RobotHumanHandoverCart, robot_human_handover_cartesian_env.py:530-555 */
   double finger_qpos_range[2][HRG_NFINGER]; /* RethinkValidGripper.qpos_range, rethink_valid_gripper.py:29-42 */
   /* ---- Cartesian action front-end (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py:26-142;
    *      config/wrappers/ik_position_delta/default_ik_position_delta.yaml).  When enabled an action row is

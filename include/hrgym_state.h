@@ -94,6 +94,8 @@ typedef struct hrg_box_state {
   int32_t weld_active;          /* eq_active of the object <-> hand mocap weld (handover tasks) */
   int32_t n_handed_over;        /* _n_object_handed_over */
   double mocap_pos[3], mocap_quat[4]; /* pose of the mocap body at the human's holding hand (set once per cycle) */
+  double weld_off[3], weld_rel[4];    /* relative pose of the weld: object origin in the mocap frame, q_mocap^-1 q_obj (identity when the human
+                                       * picks the object up from its own hand; taken at the palm contact in RobotHumanHandoverCart, 730-748) */
 } hrg_box_state;
 
 #ifdef __cplusplus

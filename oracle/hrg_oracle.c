@@ -413,6 +413,17 @@ static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hr
     if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
     if (at < 0) at = 0;
   }
+  if (m->task == HRG_TASK_HANDOVER_R2H) { /* RobotHumanHandoverCart._compute_animation_time, robot_human_handover_cartesian_env.py:556-606 */
+    const int classic = at, k0 = b->clips.clip_keyframes[clip][0], k1 = b->clips.clip_keyframes[clip][1], len = b->clips.clip_len[clip];
+    if (at > k0 && bx->task_phase == HRG_R2H_APPROACH) bx->task_phase = HRG_R2H_REACH_OUT;
+    if ((double)at > (double)k0 + (double)(k1 - k0) / 2.0 && bx->task_phase == HRG_R2H_REACH_OUT) { /* hold the hand out: loop around the middle of the keyframes */
+      at = (int)layered_sines(b, gid, s, clip, 0, b->clips.clip_n_loop[clip], (double)classic, (double)(k0 + k1) / 2.0);
+      bx->n_delayed = classic - at;
+    }
+    if (bx->task_phase == HRG_R2H_RETREAT) at -= bx->n_delayed;
+    if (at >= len - 1) { bx->task_phase = HRG_R2H_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+  }
   s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
     s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
@@ -1330,7 +1341,8 @@ static void handover_mocap(const hrgo_batch* B, int64_t gid, const hrg_env_state
   const hrg_model_desc* m = &B->m;
   const int left = B->clips.clip_holding_hand[clip_of(B, gid, s, s->anim_index)];
   const int site = left ? m->site_lhand : m->site_rhand, body = m->meas_body[site];
-  const double ang = left ? 0.5 * PI : -0.5 * PI, c = cos(ang), sn = sin(ang);
+  const int r2h = m->task == HRG_TASK_HANDOVER_R2H; /* robot_human_handover_cartesian_env.py:615-648: opposite turn, offset towards the thumb */
+  const double ang = (left != r2h) ? 0.5 * PI : -0.5 * PI, c = cos(ang), sn = sin(ang);
   const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
   double R[9];
   m3mul(R, hk->R[body], Ry);
@@ -1342,12 +1354,41 @@ static void handover_mocap(const hrgo_batch* B, int64_t gid, const hrg_env_state
   else { double S = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / S; q[1] = (R[2] + R[6]) / S; q[2] = (R[5] + R[7]) / S; q[3] = 0.25 * S; }
   for (int a = 0; a < 4; a++) bx->mocap_quat[a] = q[a];
   v3cpy(bx->mocap_pos, s->human_site[site]);
+  if (r2h) {
+    const double off[3] = {left ? 0.02 : -0.02, -0.03, -0.03};
+    double t[3];
+    m3mulv(t, R, off);
+    v3add(bx->mocap_pos, bx->mocap_pos, t);
+    v3cpy(bx->target, bx->mocap_pos); /* target_pos property: the hand the object has to reach (448-450) */
+  }
 }
 /* _human_pickup_object (700-711): the object jumps into the hand and the weld is switched on */
 static void handover_pickup(hrg_box_state* bx) {
   v3cpy(bx->pos, bx->mocap_pos);
   for (int a = 0; a < 4; a++) bx->quat[a] = bx->mocap_quat[a];
+  v3set(bx->weld_off, 0, 0, 0);
+  bx->weld_rel[0] = 1; bx->weld_rel[1] = bx->weld_rel[2] = bx->weld_rel[3] = 0;
   bx->weld_active = 1;
+}
+
+/* _human_pickup_object of RobotHumanHandoverCart (730-748): the weld takes the pose the object has relative to the hand mocap body at that
+ * moment (the reference re-poses a grip sub-body at the palm contact; same rigid attachment, expressed at the object's origin) */
+static void handover_attach(hrg_box_state* bx) {
+  double Rm[9], d[3], qc[4] = {bx->mocap_quat[0], -bx->mocap_quat[1], -bx->mocap_quat[2], -bx->mocap_quat[3]};
+  quat2mat(Rm, bx->mocap_quat);
+  v3sub(d, bx->pos, bx->mocap_pos);
+  for (int a = 0; a < 3; a++) bx->weld_off[a] = Rm[a] * d[0] + Rm[3 + a] * d[1] + Rm[6 + a] * d[2]; /* Rm' d */
+  quatmul(bx->weld_rel, qc, bx->quat);
+  bx->weld_active = 1;
+}
+/* contact between the cube and the palm (= the collision capsule of the holding hand's body): _get_object_palm_contact_pos (476-505) */
+static int palm_contact(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, const hrg_box_state* bx, const human_kin* hk) {
+  const hrg_model_desc* m = &B->m;
+  const int left = B->clips.clip_holding_hand[clip_of(B, gid, s, s->anim_index)];
+  const int body = m->meas_body[left ? m->site_lhand : m->site_rhand];
+  double Rx[9], t, cs[3], cb[3];
+  quat2mat(Rx, bx->quat);
+  return sqrt(seg_box(hk->cap1[body], hk->cap2[body], bx->pos, Rx, m->box_half, &t, cs, cb)) - m->hcap_r[body] < 0;
 }
 
 static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
@@ -1409,6 +1450,14 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
       handover_mocap(B, gid, s, bx, &hk);
       handover_pickup(bx);
     }
+    if (m->task == HRG_TASK_HANDOVER_R2H) { /* _reset_animation (the human holds nothing) + _control_human (650-660, 700-706): object in its bin, hand = target */
+      human_kin hk;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk, s->human_site);
+      handover_mocap(B, gid, s, bx, &hk);
+    }
     v3cpy(bx->obs_pos, bx->pos);
   } else goal_of(B, gid, s, 0, s->cur_goal);
   if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
@@ -1428,6 +1477,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   double M[NV * NV], bias[NV];
   hrg_box_state* bx = m->task != HRG_TASK_REACH ? &B->box[e] : NULL;
   const int nvt = bx ? NVT : NV, ncon_dyn = bx ? HRG_NCON_DYN_BOX : HRG_NCON_DYN;
+  int palm_hit = 0;
   for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
     /* ---- sim.forward() #1 (human_env.py:504): positions, M, bias at the current state ---- */
     robot_fk(m, s->qpos, &k);
@@ -1469,7 +1519,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     human_fk(m, mp, mq, qh, &hk, s->human_site);
     /* HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human
      * pose before it re-poses the hand mocap body: pass 0 = that step (no bookkeeping), pass 1 = the cycle's regular step */
-    for (int pass = m->task == HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
+    for (int pass = m->task >= HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
     /* ---- contacts + bookkeeping (human_env.py:522) ---- */
     contact_t con[HRG_NCON_MAX];
     int ncon = collide(m, &k, &hk, bx, con);
@@ -1488,6 +1538,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       v3add(rc[c], b < 0 ? m->base_pos : k.p[b], t);
     }
     if (pass == 1) {
+      if (m->task == HRG_TASK_HANDOVER_R2H) palm_hit = palm_contact(B, gid, s, bx, &hk); /* sim.data.contact of the cycle's collision phase */
       classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
       s->ncon = ncon;
       for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
@@ -1553,8 +1604,13 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     }
     if (bx && bx->weld_active) { /* weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
                                   * [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; the mocap body has no velocity; relpose = identity */
-      double epos[3], erot[3], qc[4] = {bx->mocap_quat[0], -bx->mocap_quat[1], -bx->mocap_quat[2], -bx->mocap_quat[3]}, qe[4];
-      v3sub(epos, bx->pos, bx->mocap_pos);
+      double epos[3], erot[3], qt[4], qe[4], Rm[9], tp[3];
+      quat2mat(Rm, bx->mocap_quat);
+      m3mulv(tp, Rm, bx->weld_off);
+      v3add(tp, tp, bx->mocap_pos);          /* where the weld wants the object: mocap frame o relative pose */
+      v3sub(epos, bx->pos, tp);
+      quatmul(qt, bx->mocap_quat, bx->weld_rel);
+      double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
       quatmul(qe, bx->quat, qc);
       if (qe[0] < 0) for (int a = 0; a < 4; a++) qe[a] = -qe[a];
       const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
@@ -1632,6 +1688,9 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     if (m->task == HRG_TASK_INSPECTION || m->task == HRG_TASK_HANDOVER_H2R) { /* success = the animation ran to its end; human_object_inspection_cartesian_env.py:553-600, human_robot_handover_cartesian_env.py:485-528 */
       goal_reached = !crash && bx->task_phase == HRG_PHASE_COMPLETE;
       r = goal_reached ? m->task_reward : (in_zone ? m->object_at_target_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
+    } else if (m->task == HRG_TASK_HANDOVER_R2H) { /* robot_human_handover_cartesian_env.py:507-555 */
+      goal_reached = !crash && bx->task_phase == HRG_R2H_COMPLETE;
+      r = goal_reached ? m->task_reward : (bx->task_phase == HRG_R2H_RETREAT ? m->object_in_human_hand_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
     } else {
       goal_reached = !crash && in_zone;
       r = goal_reached ? m->task_reward : (bx->gripped ? m->object_gripped_reward : -1.0); /* _sparse_reward, 471-500 */
@@ -1670,7 +1729,26 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   info[HRG_INFO_TRUNCATED] = 0;
   info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
   info[HRG_INFO_N_OBJECT_HANDED_OVER] = bx ? bx->n_handed_over : 0;
-  if (bx && m->task == HRG_TASK_HANDOVER_H2R) {
+  if (bx && m->task == HRG_TASK_HANDOVER_R2H) {
+    if (goal_reached && !m->done_at_success) { /* _on_goal_reached (662-676): next placement, next animation, the human lets go */
+      bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
+      placement_of(B, gid, s->episode, bx->obj_index, 0, bx->pos);
+      bx->quat[0] = 1; bx->quat[1] = bx->quat[2] = bx->quat[3] = 0;
+      s->anim_index = (s->anim_index + 1) % m->n_anim_ids;
+      s->animation_time = 0;
+      s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+      bx->task_phase = HRG_R2H_APPROACH; bx->n_delayed = 0; bx->weld_active = 0;
+      human_kin hk2;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk2, s->human_site);
+      handover_mocap(B, gid, s, bx, &hk2);
+      hk = hk2;
+    }
+    /* RobotHumanHandoverCart.step (452-474): the human takes the object when it touches the palm of the extended hand */
+    if (bx->task_phase == HRG_R2H_REACH_OUT && palm_hit) { handover_attach(bx); bx->task_phase = HRG_R2H_RETREAT; bx->n_handed_over++; }
+  } else if (bx && m->task == HRG_TASK_HANDOVER_H2R) {
     double o2t = 0;
     for (int a = 0; a < 3; a++) o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]);
     if (goal_reached && !m->done_at_success) { /* _on_goal_reached (649-668): next target, next animation, the human picks the object up again */

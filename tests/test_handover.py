@@ -120,3 +120,90 @@ def test_hip_matches_oracle_on_the_handover_task():
                 G.set_box(e, O.get_box(e))
     assert wins >= 3 and i_o[:, 13].max() >= 1
     O.close(); G.close()
+
+
+# ------------------------------------------------------------------------------------------------ robot -> human
+R2H = dict(env_id="RobotHumanHandoverCart")
+R_APPROACH, R_REACH_OUT, R_RETREAT, R_COMPLETE = range(4)
+# control_freq 50: 5 shield cycles per policy step, so that a cube put into the palm is still there when the step's last collision
+# phase looks for the palm contact (at 10 Hz it would have fallen 20 cm by then: only a gripper can hold it there)
+KW2 = dict(shield_type="OFF", horizon=1000, seed=3, done_at_success=False, object_in_human_hand_reward=-0.5, control_freq=50)
+T_HAND = 40   # policy step of the handover (the hand is held out from ~step 25 on)
+
+
+def _clips2():
+    return hrg.synthetic_clips(2, seed=0, min_frames=120, max_frames=160, handover="r2h")
+
+
+def _scenario2(k, batches, n_envs):
+    """Even envs: at step T_HAND (the human holds the hand out) the cube is put into the palm; odd envs never hand it over."""
+    if k == T_HAND:
+        for e in range(0, n_envs, 2):
+            bx = batches[0].get_box(e)
+            put_box(batches, e, pos=list(bx.mocap_pos), vel=[0] * 6, zero_warm=False)
+    return np.zeros((n_envs, 7))
+
+
+def test_robot_to_human_handover_on_the_oracle():
+    from oracle.oracle import OracleBatch
+    clips = _clips2()
+    d = hrg.build_model_desc(KW2, n_clips=clips.n_clips, **R2H)
+    assert d.task == CONST["HRG_TASK_HANDOVER_R2H"] and d.goal_dist == 0.06 and d.n_targets == 1
+    np.testing.assert_allclose(list(d.obj_bin), [0.45 * 0.45, 0.45 * 0.75, -0.95 * 0.15, 0.95 * 0.15])        # 750-765
+    B = OracleBatch(d, clips, 4)
+    obs = B.reset()
+    for e in range(4):
+        bx = B.get_box(e)
+        assert bx.weld_active == 0 and d.obj_bin[0] <= bx.pos[0] <= d.obj_bin[1]
+        np.testing.assert_allclose(obs[e, 50:53], list(bx.mocap_pos), rtol=1e-6)          # the target is the hand held out (448-450)
+    ph, rew, weld, lag = [], [], [], []
+    for k in range(130):
+        o, r, dn, info = B.step(_scenario2(k, [B], 4))
+        assert not info[:, 11].any()
+        bxs = [B.get_box(e) for e in range(4)]
+        ph.append([b.task_phase for b in bxs]); rew.append(r.copy()); weld.append([b.weld_active for b in bxs])
+        want = [np.array(b.mocap_pos) + hrg.model._quat2mat(list(b.mocap_quat)) @ np.array(b.weld_off) for b in bxs]
+        lag.append([np.linalg.norm(np.array(b.pos) - w) for b, w in zip(bxs, want)])
+        np.testing.assert_allclose(o[0, 50:53], list(bxs[0].mocap_pos) if not (r[0] > 0) else o[0, 50:53], rtol=1e-6)
+    ph, rew, weld, lag = map(np.array, (ph, rew, weld, lag))
+    assert (ph[:15, 1] == R_APPROACH).all() and (ph[32:, 1] == R_REACH_OUT).all() and (weld[:, 1] == 0).all() and (rew[:, 1] == -1).all()
+    T = T_HAND
+    assert ph[T - 1, 0] == R_REACH_OUT and ph[T, 0] == R_RETREAT and weld[T, 0] == 1           # palm contact -> the human holds the object
+    done_step = int(np.argmax(rew[:, 0] > 0))
+    assert done_step > T + 2 and (rew[T + 1:done_step, 0] == -0.5).all() and (ph[T + 1:done_step, 0] == R_RETREAT).all()
+    assert np.max(lag[T + 2:done_step, 0]) < 0.2                                                # carried along with the hand
+    assert ph[done_step, 0] == R_APPROACH and weld[done_step, 0] == 0 and B.get_box(0).obj_index == 1   # next round: object back in its bin
+    B.close()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_on_the_robot_to_human_handover():
+    import torch
+    from helpers import ATOL, RTOL, assert_state_close, make_pair
+    clips = _clips2()
+    kw = dict(KW2, shield_type="PFL")
+    O, G = make_pair(6, kw, clips=clips, **R2H)
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    for e in range(6):
+        assert_state_close(O.get_box(e), G.get_box(e), f"reset env {e} box")
+    rng = np.random.RandomState(0)
+    wins = 0
+    for k in range(130):
+        a = _scenario2(k, [O, G], 6)
+        a[:, :6] = rng.uniform(-0.2, 0.2, (6, 6))
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=1e-6, err_msg=f"step {k}")
+        wins += int((r_o > 0).sum())
+        for e in range(6):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+            assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
+            if k % 8 == 7:
+                G.set_state(e, O.get_state(e))
+                G.set_box(e, O.get_box(e))
+    assert wins >= 3
+    O.close(); G.close()
