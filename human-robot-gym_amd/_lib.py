@@ -88,7 +88,9 @@ class HipBatch:
     All I/O buffers are torch tensors on the batch's device; `step` is asynchronous (ordered on torch's
     current stream of that device)."""
 
-    def __init__(self, desc, clips, n_envs, env_id0=0, device=0):
+    def __init__(self, desc, clips, n_envs, env_id0=0, device=0, out=None):
+        """`out`: optional (obs, term_obs, reward, info, done) device tensors to write into — row slices of a larger block that several
+        batches share (mixed.MixedBatch); by default the batch allocates its own packed block."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("HipBatch needs a ROCm GPU (torch.cuda.is_available() is False); there is no CPU fallback")
@@ -109,6 +111,14 @@ class HipBatch:
             # observations) is the part a step publishes to the other ranks
             from .dist import packed_layout
             n, od, idim = self.n, C["HRG_OBS_DIM"], C["HRG_INFO_DIM"]
+            if out is not None:
+                self.obs, self.term_obs, self.reward, self.info, self.done = out
+                want = [((n, od), torch.float32), ((n, od), torch.float32), ((n,), torch.float32), ((n, idim), torch.int32), ((n,), torch.uint8)]
+                for t, (shape, dt) in zip(out, want):
+                    if tuple(t.shape) != shape or t.dtype != dt or t.device != self.device or not t.is_contiguous():
+                        raise ValueError(f"out tensor {tuple(t.shape)} {t.dtype} on {t.device}: expected contiguous {shape} {dt} on {self.device}")
+                self.packed = self.packed_head = self.packed_layout = None
+                return
             lay = packed_layout(n)
             offs, sizes, tot = lay["offsets"], lay["sizes"], lay["total"]
             self.packed = torch.zeros(tot, dtype=torch.uint8, device=self.device)

@@ -157,6 +157,9 @@ struct Lds {
   double bR[9];                          // its rotation matrix at the current substep
   double hand_q[4], hand_off[3];         // orientation of the hand mocap body / its offset from the hand site, computed with the human tree (handover tasks)
   int palm_hit, palm_pad;                // the cube touches the palm of the holding hand (RobotHumanHandoverCart)
+#if HRG_HANDOVER
+  double hcap_keep[HRG_NHB][6];          // the cycle's human capsules, kept across the first physics pass (hcap shares its LDS with the solver scratch)
+#endif
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators

@@ -890,15 +890,21 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   // HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human pose
   // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
   // One loop body for both passes keeps a single inlined copy of the contact and solver code.
+  if (m.task >= HRG_TASK_HANDOVER_H2R) {
+    for (int k = lane; k < HRG_NHB * 6; k += 64) (&L.hcap_keep[0][0])[k] = (&L.hcap[0][0])[k];
+  }
 #pragma unroll 1
   for (int pass = m.task >= HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
     collide(dm_, lane, &ncon);
+    STAMP(5);
     if (pass == 1) {
       int hc = L.acc_has_collision, ct = L.acc_collision_type;
       classify(dm_, ncon, &hc, &ct);
       L.acc_has_collision = hc; L.acc_collision_type = ct;
+      STAMP(6);
     }
     crash = dynamics_step(dm_, lane, ncon);
+    STAMP(7);
     if (pass == 0 && !crash) {
       s.time = s.time + m.timestep;
       eef_update(dm_);
@@ -915,7 +921,9 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
       robot_chain_fk(dm_, lane, false);
       robot_dynamics_terms(dm_, lane);
       // the human capsules share their LDS with the solver scratch of the step above: lay them out again for the second collision phase
-      human_pose_fk(dm_, lane, clip_of(dm, gid, s.episode, s.anim_index), s.animation_time);
+      for (int k = lane; k < HRG_NHB * 6; k += 64) (&L.hcap[0][0])[k] = (&L.hcap_keep[0][0])[k];
+      wave_sync();
+      STAMP(27);
     }
   }
 #else
@@ -1251,7 +1259,9 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #endif
 
 #ifdef HRG_STAMPS
-#if HRG_BOX
+#if HRG_HANDOVER
+#define hrg_debug_stamps hrg_debug_stamps_ho
+#elif HRG_BOX
 #define hrg_debug_stamps hrg_debug_stamps_box
 #endif
 extern "C" int hrg_debug_stamps(double* out, int reset) {

@@ -310,10 +310,14 @@ DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int
   return base * exp(z * log(sf));
 }
 // layered_sin_modulations (utils/animation_utils.py:91-119) over loop sines kfirst..kfirst+n-1 of the clip
+// (wave-uniform call; the 2n draws run on lanes 0..2n-1 and are handed round by shuffles, the sum runs in the reference's order)
 DI double layered_sines(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int kfirst, int n, double t, double start) {
+  static_assert(2 * HRG_MAX_LOOP <= 64, "one lane per loop property");
+  const int lane = (int)threadIdx.x, kk = lane % HRG_MAX_LOOP, sp = (lane / HRG_MAX_LOOP) & 1;
+  const double mine = loop_prop(dm, gid, episode, ai, clip, kfirst + (kk < n ? kk : 0), sp);
   double sum = 0;
   for (int k = 0; k < n; k++) {
-    const double A = loop_prop(dm, gid, episode, ai, clip, kfirst + k, 0), S = loop_prop(dm, gid, episode, ai, clip, kfirst + k, 1);
+    const double A = __shfl(mine, k), S = __shfl(mine, HRG_MAX_LOOP + k);
     sum += A * sin((t - start) / (A / S)) + start;
   }
   return sum - start * (double)(n - 1);

@@ -1,0 +1,85 @@
+"""Mixed-task batches (BASELINE.json's last configuration: the ICRA-2024 task suite in one batch, icra_2024_run_experiments.sh:4-9)."""
+import numpy as np
+import pytest
+
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd import mixed
+from human_robot_gym_amd.model import ENV_DEFAULTS
+
+
+def test_even_split_and_task_table():
+    assert mixed.split_evenly(4096, 4) == [1024] * 4
+    assert mixed.split_evenly(10, 4) == [3, 3, 2, 2] and sum(mixed.split_evenly(4097, 6)) == 4097
+    for env_id, kw in mixed.ICRA_TASKS:
+        assert env_id in ENV_DEFAULTS
+        assert kw["horizon"] == {"ReachHuman": 100}.get(env_id, 1000)          # icra_2024_run_experiments.sh:4-9
+        assert kw["shield_type"] == ("PFL" if "Handover" in env_id else "SSM")
+        clips = mixed.task_clips(env_id, 2, min_frames=60, max_frames=80)
+        assert clips.n_clips == 2
+
+
+def test_mixed_batch_fails_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        mixed.make_mixed_batch(8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("concurrent", [True, False])
+def test_mixed_batch_equals_the_per_task_batches(concurrent):
+    """Each task's rows of a mixed batch are bit-identical to that task stepped alone (same global env ids, same actions)."""
+    import torch
+    from human_robot_gym_amd._lib import HipBatch
+    n = 40
+    M = mixed.make_mixed_batch(n, n_clips=3, seed=5, concurrent=concurrent)
+    assert M.env_ids == [t[0] for t in mixed.ICRA_TASKS] and M.n == n
+    singles = []
+    for (env_id, kw), sl in zip(mixed.ICRA_TASKS, M.slices):
+        clips = mixed.task_clips(env_id, 3)
+        desc = hrg.build_model_desc(dict(kw, seed=5), n_clips=clips.n_clips, env_id=env_id)
+        singles.append(HipBatch(desc, clips, sl.stop - sl.start, env_id0=sl.start))
+    obs = M.reset().cpu().numpy()
+    for S, sl in zip(singles, M.slices):
+        np.testing.assert_array_equal(obs[sl], S.reset().cpu().numpy())
+    rng = np.random.RandomState(0)
+    for k in range(12):
+        a = torch.from_numpy(rng.uniform(-1, 1, (n, 7))).cuda()
+        o, r, d, i = [x.cpu().numpy().copy() for x in M.step(a)]
+        t = M.term_obs.cpu().numpy()
+        for S, sl in zip(singles, M.slices):
+            so, sr, sd, si = S.step(a[sl].contiguous())
+            np.testing.assert_array_equal(o[sl], so.cpu().numpy(), err_msg=f"step {k}")
+            np.testing.assert_array_equal(r[sl], sr.cpu().numpy())
+            np.testing.assert_array_equal(d[sl], sd.cpu().numpy())
+            np.testing.assert_array_equal(i[sl], si.cpu().numpy())
+            np.testing.assert_array_equal(t[sl], S.term_obs.cpu().numpy())
+    for S in singles:
+        S.close()
+    M.close()
+
+
+@pytest.mark.gpu
+def test_mixed_vec_env_surface():
+    env = mixed.make_mixed_vec_env(12, env_kwargs=dict(horizon=5), tasks=[(e, dict(k, horizon=5)) for e, k in mixed.ICRA_TASKS], n_clips=2, seed=1)
+    assert env.num_envs == 12 and env.observation_space.shape == (57,) and env.action_space.shape == (7,)
+    obs = env.reset()
+    assert obs.shape == (12, 57) and obs.dtype == np.float32
+    assert np.all(obs[env.task_slices["ReachHuman"], 39:53] == 0)              # cube columns: zero for ReachHuman
+    assert np.any(obs[env.task_slices["PickPlaceHumanCart"], 47:50] != 0)      # object_pos
+    rng = np.random.RandomState(0)
+    n_done = 0
+    for _ in range(6):
+        obs, rew, dones, infos = env.step(rng.uniform(-1, 1, (12, 7)))
+        assert [d["task"] for d in infos] == env.get_attr("task")
+        for d, done in zip(infos, dones):
+            assert ("terminal_observation" in d) == bool(done)
+            if done:
+                assert d["terminal_observation"].shape == (57,) and d["episode"]["l"] == 5
+        n_done += int(dones.sum())
+    assert n_done == 12                                                         # horizon 5: every env timed out exactly once
+    env2 = mixed.make_mixed_vec_env(8, obs_keys=["robot0_eef_pos", "dist_eef_to_human_head"], n_clips=2)
+    assert env2.reset().shape == (8, 4)
+    env.close()
+    env2.close()
