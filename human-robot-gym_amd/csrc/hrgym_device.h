@@ -155,6 +155,7 @@ struct Lds {
 #if HRG_BOX
   hrg_box_state bx;                      // the cube (streamed from its own HBM array)
   double bR[9];                          // its rotation matrix at the current substep
+  double bMr[9];                         // its world-frame rotational inertia  mean 1 + R diag(I - mean) R'  (exactly diagonal for a cube)
   double hand_q[4], hand_off[3];         // orientation of the hand mocap body / its offset from the hand site, computed with the human tree (handover tasks)
   int palm_hit, palm_pad;                // the cube touches the palm of the holding hand (RobotHumanHandoverCart)
 #if HRG_HANDOVER
@@ -386,10 +387,10 @@ DI double seg_seg(PA p1, PB q1, PC p2, PD q2, double* c1, double* c2) {
 }
 
 #if HRG_BOX
-// closest points of a segment and a cube (centre c, rotation R row-major, half edge hb): the squared distance along the
+// closest points of a segment and a box (centre c, rotation R row-major, half extents hb[3]): the squared distance along the
 // segment is a convex piecewise quadratic in t; safeguarded Newton on its derivative (exact inside one piece).
 template <class PA, class PB, class PC, class PR>
-DI double seg_box(PA p1, PB p2, PC c, PR R, double hb, double* on_seg, double* on_box) {
+DI double seg_box(PA p1, PB p2, PC c, PR R, const double* hb, double* on_seg, double* on_box) {
   double a[3], d[3], t0[3];
   v3sub(t0, p1, c);
   for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
@@ -398,8 +399,8 @@ DI double seg_box(PA p1, PB p2, PC c, PR R, double hb, double* on_seg, double* o
   double g0 = 0, g1 = 0, t;
   for (int k = 0; k < 3; k++) {
     const double x0 = a[k], x1 = a[k] + d[k];
-    g0 += (x0 > hb ? x0 - hb : (x0 < -hb ? x0 + hb : 0.0)) * d[k];
-    g1 += (x1 > hb ? x1 - hb : (x1 < -hb ? x1 + hb : 0.0)) * d[k];
+    g0 += (x0 > hb[k] ? x0 - hb[k] : (x0 < -hb[k] ? x0 + hb[k] : 0.0)) * d[k];
+    g1 += (x1 > hb[k] ? x1 - hb[k] : (x1 < -hb[k] ? x1 + hb[k] : 0.0)) * d[k];
   }
   if (g0 >= 0) t = 0;
   else if (g1 <= 0) t = 1;
@@ -410,7 +411,7 @@ DI double seg_box(PA p1, PB p2, PC c, PR R, double hb, double* on_seg, double* o
     for (int it = 0; it < 10; it++) {
       double g = 0, H = 0;
       for (int k = 0; k < 3; k++) {
-        const double x = a[k] + t * d[k], e = x > hb ? x - hb : (x < -hb ? x + hb : 0.0);
+        const double x = a[k] + t * d[k], e = x > hb[k] ? x - hb[k] : (x < -hb[k] ? x + hb[k] : 0.0);
         g += e * d[k];
         if (e != 0) H += d[k] * d[k];
       }
@@ -422,7 +423,7 @@ DI double seg_box(PA p1, PB p2, PC c, PR R, double hb, double* on_seg, double* o
     }
   }
   double x[3], y[3], e2 = 0;
-  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb, hb); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb[k], hb[k]); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
   for (int k = 0; k < 3; k++) {
     on_seg[k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
     on_box[k] = c[k] + R[3 * k] * y[0] + R[3 * k + 1] * y[1] + R[3 * k + 2] * y[2];

@@ -51,6 +51,16 @@ DI int row_zone(int type, double lim, double x) {  // which quadratic / linear p
 }
 
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
+#if HRG_BOX
+// row a (0..5) of the box's inertia block times the 6 box entries v: m v_a for the translation, the world-frame rotational inertia
+// row for the rotation (its off-diagonal entries are exact zeros for a cube)
+DI double box_Mrow(double mass, int a, const double* v) {
+  const Lds& L = g_L;
+  if (a < 3) return mass * v[a];
+  const int r = 3 * (a - 3);
+  return L.bMr[r + (a - 3)] * v[a] + L.bMr[r + (a - 2) % 3] * v[3 + (a - 2) % 3] + L.bMr[r + (a - 1) % 3] * v[3 + (a - 1) % 3];
+}
+#endif
 HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -75,14 +85,33 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     L.qacc[lane] = s.qacc_warmstart[lane];
   }
 #if HRG_BOX
-  // free cube: block-diagonal inertia (isotropic: no gyroscopic term), gravity only
+  // free box, world-frame angular velocity: M = blockdiag(m 1, R diag(I) R'), bias torque w x (R diag(I) R' w), gravity.  The rotational
+  // inertia is split into mean 1 + R diag(I - mean) R': a cube keeps an exactly diagonal M and no gyroscopic term
   hrg_box_state& bx = L.bx;
-  const double mdiag = (lane - NV) < 3 ? m.box_mass : m.box_inertia;  // inertia entry of system dof `lane` for NV <= lane < NVT
+  const bool aniso = !(m.box_inertia[0] == m.box_inertia[1] && m.box_inertia[1] == m.box_inertia[2]);   // model constant: wave-uniform
+  if (lane < 9) {
+    const int i = lane / 3, j = lane - 3 * i;
+    double t = 0;
+    if (aniso) for (int k = 0; k < 3; k++) t += L.bR[3 * i + k] * (m.box_inertia[k] - m.box_inertia_mean) * L.bR[3 * j + k];
+    L.bMr[lane] = (i == j ? m.box_inertia_mean : 0.0) + t;
+  }
+  wave_sync();
   if (lane >= NV && lane < NVT) {
     const int a = lane - NV;
-    const double ga = a < 3 ? m.gravity[a] : 0.0;
-    L.a0[lane] = ga;
-    L.Ma0[lane] = a < 3 ? m.box_mass * ga : 0.0;
+    double a0v = a < 3 ? m.gravity[a] : 0.0, Ma0v = a < 3 ? m.box_mass * a0v : 0.0;
+    if (aniso && a >= 3) {   // each rotational lane runs the short chain itself: a0 = R diag(1/I) R' ((R diag(I - mean) R' w) x w)
+      const double w[3] = {bx.vel[3], bx.vel[4], bx.vel[5]};
+      double Ld[3], Lw[3], tau[3], tl[3], ar[3];
+      for (int k = 0; k < 3; k++) Ld[k] = (m.box_inertia[k] - m.box_inertia_mean) * (L.bR[k] * w[0] + L.bR[3 + k] * w[1] + L.bR[6 + k] * w[2]);
+      for (int k = 0; k < 3; k++) Lw[k] = L.bR[3 * k] * Ld[0] + L.bR[3 * k + 1] * Ld[1] + L.bR[3 * k + 2] * Ld[2];
+      v3cross(tau, Lw, w);   // -(w x L)
+      for (int k = 0; k < 3; k++) tl[k] = (L.bR[k] * tau[0] + L.bR[3 + k] * tau[1] + L.bR[6 + k] * tau[2]) / m.box_inertia[k];
+      for (int k = 0; k < 3; k++) ar[k] = L.bR[3 * k] * tl[0] + L.bR[3 * k + 1] * tl[1] + L.bR[3 * k + 2] * tl[2];
+      a0v = ar[a - 3];
+      Ma0v = L.bMr[3 * (a - 3)] * ar[0] + L.bMr[3 * (a - 3) + 1] * ar[1] + L.bMr[3 * (a - 3) + 2] * ar[2];
+    }
+    L.a0[lane] = a0v;
+    L.Ma0[lane] = Ma0v;
     L.qacc[lane] = bx.acc_warmstart[a];
   }
 #endif
@@ -186,7 +215,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       pos = sn > 1e-12 ? qe[1 + (a - 3)] / sn * ang : 0.0;
     }
     cand = true; type = 2; rpart = false;
-    diag = a < 3 ? 1.0 / m.box_mass : 1.0 / m.box_inertia;
+    diag = a < 3 ? 1.0 / m.box_mass : m.box_invweight_rot;
     rdof = NV + a; rsgn = 1.0; vel = bx.vel[a];
   }
 #endif
@@ -234,7 +263,12 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       if (active) { row_cost(type, D, floss, flim, rowdot(L.qacc) - aref, &c0, &g_, &h_); row_cost(type, D, floss, flim, rowdot(L.a0) - aref, &c1, &g_, &h_); }
       double quad = 0.5 * Mij * ei * ej;
 #if HRG_BOX
-      if (lane < HRG_NBOXV) { const double eb = L.qacc[NV + lane] - L.a0[NV + lane]; quad += 0.5 * (lane < 3 ? m.box_mass : m.box_inertia) * eb * eb; }
+      if (lane < HRG_NBOXV) {
+        const double eb = L.qacc[NV + lane] - L.a0[NV + lane];
+        double Me = m.box_mass * eb;
+        if (lane >= 3) { Me = 0; for (int b = 0; b < 3; b++) Me += L.bMr[3 * (lane - 3) + b] * (L.qacc[NV + 3 + b] - L.a0[NV + 3 + b]); }
+        quad += 0.5 * eb * Me;
+      }
 #endif
       const double cost_ws = wave_sum(quad + c0), cost_a0 = wave_sum(c1);
       wave_sync();
@@ -265,7 +299,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       }
 #if HRG_BOX
       else if (lane < NVT) {
-        double t = -L.Ma0[lane] + mdiag * L.qacc[lane];
+        double t = -L.Ma0[lane] + box_Mrow(m.box_mass, lane - NV, &L.qacc[NV]);
         gm = t;
         for (uint64_t mm = bmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
 #if HRG_HANDOVER
@@ -287,7 +321,8 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
           const double hq = L.rh[ROW_CON0 + q];
           if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
         }
-        double sval = mi == mj ? (mi < 3 ? m.box_mass : (mi < HRG_NBOXV ? m.box_inertia : 1.0)) : 0.0;
+        double sval = mi == mj ? (mi < 3 ? m.box_mass : 1.0) : 0.0;
+        if (mi >= 3 && mi < HRG_NBOXV && mj >= 3 && mj < HRG_NBOXV) sval = L.bMr[3 * (mi - 3) + (mj - 3)];
 #if HRG_HANDOVER
         if (mi == mj && mi < HRG_NBOXV) sval += L.rh[ROW_WELD0 + mi];
 #endif
@@ -322,7 +357,8 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
 #pragma unroll 1
       for (int e = lane; e < NVT * NVT; e += 64) {
         const int i = e / NVT, j = e - i * NVT;
-        double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j ? (i - NV < 3 ? m.box_mass : m.box_inertia) : 0.0);
+        double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j && i < NV + 3 ? m.box_mass : 0.0);
+        if (i >= NV + 3 && j >= NV + 3) hv = L.bMr[3 * (i - NV - 3) + (j - NV - 3)];
         if (i == j && i < NV) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; }
 #if HRG_HANDOVER
         if (i == j && i >= NV) hv += L.rh[ROW_WELD0 + i - NV];
@@ -350,7 +386,7 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
         dd = L.d[lane];
 #pragma unroll
         for (int j = 0; j < NV; j++) Mdi += L.M[lane * NV + j] * L.d[j];
-      } else if (lane < NVT) { dd = L.d[lane]; Mdi = mdiag * dd; }
+      } else if (lane < NVT) { dd = L.d[lane]; Mdi = box_Mrow(m.box_mass, lane - NV, &L.d[NV]); }
 #else
       double hval = Mij;
       if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
@@ -1344,7 +1380,8 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
         return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");
   if (desc->ik_enabled && !(desc->ik_max_iter >= 1 && desc->ik_max_iter <= 1000 && desc->ik_damping > 0 && desc->ik_action_limit > 0 && desc->ik_residual_threshold >= 0))
     return fail(HRG_ERR_INVALID, "ik: need 1 <= max_iter <= 1000, damping > 0, action_limit > 0, residual_threshold >= 0");
-  if (desc->task != HRG_TASK_REACH && !(desc->box_half > 0 && desc->box_mass > 0 && desc->box_inertia > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
+  if (desc->task != HRG_TASK_REACH && !(desc->box_half[0] > 0 && desc->box_half[1] > 0 && desc->box_half[2] > 0 && desc->box_mass > 0 && desc->box_inertia[0] > 0 && desc->box_inertia[1] > 0 &&
+                                       desc->box_inertia[2] > 0 && desc->box_inertia_mean > 0 && desc->box_invweight_rot > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
     return fail(HRG_ERR_INVALID, "PickPlaceHumanCart needs box_half, box_mass, box_inertia, n_targets, n_obj_placements > 0");
   HIPCHK(hipSetDevice(device));
   hrg_batch* b = new hrg_batch();

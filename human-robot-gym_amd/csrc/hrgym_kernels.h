@@ -737,7 +737,7 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
     bool hit = false;
     Contact c;
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
-    const double hb = m.box_half;
+    const double hb[3] = {m.box_half[0], m.box_half[1], m.box_half[2]};
     if (lane < HRG_NRCAP) {
       const int i = lane;
       if (m.rcap_body[i] >= 0) {
@@ -751,7 +751,7 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
             double loc[3], rel[3], best = 1e300;
             int ax = 0;
             v3sub(rel, cs, bx.pos);
-            for (int a = 0; a < 3; a++) { loc[a] = L.bR[a] * rel[0] + L.bR[3 + a] * rel[1] + L.bR[6 + a] * rel[2]; if (hb - fabs(loc[a]) < best) { best = hb - fabs(loc[a]); ax = a; } }
+            for (int a = 0; a < 3; a++) { loc[a] = L.bR[a] * rel[0] + L.bR[3 + a] * rel[1] + L.bR[6 + a] * rel[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
             const double sg = loc[ax] >= 0 ? -1.0 : 1.0;
             for (int a = 0; a < 3; a++) c.n[a] = sg * L.bR[3 * a + ax];
             dist = -best - m.rcap_r[i];
@@ -762,7 +762,7 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
       }
     } else if (lane >= 16 && lane < 32) {
       const int pl = (lane - 16) >> 3, cn = lane & 7;
-      const double loc[3] = {(cn & 1) ? hb : -hb, (cn & 2) ? hb : -hb, (cn & 4) ? hb : -hb};
+      const double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]};
       double p[3];
       m3mulv(p, L.bR, loc);
       v3add(p, p, bx.pos);

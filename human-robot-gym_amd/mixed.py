@@ -218,7 +218,7 @@ def _mixed_cls():
         def _make_infos(self, info, dones, term_obs):
             infos = super()._make_infos(info, dones, term_obs)
             for d, task in zip(infos, self._task_of_row):
-                d["task"] = task
+                dict.__setitem__(d, "task", task)   # (not d[...] = ...: that would fill the lazy rows)
             return infos
 
         def seed(self, seed=None):

@@ -512,11 +512,17 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.task = CONST[_TASK_OF[env_id]]
         d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616
         size = [float(x) for x in kw["object_full_size"]]
-        if not (size[0] == size[1] == size[2]):
-            raise NotImplementedError("object_full_size: the stepper models a cube")
-        d.box_half = 0.5 * size[0]
-        d.box_mass = 1000.0 * size[0] ** 3                       # BoxObject default density [UPSTREAM robosuite]
-        d.box_inertia = d.box_mass * size[0] ** 2 / 6.0
+        if not all(x > 0 for x in size):
+            raise ValueError("object_full_size must be positive")
+        half = [0.5 * x for x in size]
+        d.box_half[:] = half
+        d.box_mass = 1000.0 * size[0] * size[1] * size[2]        # BoxObject default density [UPSTREAM robosuite]
+        inertia = [d.box_mass * (half[(a + 1) % 3] ** 2 + half[(a + 2) % 3] ** 2) / 3.0 for a in range(3)]
+        if size[0] == size[1] == size[2]:                        # a cube: one value, so that the deviation from the mean is exactly zero
+            inertia = [d.box_mass * size[0] ** 2 / 6.0] * 3
+        d.box_inertia[:] = inertia
+        d.box_inertia_mean = inertia[0] if inertia[0] == inertia[1] == inertia[2] else sum(inertia) / 3.0
+        d.box_invweight_rot = 1.0 / inertia[0] if inertia[0] == inertia[1] == inertia[2] else sum(1.0 / x for x in inertia) / 3.0
         tx, ty = kw["table_full_size"][0], kw["table_full_size"][1]
         d.table_half[:] = [0.5 * tx, 0.5 * ty]
         bx, by = 0.5 * tx - 0.05, 0.5 * ty - 0.05
@@ -533,8 +539,8 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
             d.object_at_target_reward = float(kw["object_at_target_reward"])
             d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])
         # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]
-        d.obj_z = 0.8 + d.box_half
-        d.tgt_z = 0.8 + 0.5 * size[2] + d.box_half
+        d.obj_z = 0.8 + half[2]
+        d.tgt_z = 0.8 + 0.5 * size[2] + half[2]
         d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)
         d.n_targets = max(int(kw["horizon"] * kw["n_targets_sampled_per_100_steps"] / 100), 1)
         d.object_gripped_reward = float(kw["object_gripped_reward"])

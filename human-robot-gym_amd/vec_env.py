@@ -91,6 +91,78 @@ OBS_COLUMNS = {
 }
 
 
+_EAGER_KEYS = frozenset(("terminal_observation", "episode", "TimeLimit.truncated"))   # what SB3's rollout loops look up on every info
+
+
+class LazyInfo(dict):
+    """Per-env info dict whose kernel-derived entries (INFO_KEYS, "action", the expert observations) are filled in on first use.
+
+    SB3's collect loops only `.get()` "episode" / "terminal_observation" / "TimeLimit.truncated" on every info of every step; those
+    are stored eagerly, so a 4096-env step does not pay for 4096 x 15 dict entries nobody reads.  Any other access (indexing, `in`,
+    iteration, `len`, `==`, `dict(info)`, copy / pickle) materialises the row first; afterwards the object is an ordinary dict."""
+    __slots__ = ("_src", "_i")
+
+    def _fill(self):
+        src = self._src
+        if src is not None:
+            self._src = None
+            src.fill(self, self._i)
+
+    def get(self, key, default=None):
+        if self._src is not None and key not in _EAGER_KEYS:
+            self._fill()
+        return dict.get(self, key, default)
+
+    def __getitem__(self, key):
+        if self._src is not None and key not in _EAGER_KEYS:
+            self._fill()
+        return dict.__getitem__(self, key)
+
+    def __contains__(self, key):
+        if self._src is not None and key not in _EAGER_KEYS:
+            self._fill()
+        return dict.__contains__(self, key)
+
+    def _filled(name):  # noqa: N805
+        def method(self, *a, **k):
+            self._fill()
+            return getattr(dict, name)(self, *a, **k)
+        method.__name__ = name
+        return method
+
+    for _n in ("__iter__", "__len__", "__eq__", "__ne__", "__repr__", "__setitem__", "__delitem__", "__or__", "__ror__", "__ior__", "__reversed__",
+               "keys", "values", "items", "copy", "pop", "popitem", "setdefault", "update", "clear"):
+        locals()[_n] = _filled(_n)
+    del _n, _filled
+    __hash__ = None
+
+    def __reduce__(self):   # pickle / deepcopy: a plain dict
+        self._fill()
+        return (dict, (dict(self),))
+
+
+class _InfoSource:
+    """What the infos of one step are filled from: a copy of the info block, the executed actions, the expert views."""
+
+    def __init__(self, rows, acts, expert, prev_full, term_obs):
+        self.rows, self.acts, self.expert, self.prev_full, self.term_obs = rows, acts, expert, prev_full, term_obs
+
+    def fill(self, d, i):
+        row = self.rows[i].tolist()
+        set_ = dict.__setitem__
+        for k, v in zip(INFO_KEYS, row):
+            if k != "TimeLimit.truncated":
+                set_(d, k, v)
+        for j, k in _BOOL_ITEMS:
+            if k != "TimeLimit.truncated":
+                set_(d, k, row[j] != 0)
+        set_(d, "action", self.acts[i])  # collision_prevention_wrapper.py:42-43: the executed action
+        if self.expert is not None:  # expert_obs_wrapper.py:171-175 (the step's own observation: pre-reset where done)
+            prev, cur = self.prev_full[i], self.term_obs[i]
+            set_(d, "previous_expert_observation", {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in self.expert})
+            set_(d, "current_expert_observation", {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in self.expert})
+
+
 class _TorchBackend:
     """numpy <-> HipBatch adapter: one H2D copy of the actions, one D2H copy of the packed output block per step."""
 
@@ -240,28 +312,25 @@ class HipVecEnv(_VecEnvBase):
         return obs, reward, dones, infos
 
     def _make_infos(self, info, dones, term_obs):
-        # one bulk conversion to Python scalars and one zip per env instead of 13 numpy scalar extractions per env
-        rows = np.asarray(info).tolist()
-        done_l = dones.tolist()
-        acts = self._actions
-        now = time.time() - self._t_start
-        expert = self.expert_obs_keys
-        infos = []
-        for i, row in enumerate(rows):
-            d = dict(zip(INFO_KEYS, row))
-            for j, k in _BOOL_ITEMS:
-                d[k] = row[j] != 0
-            d["action"] = acts[i]  # collision_prevention_wrapper.py:42-43: the executed action
-            if expert is not None:  # expert_obs_wrapper.py:171-175 (the step's own observation: pre-reset where done)
-                prev, cur = self._expert_cur[i], np.asarray(term_obs[i])
-                d["previous_expert_observation"] = {k: np.array(prev[list(OBS_COLUMNS[k])]) for k in expert}
-                d["current_expert_observation"] = {k: np.array(cur[list(OBS_COLUMNS[k])]) for k in expert}
-            if done_l[i]:
-                d["terminal_observation"] = self._view(np.asarray(term_obs[i]))
-                d["episode"] = {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": round(now, 6)}
-            else:
-                del d["TimeLimit.truncated"]
-            infos.append(d)
+        # the per-env dicts are filled from a copy of the info block on first use (LazyInfo)
+        info = np.array(info, copy=True)
+        src = _InfoSource(info, self._actions, self.expert_obs_keys, self._expert_cur, np.array(term_obs, copy=True) if self.expert_obs_keys is not None else None)
+        n = self.num_envs
+        new = LazyInfo.__new__
+        infos = [new(LazyInfo) for _ in range(n)]
+        for i, d in enumerate(infos):
+            d._src = src
+            d._i = i
+        idx = np.nonzero(dones)[0]
+        if len(idx):
+            now = round(time.time() - self._t_start, 6)
+            trunc = info[idx, INFO_KEYS.index("TimeLimit.truncated")] != 0
+            set_ = dict.__setitem__
+            for i, tr in zip(idx.tolist(), trunc.tolist()):
+                d = infos[i]
+                set_(d, "TimeLimit.truncated", tr)
+                set_(d, "terminal_observation", self._view(np.array(term_obs[i])))
+                set_(d, "episode", {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": now})
         return infos
 
     def close(self):

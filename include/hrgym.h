@@ -235,8 +235,10 @@ typedef struct hrg_model_desc {
   /* ---- manipulation object + task of PickPlaceHumanCart (pick_place_human_cartesian_env.py:257-404, 637-708) ---- */
   int32_t task;                 /* HRG_TASK_* */
   int32_t n_obj_placements, n_targets; /* max(int(horizon * n_*_sampled_per_100_steps / 100), 1): 338-349 */
-  double box_half;              /* half edge of the cube (object_full_size / 2) */
-  double box_mass, box_inertia; /* BoxObject default density 1000; cube inertia m (2h)^2 / 6 */
+  double box_half[3];           /* half extents of the box object (object_full_size / 2) */
+  double box_mass, box_inertia[3]; /* BoxObject default density 1000; principal inertia m (b^2 + c^2) / 3 per axis (half extents b, c) */
+  double box_inertia_mean;      /* mean of box_inertia: the rotational inertia is handled as mean * identity + R diag(inertia - mean) R' */
+  double box_invweight_rot;     /* body_invweight0 (rotation) of the free body: mean of 1 / box_inertia */
   double obj_bin[4], tgt_bin[4]; /* xmin xmax ymin ymax of the sampling bins (843-875) */
   double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
   double object_gripped_reward;

@@ -825,7 +825,7 @@ typedef struct {
 /* Closest points of a segment p1-p2 and a cube (centre c, rotation R row-major, half edge hb): squared distance of
  * f(t) = |P(t) - clamp(P(t))|^2 in the cube frame, a convex piecewise quadratic in t, minimised on [0,1] by a
  * safeguarded Newton iteration (each step is exact inside one piece).  Stand-in for mjc_CapsuleBox. */
-static double seg_box(const double* p1, const double* p2, const double* c, const double* R, double hb, double* tmin, double* on_seg, double* on_box) {
+static double seg_box(const double* p1, const double* p2, const double* c, const double* R, const double* hb, double* tmin, double* on_seg, double* on_box) {
   double a[3], d[3], t0[3];
   v3sub(t0, p1, c);
   for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2]; /* R' (p1 - c) */
@@ -834,8 +834,8 @@ static double seg_box(const double* p1, const double* p2, const double* c, const
   double g0 = 0, g1 = 0, t;
   for (int k = 0; k < 3; k++) {
     double x0 = a[k], x1 = a[k] + d[k];
-    g0 += (x0 > hb ? x0 - hb : (x0 < -hb ? x0 + hb : 0.0)) * d[k];
-    g1 += (x1 > hb ? x1 - hb : (x1 < -hb ? x1 + hb : 0.0)) * d[k];
+    g0 += (x0 > hb[k] ? x0 - hb[k] : (x0 < -hb[k] ? x0 + hb[k] : 0.0)) * d[k];
+    g1 += (x1 > hb[k] ? x1 - hb[k] : (x1 < -hb[k] ? x1 + hb[k] : 0.0)) * d[k];
   }
   if (g0 >= 0) t = 0; /* convex: slope >= 0 at t = 0 */
   else if (g1 <= 0) t = 1;
@@ -845,7 +845,7 @@ static double seg_box(const double* p1, const double* p2, const double* c, const
     for (int it = 0; it < 10; it++) {
       double g = 0, H = 0;
       for (int k = 0; k < 3; k++) {
-        double x = a[k] + t * d[k], e = x > hb ? x - hb : (x < -hb ? x + hb : 0.0);
+        double x = a[k] + t * d[k], e = x > hb[k] ? x - hb[k] : (x < -hb[k] ? x + hb[k] : 0.0);
         g += e * d[k];
         if (e != 0) H += d[k] * d[k];
       }
@@ -857,7 +857,7 @@ static double seg_box(const double* p1, const double* p2, const double* c, const
     }
   }
   double x[3], y[3], e2 = 0;
-  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb, hb); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+  for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb[k], hb[k]); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
   *tmin = t;
   for (int k = 0; k < 3; k++) {
     on_seg[k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
@@ -920,7 +920,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
   if (bx) { /* robot capsule - cube, table - cube corners, floor - cube corners */
     double Rx[9];
     quat2mat(Rx, bx->quat);
-    const double hb = m->box_half;
+    const double* hb = m->box_half;
     for (int i = 0; i < HRG_NRCAP; i++) {
       if (m->rcap_body[i] < 0) continue;
       double t, cs[3], cb[3], nn[3], pos[3];
@@ -930,7 +930,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       else { /* capsule axis inside the cube: push out through the nearest face */
         double loc[3], best = 1e300; int ax = 0;
         v3sub(pos, cs, bx->pos);
-        for (int a = 0; a < 3; a++) { loc[a] = Rx[a] * pos[0] + Rx[3 + a] * pos[1] + Rx[6 + a] * pos[2]; if (hb - fabs(loc[a]) < best) { best = hb - fabs(loc[a]); ax = a; } }
+        for (int a = 0; a < 3; a++) { loc[a] = Rx[a] * pos[0] + Rx[3 + a] * pos[1] + Rx[6 + a] * pos[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
         double sg = loc[ax] >= 0 ? -1.0 : 1.0; /* normal points from the capsule into the cube */
         for (int a = 0; a < 3; a++) nn[a] = sg * Rx[3 * a + ax];
         dist = -best - m->rcap_r[i];
@@ -940,7 +940,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
     }
     for (int pl = 0; pl < 2; pl++)
       for (int cn = 0; cn < 8; cn++) {
-        double loc[3] = {(cn & 1) ? hb : -hb, (cn & 2) ? hb : -hb, (cn & 4) ? hb : -hb}, p[3];
+        double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]}, p[3];
         m3mulv(p, Rx, loc);
         v3add(p, p, bx->pos);
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
@@ -1555,14 +1555,26 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       qd[i] = s->qvel[i];
     }
     chol_solve(LM, NV, a0);
-    if (bx) { /* free cube: block-diagonal inertia (isotropic, so no gyroscopic term), gravity only */
+    if (bx) { /* free box, world-frame angular velocity: M = blockdiag(m 1, R diag(I) R'), bias torque w x (R diag(I) R' w), gravity.
+               * The rotational inertia is split into mean * 1 + R diag(I - mean) R': a cube keeps an exactly diagonal M and no gyroscopic term */
+      double Rx[9], Mdev[9], w[3] = {bx->vel[3], bx->vel[4], bx->vel[5]}, Ld[3], Lw[3], tau[3], tl[3];
+      quat2mat(Rx, bx->quat);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double t = 0;
+        for (int kk = 0; kk < 3; kk++) t += Rx[3 * i + kk] * (m->box_inertia[kk] - m->box_inertia_mean) * Rx[3 * j + kk];
+        Mdev[3 * i + j] = t;
+      }
+      for (int kk = 0; kk < 3; kk++) Ld[kk] = (m->box_inertia[kk] - m->box_inertia_mean) * (Rx[kk] * w[0] + Rx[3 + kk] * w[1] + Rx[6 + kk] * w[2]);
+      m3mulv(Lw, Rx, Ld); /* R diag(I - mean) R' w */
+      v3cross(tau, Lw, w); /* -(w x L) */
+      for (int kk = 0; kk < 3; kk++) tl[kk] = (Rx[kk] * tau[0] + Rx[3 + kk] * tau[1] + Rx[6 + kk] * tau[2]) / m->box_inertia[kk]; /* diag(1/I) R' tau */
       memset(Mt, 0, sizeof Mt);
       for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Mt[i * NVT + j] = M[i * NV + j];
       for (int a = 0; a < 3; a++) {
         Mt[(NV + a) * NVT + NV + a] = m->box_mass;
-        Mt[(NV + 3 + a) * NVT + NV + 3 + a] = m->box_inertia;
+        for (int b = 0; b < 3; b++) Mt[(NV + 3 + a) * NVT + NV + 3 + b] = (a == b ? m->box_inertia_mean : 0.0) + Mdev[3 * a + b];
         a0[NV + a] = m->gravity[a];
-        a0[NV + 3 + a] = 0;
+        a0[NV + 3 + a] = Rx[3 * a] * tl[0] + Rx[3 * a + 1] * tl[1] + Rx[3 * a + 2] * tl[2];
       }
       for (int a = 0; a < HRG_NBOXV; a++) qd[NV + a] = bx->vel[a];
     } else memcpy(Mt, M, sizeof M);
@@ -1616,7 +1628,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
       for (int a = 0; a < 3; a++) erot[a] = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
       for (int a = 0; a < 3; a++) { double J[NVT] = {0}; J[NV + a] = 1; efc_add(m, &E, J, qd, ROW_EQUALITY, epos[a], 0, 0, 1.0 / m->box_mass); }
-      for (int a = 0; a < 3; a++) { double J[NVT] = {0}; J[NV + 3 + a] = 1; efc_add(m, &E, J, qd, ROW_EQUALITY, erot[a], 0, 0, 1.0 / m->box_inertia); }
+      for (int a = 0; a < 3; a++) { double J[NVT] = {0}; J[NV + 3 + a] = 1; efc_add(m, &E, J, qd, ROW_EQUALITY, erot[a], 0, 0, m->box_invweight_rot); }
     }
     double qacc[NVT];
     memcpy(qacc, s->qacc_warmstart, sizeof(double) * NV);
@@ -2012,7 +2024,7 @@ void hrgo_test_human_dyn(const hrg_model_desc* m, const double* frames, int n_fr
   }
 }
 /* out: squared distance, closest point on the segment (3), closest point on the cube (3) */
-void hrgo_test_segbox(const double* p1, const double* p2, const double* c, const double* quat, double hb, double* out) {
+void hrgo_test_segbox(const double* p1, const double* p2, const double* c, const double* quat, const double* hb, double* out) {
   double R[9], t;
   quat2mat(R, quat);
   out[0] = seg_box(p1, p2, c, R, hb, &t, out + 1, out + 4);

@@ -26,7 +26,7 @@ def test_desc_follows_the_reference_defaults():
     np.testing.assert_allclose(list(d.init_qpos), [0, 0, -np.pi / 2, 0, -np.pi / 2, np.pi / 4])
     np.testing.assert_allclose(list(d.obj_bin), [0.7 * 0.35, 0.7 * 0.6, 0.95 * 0.25, 0.95 * 0.45])      # 843-858
     np.testing.assert_allclose(list(d.tgt_bin), [0.7 * 0.35, 0.7 * 0.6, 0.95 * -0.45, 0.95 * -0.25])    # 860-875
-    assert d.box_half == 0.02 and abs(d.box_mass - 0.064) < 1e-12 and d.object_gripped_reward == -0.25 and d.obstacle_margin == 0.0
+    assert list(d.box_half) == [0.02] * 3 and list(d.box_inertia) == [d.box_inertia_mean] * 3 and abs(d.box_mass - 0.064) < 1e-12 and d.object_gripped_reward == -0.25 and d.obstacle_margin == 0.0
     assert abs(d.obj_z - 0.82) < 1e-12 and abs(d.tgt_z - 0.84) < 1e-12
     assert hrg.build_model_desc(None).task == CONST["HRG_TASK_REACH"]
 
@@ -59,7 +59,7 @@ def test_cube_settles_on_the_table_and_stays():
         _, r, _, info = B.step(np.zeros((4, 7)))
     for e in range(4):
         bx = B.get_box(e)
-        assert abs(bx.pos[2] - (d.table_top_z + d.box_half)) < 3e-4 and max(abs(v) for v in bx.vel) < 1e-3
+        assert abs(bx.pos[2] - (d.table_top_z + d.box_half[2])) < 3e-4 and max(abs(v) for v in bx.vel) < 1e-3
         assert abs(bx.quat[0]) > 1 - 1e-6
     pairs, ncon = B.contacts()
     assert (ncon == 4).all() and (pairs[:, :4, 0] == 34).all() and (pairs[:, :4, 1] == 36).all()   # table (34) - cube (36) corners
@@ -77,7 +77,7 @@ def test_tumbling_cube_comes_to_rest_on_a_face():
         assert not info[:, 11].any()
     for e in range(8):
         bx = B.get_box(e)
-        assert abs(bx.pos[2] - (d.table_top_z + d.box_half)) < 1e-3, bx.pos[2]
+        assert abs(bx.pos[2] - (d.table_top_z + d.box_half[2])) < 1e-3, bx.pos[2]
         assert max(abs(v) for v in bx.vel) < 0.05
         assert abs(np.linalg.norm(list(bx.quat)) - 1) < 1e-12
     B.close()
@@ -100,7 +100,7 @@ def test_grasp_carry_release():
     assert (dz[5:30] < 0.045).all()                                         # carried along with the end effector
     assert (grip[33:] == 0).all() and (rew[33:] == -1).all()                # released
     for e in range(2):
-        assert abs(B.get_box(e).pos[2] - (d.table_top_z + d.box_half)) < 1e-3   # and back on the table
+        assert abs(B.get_box(e).pos[2] - (d.table_top_z + d.box_half[2])) < 1e-3   # and back on the table
     B.close()
 
 
@@ -144,7 +144,8 @@ def test_seg_box_known_answers():
     lib = load()
     out = (ctypes.c_double * 7)()
     def sb(p1, p2, c=(0, 0, 0), q=(1, 0, 0, 0), hb=0.5):
-        lib.hrgo_test_segbox((ctypes.c_double * 3)(*p1), (ctypes.c_double * 3)(*p2), (ctypes.c_double * 3)(*c), (ctypes.c_double * 4)(*q), ctypes.c_double(hb), out)
+        hb3 = np.broadcast_to(np.asarray(hb, float), (3,))
+        lib.hrgo_test_segbox((ctypes.c_double * 3)(*p1), (ctypes.c_double * 3)(*p2), (ctypes.c_double * 3)(*c), (ctypes.c_double * 4)(*q), (ctypes.c_double * 3)(*hb3), out)
         return np.array(out[:])
     o = sb((2, 0, 0), (3, 0, 0))                      # pointing away: closest at the first end point, face +x
     assert abs(o[0] - 1.5 ** 2) < 1e-14 and np.allclose(o[1:4], (2, 0, 0)) and np.allclose(o[4:7], (0.5, 0, 0))
@@ -158,13 +159,14 @@ def test_seg_box_known_answers():
     for _ in range(200):
         p1, p2, c = rng.uniform(-2, 2, 3), rng.uniform(-2, 2, 3), rng.uniform(-0.5, 0.5, 3)
         q = rng.normal(size=4); q /= np.linalg.norm(q)
-        o = sb(p1, p2, c, q, 0.4)
+        hb = rng.uniform(0.05, 0.6, 3) if _ % 2 else np.full(3, 0.4)          # boxes with three different half extents, and cubes
+        o = sb(p1, p2, c, q, hb)
         w, x, y, z = q
         R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
                       [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
         t = np.linspace(0, 1, 4001)[:, None]
         P = (p1 + t * (p2 - p1) - c) @ R
-        e = P - np.clip(P, -0.4, 0.4)
+        e = P - np.clip(P, -hb, hb)
         assert o[0] <= (e ** 2).sum(1).min() + 1e-12 and o[0] >= (e ** 2).sum(1).min() - 1e-5
 
 
@@ -227,4 +229,54 @@ def test_pick_place_variants_close_and_pointing():
             seen.add(best)
             np.testing.assert_allclose(obs[e, 43:46], obs[e, 50:53] - np.array(s.eef_pos), rtol=1e-5, atol=1e-6)
     assert seen == {0, 1}                       # both pointing hands occur over the envs' clips
+    B.close()
+
+
+
+
+def _brick_batch(n, size=(0.04, 0.07, 0.03), control_freq=250):
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=200, max_frames=300)
+    d = hrg.build_model_desc(dict(KW, object_full_size=list(size), control_freq=control_freq), n_clips=clips.n_clips, **PP)
+    return OracleBatch(d, clips, n), d
+
+
+def _rot(q):
+    w, x, y, z = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)], [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                     [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+
+
+def test_box_object_with_three_different_edges():
+    """object_full_size need not be a cube (pick_place_human_cartesian_env.py:262): principal inertia per axis, and in free flight the
+    angular momentum R diag(I) R' w stays constant while w itself wanders (the gyroscopic term of the free joint)."""
+    B, d = _brick_batch(2)                     # control_freq 250: one 4 ms substep per step, so every substep can be inspected
+    m, h = d.box_mass, np.array(list(d.box_half))
+    assert np.allclose(h, [0.02, 0.035, 0.015]) and abs(m - 1000 * 0.04 * 0.07 * 0.03) < 1e-12
+    assert np.allclose(list(d.box_inertia), [m * (h[1] ** 2 + h[2] ** 2) / 3, m * (h[0] ** 2 + h[2] ** 2) / 3, m * (h[0] ** 2 + h[1] ** 2) / 3])
+    assert abs(d.box_inertia_mean - np.mean(list(d.box_inertia))) < 1e-18 and abs(d.box_invweight_rot - np.mean(1 / np.array(list(d.box_inertia)))) < 1e-9
+    B.reset()
+    I = np.array(list(d.box_inertia))
+    put_box([B], 0, pos=[0.5, 0.0, 1.6], quat=[1, 0, 0, 0], vel=[0, 0, 0, 6.0, 0.5, 4.0])     # spin about no principal axis, 0.8 m above the table
+    Ls, ws = [], []
+    for k in range(60):                        # 0.24 s of free fall (0.28 m): no contact yet
+        bx = B.get_box(0)
+        R, w = _rot(list(bx.quat)), np.array(list(bx.vel)[3:])
+        Ls.append(R @ (I * (R.T @ w))); ws.append(w)
+        B.step(np.zeros((2, 7)))
+    Ls, ws = np.array(Ls), np.array(ws)
+    assert np.abs(Ls - Ls[0]).max() < 0.02 * np.linalg.norm(Ls[0])          # first-order integrator: conserved to a few per cent over 60 substeps
+    assert np.abs(ws - ws[0]).max() > 0.15 * np.linalg.norm(ws[0])          # ... while the angular velocity moves a lot (it would be constant for a cube)
+    assert abs(B.get_box(0).vel[2] - (-9.81 * 0.24)) < 1e-9
+    B.close()
+    B, d = _brick_batch(4, control_freq=10)
+    B.reset()
+    rng = np.random.RandomState(1)
+    for k in range(50):
+        _, _, _, info = B.step(tumble(k, [B], rng, 4))
+        assert not info[:, 11].any()
+    for e in range(4):                         # at rest on one of its faces: centre height = one of the half extents, that axis vertical
+        bx = B.get_box(e)
+        R = _rot(list(bx.quat))
+        ax = int(np.argmax(np.abs(R[2])))
+        assert abs(abs(R[2, ax]) - 1) < 1e-3 and abs(bx.pos[2] - (d.table_top_z + h[ax])) < 1e-3 and max(abs(v) for v in bx.vel) < 0.05
     B.close()

@@ -89,6 +89,16 @@ def test_tumbling_cube_parity():
     assert st["box_contacts"] > 0
 
 
+def test_box_with_three_different_edges_parity():
+    """object_full_size = a brick: per-axis half extents in the narrowphase, the world-frame rotational inertia R diag(I) R' with its
+    gyroscopic torque in the solver (tumbling through the air and on the table), and random arm motion around it."""
+    brick = dict(object_full_size=[0.04, 0.07, 0.03])
+    st = _rollout(dict(shield_type="OFF", horizon=100, seed=5, **brick), 12, 14, 3, tumble, resync=True)
+    assert st["box_contacts"] > 0
+    _rollout(dict(shield_type="OFF", horizon=100, seed=8, control_freq=50, **brick), 8, 40, 4, tumble, resync=True)   # 5 substeps per step: in the air, too
+    _rollout(dict(shield_type="SSM", horizon=25, reward_shaping=True, **brick), 12, 30, 2, lambda k, b, rng, n: random_actions(k, b, rng, n), resync=False)
+
+
 def test_delivery_parity():
     st = _rollout(dict(shield_type="SSM", horizon=100, seed=6, reward_shaping=False), 8, 12, 1, deliver, resync=False)
     assert st["success"] == 16
@@ -119,7 +129,7 @@ def test_full_size_properties():
         outs.append((obs.cpu().numpy().copy(), r.cpu().numpy().copy(), info.cpu().numpy().copy()))
         assert not info[:, 11].any().item()
         z = obs[:, 49].cpu().numpy()
-        assert np.all(np.abs(z - (d.table_top_z + d.box_half)) < 2e-3)
+        assert np.all(np.abs(z - (d.table_top_z + d.box_half[2])) < 2e-3)
         G.close()
     for a, b in zip(outs[0], outs[1]):
         np.testing.assert_array_equal(a, b)
@@ -211,8 +221,8 @@ def test_long_run_stays_finite_and_on_the_table():
             o = obs.cpu().numpy()
             assert np.isfinite(o).all() and np.isfinite(r.cpu().numpy()).all()
             z = o[:, 49]
-            on_floor = np.abs(z - (d.floor_z + d.box_half)) < 5e-3          # knocked off the table: rests on the floor
-            odd = ~(on_floor | (z > d.table_top_z + d.box_half - 5e-3))
+            on_floor = np.abs(z - (d.floor_z + d.box_half[2])) < 5e-3          # knocked off the table: rests on the floor
+            odd = ~(on_floor | (z > d.table_top_z + d.box_half[2] - 5e-3))
             assert odd.sum() <= 2 and (z < 2.0).all(), (k, np.sort(z[odd])[:20], o[odd][:6, 47:50], int(odd.sum()))   # a cube in free fall at the sampling instant
             assert on_floor.mean() < 0.05
         crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item())

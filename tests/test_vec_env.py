@@ -178,3 +178,29 @@ def test_goal_env_type_serves_her(env_id, shaping):
     assert np.allclose(r3, 1.0 + (1.0 + (0.0 if env_id == "ReachHuman" else -0.02 * np.linalg.norm(ag[:, 3:6] - ag[:, :3], axis=1)) if shaping else 0.0), atol=1e-6)
     assert isinstance(env.compute_reward(ag[0], relabeled[0], dict(collision_type=8)), float)
     assert abs(env.compute_reward(ag[0], relabeled[0], dict(collision_type=8)) - (r3[0] - 3.0)) < 1e-6   # static collision penalty
+
+
+def test_lazy_info_dicts_behave_like_dicts():
+    """LazyInfo: SB3's per-step lookups do not materialise a row; any other use does, and copies / pickles are plain dicts."""
+    import copy
+    import pickle
+    from human_robot_gym_amd.vec_env import INFO_KEYS, LazyInfo, _InfoSource
+    rows = np.array([[i] * len(INFO_KEYS) for i in range(3)], np.int32)
+    src = _InfoSource(rows, np.arange(21.0).reshape(3, 7), None, None, None)
+
+    def mk(i):
+        d = LazyInfo.__new__(LazyInfo)
+        d._src, d._i = src, i
+        return d
+    d = mk(1)
+    assert d.get("episode") is None and d.get("TimeLimit.truncated", False) is False and "terminal_observation" not in d
+    assert d._src is not None                                   # still lazy after the lookups SB3 does on every info
+    assert d["n_goal_reached"] == 1 and d["collision"] is True and d._src is None
+    assert len(mk(2)) == len(INFO_KEYS) and "TimeLimit.truncated" not in mk(2)   # (+ action, - TimeLimit.truncated)
+    for plain in (dict(mk(2)), {**mk(2)}, copy.deepcopy(mk(2)), pickle.loads(pickle.dumps(mk(2))), mk(2).copy()):
+        assert type(plain) is dict and plain["n_collisions"] == 2 and plain["sim_crash"] is True and plain["action"][0] == 14.0
+    assert set(mk(1).keys()) == (set(INFO_KEYS) - {"TimeLimit.truncated"}) | {"action"}
+    d = mk(0)
+    d["x"] = 5
+    assert d["x"] == 5 and d["timeout"] is False and "collision_type" in repr(mk(0))
+    assert [k for k in mk(1)][:2] == INFO_KEYS[:2]
