@@ -207,3 +207,35 @@ def test_hip_matches_oracle_on_the_robot_to_human_handover():
                 G.set_box(e, O.get_box(e))
     assert wins >= 3
     O.close(); G.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("env_id,shield", [("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL"), ("HumanObjectInspectionCart", "SSM")])
+def test_collaboration_tasks_long_run_stays_finite(env_id, shield):
+    """Soak: 1024 envs x 200 policy steps of random actions with auto-resets (horizon 150): nothing turns non-finite, no simulation
+    crashes, the object stays a rigid body, the human's phase machine moves on (the idle loops are reached)."""
+    import torch
+    from human_robot_gym_amd import mixed
+    from human_robot_gym_amd._lib import HipBatch
+    n = 1024
+    clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600)
+    d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31), n_clips=clips.n_clips, env_id=env_id)
+    G = HipBatch(d, clips, n)
+    G.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    crashes = 0
+    phases = np.zeros(8, int)
+    for k in range(200):
+        a = (torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda()
+        obs, r, dn, info = G.step(a)
+        crashes += int(info[:, 11].sum().item())
+        if k % 40 == 39:
+            o = obs.cpu().numpy()
+            assert np.isfinite(o).all() and np.isfinite(r.cpu().numpy()).all()
+            assert (o[:, 49] > 0.5).all() and (o[:, 49] < 2.5).all()           # object height: on the table, in a hand, or on the floor
+            _, bx = G.get_states(np.arange(0, n, 16))
+            phases += np.bincount([b.task_phase for b in bx], minlength=8)
+            assert max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx) < 1e-12
+    assert crashes == 0
+    assert phases[1:].sum() > 0, phases                                       # beyond APPROACH
+    G.close()

@@ -1,0 +1,35 @@
+"""Statistics of long random-action runs of the collaboration tasks on the HIP stepper (finite values, crash rate, phase histogram)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+import human_robot_gym_amd as hrg  # noqa: E402
+from human_robot_gym_amd import mixed  # noqa: E402
+from human_robot_gym_amd._lib import HipBatch  # noqa: E402
+
+n, steps = 2048, 300
+for env_id, shield in (("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL")):
+    clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600)
+    d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31), n_clips=clips.n_clips, env_id=env_id)
+    G = HipBatch(d, clips, n)
+    G.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    crashes = dones = wins = 0
+    bad = 0
+    for k in range(steps):
+        a = (torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda()
+        obs, r, dn, info = G.step(a)
+        crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item()); wins += int((r > 0).sum().item())
+        if k % 50 == 49:
+            o = obs.cpu().numpy()
+            bad += int((~np.isfinite(o)).sum())
+            z = o[:, 49]
+            print(f"  {env_id} step {k}: object z min {z.min():.3f} max {z.max():.3f}; below table-5mm {(z < 0.8 + 0.02 - 5e-3).mean():.3f}; gripped {o[:, 39].mean():.3f}", flush=True)
+    st, bx = G.get_states(np.arange(0, n, 8))
+    ph = np.bincount([b.task_phase for b in bx], minlength=6)
+    qn = max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx)
+    print(f"{env_id}: crashes {crashes} dones {dones} positive rewards {wins} non-finite {bad} phases {ph.tolist()} weld_active {np.mean([b.weld_active for b in bx]):.3f} "
+          f"handed over {sum(b.n_handed_over for b in bx)} |quat|-1 {qn:.2e}", flush=True)
+    G.close()
