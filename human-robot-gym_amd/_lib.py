@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("HRG_LIB_PATH") or os.path.join(_HERE, "libhrgym_hip.s
 SRC = os.path.join(_HERE, "csrc", "hrgym_hip.hip")
 SRC_BOX = os.path.join(_HERE, "csrc", "hrgym_box.hip")   # the same sources compiled with the manipulation object (PickPlaceHumanCart)
 SRC_HO = os.path.join(_HERE, "csrc", "hrgym_handover.hip")   # ... and once more with the object <-> hand weld of the handover tasks
+SRC_LIFT = os.path.join(_HERE, "csrc", "hrgym_lift.hip")     # ... and with the connect equalities / task logic of CollaborativeLiftingCart
 
 EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
@@ -24,11 +25,11 @@ EXPORTS = [
 
 def build_library(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, SRC_BOX, SRC_HO] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
+    deps = [SRC, SRC_BOX, SRC_HO, SRC_LIFT] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
         os.path.join(os.path.dirname(_HERE), "include", f) for f in ("hrgym.h", "hrgym_state.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH, SRC, SRC_BOX, SRC_HO]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH, SRC, SRC_BOX, SRC_HO, SRC_LIFT]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

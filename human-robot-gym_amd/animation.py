@@ -90,7 +90,52 @@ class ClipSet:
         return t
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False):
+def _rot(axis, ang):
+    c, s_ = np.cos(ang), np.sin(ang)
+    i, j = [(1, 2), (2, 0), (0, 1)][axis]
+    R = np.zeros(ang.shape + (3, 3))
+    R[..., axis, axis] = 1.0
+    R[..., i, i], R[..., j, j], R[..., i, j], R[..., j, i] = c, c, -s_, s_
+    return R
+
+
+def _quat_xyzw_to_mat(q):
+    x, y, z, w = q[..., 0], q[..., 1], q[..., 2], q[..., 3]
+    R = np.empty(q.shape[:-1] + (3, 3))
+    R[..., 0, 0], R[..., 0, 1], R[..., 0, 2] = 1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)
+    R[..., 1, 0], R[..., 1, 1], R[..., 1, 2] = 2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)
+    R[..., 2, 0], R[..., 2, 1], R[..., 2, 2] = 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)
+    return R
+
+
+def hand_sites(frames, info):
+    """World positions of the L_Hand / R_Hand sites for every frame [n, FRAME_DIM] of a clip placed by `info` (no per-episode offsets):
+    the pose chain of HumanEnv._control_human (human_env.py:1736-1763) and the tree of human.xml, vectorised over frames.  Host-side
+    helper for shaping synthetic clips; the steppers have their own kinematics."""
+    bodies = load_assets()["human"]["bodies"]
+    n = len(frames)
+    Rb = _quat_xyzw_to_mat(np.array([0.5, 0.5, 0.5, 0.5]))          # human_base_quat (human_env.py:373)
+    Ri = _quat_xyzw_to_mat(np.asarray(info["orientation_quat"], float))
+    Rbi = Rb @ Ri
+    R = [None] * len(bodies)
+    p = [None] * len(bodies)
+    R[0] = Rbi @ _quat_xyzw_to_mat(frames[:, 3:7])
+    p[0] = (frames[:, 0:3] + np.asarray(info["position_offset"], float)) @ Rbi.T
+    for b in range(1, len(bodies)):
+        par, anc = bodies[b]["parent"], np.asarray(bodies[b]["anchor"], float)
+        q = frames[:, 7 + 3 * (b - 1): 10 + 3 * (b - 1)]
+        R[b] = R[par] @ _rot(2, q[:, 0]) @ _rot(1, q[:, 1]) @ _rot(0, q[:, 2])      # z, y, x
+        p[b] = p[par] + R[par] @ anc - R[b] @ anc
+    names = [b["name"] for b in bodies]
+    out = []
+    for nm in ("L_Hand", "R_Hand"):
+        b = names.index(nm)
+        out.append(p[b] + R[b] @ np.asarray(bodies[b]["anchor"], float))
+    assert out[0].shape == (n, 3)
+    return out[0], out[1]
+
+
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -114,8 +159,10 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         yaw = band(0.4, 0.2)
         anim["Pelvis_quat"] = np.stack([np.zeros(n), np.sin(yaw / 2), np.zeros(n), np.cos(yaw / 2)], 1)  # about Y (up)
         for name in order:
-            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else 0.3  # convert_bvh.py:55-72 None joints
+            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else (0.05 if lifting is not None else 0.3)  # convert_bvh.py:55-72 None joints
             mean = {"L_Shoulder_z": -1.1, "R_Shoulder_z": 1.1}.get(name, 0.0)  # arms hang down instead of the T-pose
+            if lifting is not None:  # ... and a little closer: the hands half a metre apart, like the board's grips
+                mean = {"L_Shoulder_z": -1.43, "R_Shoulder_z": 1.43}.get(name, 0.0)
             anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.zeros(n)
         # the clip's info file places the human at the table edge in front of the robot: BVH +z maps to world +x
         # under human_base_quat (human_env.py:373), so 1.2 m along z = 1.2 m in front of the robot base
@@ -130,8 +177,41 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
             info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        if lifting is not None:
+            # stand-in for the CollaborativeLifting/* recordings: a human facing the robot who raises and lowers the far end of the board.
+            # `lifting` = world position of the middle between the two hands at the first frame (where the board's grips are at a reset);
+            # the pelvis track is shifted frame by frame so that the middle of the hands follows a smooth lift of up to 25 cm with a
+            # little sideways sway, while the (small) arm motion tilts the board
+            anim["Pelvis_quat"] = np.tile(np.array([0.0, 1.0, 0.0, 0.0]), (n, 1))   # half a turn about the vertical: facing the robot, left hand at -y
+            F = np.zeros((n, FRAME_DIM))
+            F[:, 0], F[:, 1], F[:, 2] = anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"]
+            F[:, 3:7] = anim["Pelvis_quat"]
+            for k, name in enumerate(order):
+                F[:, 7 + k] = anim[name]
+            lh, rh = hand_sites(F, info)
+            u = t / t[-1]
+            lift = 0.25 * np.sin(np.pi * u) ** 2 * rng.uniform(0.5, 1.0)
+            sway = 0.04 * np.sin(2 * np.pi * u * rng.uniform(0.5, 1.5))
+            want = np.asarray(lifting, float)[None, :] + np.stack([0.0 * u, sway, lift], 1)
+            Rb = _quat_xyzw_to_mat(np.array([0.5, 0.5, 0.5, 0.5])) @ _quat_xyzw_to_mat(np.asarray(info["orientation_quat"], float))
+            shift = (want - 0.5 * (lh + rh)) @ Rb          # world shift -> animation frame (p_world = Rb p_anim)
+            anim["Pelvis_pos_x"] = anim["Pelvis_pos_x"] + shift[:, 0]
+            anim["Pelvis_pos_y"] = anim["Pelvis_pos_y"] + shift[:, 1]
+            anim["Pelvis_pos_z"] = anim["Pelvis_pos_z"] + shift[:, 2]
         clips.append((anim, info))
     return ClipSet(clips)
+
+
+def lifting_hands_nominal(desc):
+    """Where the board's two hand grips are at a reset of CollaborativeLiftingCart (middle between them): the argument `lifting` of
+    `synthetic_clips`.  The board sits in the gripper with its robot-side edge `lift_grip_depth` past the grip site."""
+    from .model import robot_fk_numpy
+    q = list(desc.init_qpos[:]) + [0.0] * (CONST["HRG_NV"] - len(desc.init_qpos[:]))
+    R, p = robot_fk_numpy(desc, q)
+    k = CONST["HRG_NARM"] - 1
+    ze, eef = R[k][:, 2], p[k] + R[k] @ np.asarray(desc.eef_pos[:])
+    ax = 0.5 * (np.asarray(desc.lift_anchor[0][:]) + np.asarray(desc.lift_anchor[1][:]))
+    return eef + ze * (desc.box_half[0] - desc.lift_grip_depth - ax[0])
 
 
 def static_clip(n_frames=600, pelvis=(0.0, 1.0, 0.0)):

@@ -28,6 +28,9 @@
 #endif
 // HRG_HANDOVER=1 (with HRG_BOX=1, hrgym_handover.hip): the cube variant plus what only the handover tasks need -- the object <-> hand
 // weld rows, a second physics step per cycle, the hand mocap pose.  A third translation unit, so the pick-place kernels stay lean.
+#ifndef HRG_LIFT
+#define HRG_LIFT 0   // HRG_LIFT=1 (with HRG_BOX=1, hrgym_lift.hip): CollaborativeLiftingCart -- two connect equalities board <-> hand mocap bodies, the lifting task logic
+#endif
 #ifndef HRG_HANDOVER
 #define HRG_HANDOVER 0
 #endif
@@ -138,8 +141,8 @@ struct Contact {
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
 #define ROW_WELD0 (ROW_CON0 + 4 * NCON_DYN)   // 6 equality rows of the object <-> hand weld (cube variant: lanes 56..61)
-#if HRG_BOX && HRG_HANDOVER
-#define NROW (ROW_WELD0 + 6)
+#if HRG_BOX && (HRG_HANDOVER || HRG_LIFT)
+#define NROW (ROW_WELD0 + 6)   // lifting: the 6 rows of the two connect equalities take the weld's slots (general rows, stored after the contact rows in Jc)
 #else
 #define NROW ROW_WELD0
 #endif
@@ -195,7 +198,7 @@ struct Lds {
       int cur[HRG_NPREV_MAX];
     };
     struct {  // dynamics_step: contact rows of J (padded to 9: conflict-free ds_read_b64), per-row gradient / curvature
-      double Jc[4 * NCON_DYN][NVS + 1], rg[NROW], rh[NROW];
+      double Jc[4 * NCON_DYN + (HRG_LIFT ? 6 : 0)][NVS + 1], rg[NROW], rh[NROW];
     };
   };
 };

@@ -193,6 +193,23 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
       cand = nz > 0;
     }
   }
+#if HRG_LIFT
+  else if (r < NROW && bx.weld_active) { // two connect equalities (collaborative_lifting_cartesian_env.py:924-958): the board's grip points follow the hand mocap
+                                         // bodies; residual = p_board + R anchor - p_mocap, velocity of the point = v + w x r.  General rows: stored like contact rows
+    const int hd = (r - ROW_WELD0) / 3, a = (r - ROW_WELD0) - 3 * hd;
+    double rr[3], rxe[3];
+    const double anc[3] = {m.lift_anchor[hd][0], m.lift_anchor[hd][1], m.lift_anchor[hd][2]};
+    m3mulv(rr, L.bR, anc);
+    const double ea[3] = {a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0};
+    v3cross(rxe, rr, ea);   // (w x r) . e_a = w . (r x e_a)
+    pos = bx.pos[a] + rr[a] - (hd ? bx.weld_off[a] : bx.mocap_pos[a]);
+    for (int i = 0; i < NV; i++) L.Jc[r - ROW_CON0][i] = 0.0;
+    for (int b = 0; b < 3; b++) { L.Jc[r - ROW_CON0][NV + b] = ea[b]; L.Jc[r - ROW_CON0][NV + 3 + b] = rxe[b]; }
+    vel = bx.vel[a] + rxe[0] * bx.vel[3] + rxe[1] * bx.vel[4] + rxe[2] * bx.vel[5];
+    cand = true; type = 2; rpart = false; bpart = true;
+    diag = 1.0 / m.box_mass;
+  }
+#endif
 #if HRG_HANDOVER
   else if (r < NROW && bx.weld_active) { // weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
                                          // [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; unit rows on the cube's own DoF, the mocap body has no velocity
@@ -220,7 +237,11 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
   }
 #endif
   const bool active = cand && diag > 0;
+#if HRG_LIFT
+  const bool is_con = r >= ROW_CON0 && r < NROW;   // the connect rows are general rows on the board's DoF: handled like contact rows
+#else
   const bool is_con = r >= ROW_CON0 && r < ROW_WELD0;
+#endif
   double aref = 0, D = 0, flim = 0;
   if (active) {
     double imp;
@@ -231,7 +252,11 @@ HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int n
     if (type == 0) flim = floss / D;
   }
   const uint64_t mask = __ballot(active);
-  const uint64_t cmask = mask >> ROW_CON0;  // active contact rows
+#if HRG_HANDOVER
+  const uint64_t cmask = (mask & ((1ull << ROW_WELD0) - 1)) >> ROW_CON0;  // active contact rows (the weld's unit rows are added on the diagonal, not through Jc)
+#else
+  const uint64_t cmask = mask >> ROW_CON0;  // active contact rows (lifting: and the connect rows behind them)
+#endif
 #if HRG_BOX
   // contact rows by the block of the Hessian they touch.  Without a robot-cube contact the 14-DoF system is block diagonal
   // (8x8 robot tree, 6x6 cube) and both blocks are factored in registers; a coupled system takes the 14x14 LDS path.
@@ -750,6 +775,14 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
       v = ap / HRG_NFINGER;
     } else if (lane >= 47 && lane < 50) v = bx.obs_pos[lane - 47];
     else if (lane >= 50 && lane < 53) v = bx.target[lane - 50];
+#if HRG_LIFT
+    if (m.task == HRG_TASK_LIFTING) { // collaborative_lifting_cartesian_env.py:982-1085: board_balance in the first target column, board_quat (x, y, z, w) in 43-45 and 51
+      if (lane >= 43 && lane < 46) v = bx.quat[1 + lane - 43];
+      else if (lane == 51) v = bx.quat[0];
+      else if (lane == 52) v = 0.0;
+      else if (lane == 50) { double Rx[9]; const double qb[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]}; quat2mat(Rx, qb); v = Rx[8]; }
+    }
+#endif
 #endif
     out[lane] = (float)v;
   }
@@ -805,6 +838,47 @@ DI void eef_update(const DevModel* __restrict__ dm_) {
   v3cpy(L.st.eef_pos, e);
 }
 
+#if HRG_LIFT
+// rotation matrix (row-major) -> unit quaternion (w, x, y, z), largest-component branch
+DI void mat2quat(double* q, const double* R) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const double s_ = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s_; q[1] = (R[7] - R[5]) / s_; q[2] = (R[2] - R[6]) / s_; q[3] = (R[3] - R[1]) / s_; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s_ = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s_; q[1] = 0.25 * s_; q[2] = (R[1] + R[3]) / s_; q[3] = (R[2] + R[6]) / s_; }
+  else if (R[4] > R[8]) { const double s_ = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s_; q[1] = (R[1] + R[3]) / s_; q[2] = 0.25 * s_; q[3] = (R[5] + R[7]) / s_; }
+  else { const double s_ = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s_; q[1] = (R[2] + R[6]) / s_; q[2] = (R[5] + R[7]) / s_; q[3] = 0.25 * s_; }
+}
+// _update_mocap_body_transforms (collaborative_lifting_cartesian_env.py:590-616): the two mocap bodies sit at the hand sites
+DI void lifting_mocap(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  wave_sync();
+  if (lane < 3) { L.bx.mocap_pos[lane] = L.st.human_site[m.site_lhand][lane]; L.bx.weld_off[lane] = L.st.human_site[m.site_rhand][lane]; }
+  wave_sync();
+}
+// CollaborativeLiftingCart._reset_animation (644-657) puts the board where the Schunk gripper's init_qpos straddles it; with the stand-in gripper
+// the pose follows from the gripper frame (see oracle/hrg_oracle.c lifting_place_board).  Needs the chain kinematics and eef_pos of the posture.
+DI void lifting_place_board(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_box_state& bx = L.bx;
+  double Re[9], Rb[9], q[4], xb[3], yb[3], zb[3], ze[3], pos[3];
+  for (int a = 0; a < 9; a++) Re[a] = L.kR[NARM - 1][a];
+  const double sg = Re[7] >= 0 ? 1.0 : -1.0;
+  for (int a = 0; a < 3; a++) { ze[a] = Re[3 * a + 2]; xb[a] = -ze[a]; zb[a] = sg * Re[3 * a + 1]; }
+  v3cross(yb, zb, xb);
+  for (int a = 0; a < 3; a++) { Rb[3 * a] = xb[a]; Rb[3 * a + 1] = yb[a]; Rb[3 * a + 2] = zb[a]; }
+  mat2quat(q, Rb);
+  for (int a = 0; a < 3; a++) pos[a] = L.st.eef_pos[a] + ze[a] * (m.box_half[0] - m.lift_grip_depth);
+  wave_sync();
+  if (lane < 3) { bx.pos[lane] = pos[lane]; bx.obs_pos[lane] = pos[lane]; }
+  if (lane < 4) bx.quat[lane] = q[lane];
+  if (lane < HRG_NBOXV) { bx.vel[lane] = 0.0; bx.acc_warmstart[lane] = 0.0; }
+  wave_sync();
+}
+#endif
+
 // HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
 // + FailsafeController.reset (failsafe_controller.py:204-250)
 HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid, float* obs_out) {
@@ -851,7 +925,17 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     if (lane == 0) bx.quat[0] = 1.0;
     wave_sync();
 #if HRG_HANDOVER
-    if (m.task >= HRG_TASK_HANDOVER_H2R) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (H2R 635-647, 686-711; R2H 650-660, 700-706)
+    if (HRG_IS_HANDOVER(m.task)) handover_pickup(dm_, lane, gid, true);   // _reset_animation + _control_human (H2R 635-647, 686-711; R2H 650-660, 700-706)
+#endif
+#if HRG_LIFT
+    if (m.task == HRG_TASK_LIFTING) { // _reset_internal (670-681): _control_human + _reset_animation; the human holds the board from the start
+      human_control(dm_, lane, gid);
+      lifting_mocap(dm_, lane);
+      lifting_place_board(dm_, lane);
+      bx.weld_active = 1;
+      if (lane < 3) bx.target[lane] = bx.pos[lane];
+      wave_sync();
+    }
 #endif
   }
 #else
@@ -919,6 +1003,9 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   wave_sync();
   STAMP(3);
   if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
+#if HRG_LIFT
+  if (m.task == HRG_TASK_LIFTING) lifting_mocap(dm_, lane);   // CollaborativeLiftingCart._control_human (583-588)
+#endif
   STAMP(4);
   int ncon = 0;
   int crash = 0;
@@ -926,11 +1013,11 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   // HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human pose
   // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
   // One loop body for both passes keeps a single inlined copy of the contact and solver code.
-  if (m.task >= HRG_TASK_HANDOVER_H2R) {
+  if (HRG_IS_HANDOVER(m.task)) {
     for (int k = lane; k < HRG_NHB * 6; k += 64) (&L.hcap_keep[0][0])[k] = (&L.hcap[0][0])[k];
   }
 #pragma unroll 1
-  for (int pass = m.task >= HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
+  for (int pass = HRG_IS_HANDOVER(m.task) ? 0 : 1; pass < 2 && !crash; pass++) {
     collide(dm_, lane, &ncon);
     STAMP(5);
     if (pass == 1) {
@@ -997,6 +1084,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   wave_sync();
   if (m.ik_enabled) ik_action(dm_, lane);  // IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373)
   screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
+#if HRG_LIFT
+  if (m.task == HRG_TASK_LIFTING) { wave_sync(); if (lane == 0) L.act[NARM] = 1.0; wave_sync(); }   // CollaborativeLiftingCart.step (368-391): the gripper action is replaced by 'close'
+#endif
   if ((m.cp_enabled || m.ik_enabled) && lane < HRG_ACT_DIM) action[lane] = L.act[lane];
   s.timestep = s.timestep + 1;
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
@@ -1031,13 +1121,25 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   const int in_zone = sqrt(o2t) <= m.goal_dist;
   // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
   const int inspection = m.task == HRG_TASK_INSPECTION || m.task == HRG_TASK_HANDOVER_H2R;   // success = the task's animation ran to its end
-  const int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : (inspection ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
+  const int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : ((inspection || m.task == HRG_TASK_LIFTING) ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
   double r = goal_reached ? m.task_reward : ((inspection && in_zone) ? m.object_at_target_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
 #if HRG_HANDOVER
   if (m.task == HRG_TASK_HANDOVER_R2H)   // robot_human_handover_cartesian_env.py:507-555
     r = goal_reached ? m.task_reward : (bx.task_phase == HRG_R2H_RETREAT ? m.object_in_human_hand_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
 #endif
-  const double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
+  double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
+#if HRG_LIFT
+  double balance = 1.0;
+  if (m.task == HRG_TASK_LIFTING) { // collaborative_lifting_cartesian_env.py:429-507: success = the animation ran to its end; base reward +1; dense = normalised balance angle - 2
+    double Rx[9];
+    const double qb[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]};
+    quat2mat(Rx, qb);
+    balance = Rx[8];
+    r = (!crash && bx.task_phase == HRG_PHASE_COMPLETE) ? m.task_reward : (balance < m.min_balance ? m.imbalance_failure_reward : (!bx.gripped ? m.board_released_reward : 1.0));
+    const double ba = asin(clampd(balance, -1.0, 1.0)) * 2 / HRG_PI, mba = asin(m.min_balance) * 2 / HRG_PI;
+    dense = (ba - mba) / (1 - mba) - 2.0;
+  }
+#endif
 #else
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
@@ -1056,6 +1158,15 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   else {
     if (m.done_at_collision && illegal) d = 1;
     if (m.done_at_success && goal_reached) d = 1;
+#if HRG_LIFT
+    if (m.task == HRG_TASK_LIFTING) { // _check_done (509-561): unbalanced, or the board out of the gripper for more than 5 steps in a row
+      const int nd = L.bx.gripped ? 0 : L.bx.n_delayed + 1;
+      wave_sync();
+      L.bx.n_delayed = nd;
+      wave_sync();
+      if (balance < m.min_balance || nd > 5) d = 1;
+    }
+#endif
   }
   const int ncoll = s.n_collisions_static + s.n_collisions_robot + s.n_collisions_human + s.n_collisions_critical;
   int truncated = 0;
@@ -1087,6 +1198,33 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #if HRG_BOX
   if (!d) write_obs(dm_, lane, goal, obs);  // the step's observation predates _on_goal_reached (pick_place_human_cartesian_env.py:414-438)
   wave_sync();
+#if HRG_LIFT
+  if (m.task == HRG_TASK_LIFTING) {
+    if (goal_reached && !m.done_at_success && !d) { // _on_goal_reached (631-642): the robot back at its initial posture (deterministic), controller reset, next animation,
+                                                     // _control_human, board back in the gripper
+      const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+      wave_sync();
+      if (lane < NV) { s.qpos[lane] = lane < NARM ? m.init_qpos[lane] : m.finger_init_qpos[lane - NARM]; s.qvel[lane] = 0.0; s.qacc_warmstart[lane] = 0.0; }
+      s.grip_action = 0.0;
+      { // FailsafeController.reset: the shield's trajectory / path / measurement memory back to the state of a fresh episode
+        double* z0 = (double*)&s.ltt;
+        const int nz = (int)(((const double*)&s.human_site[0][0]) - z0);
+        for (int k = lane; k < nz; k += 64) z0[k] = 0.0;
+      }
+      s.new_goal = 0; s.n_meas = 0;
+      s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+      bx.task_phase = HRG_PHASE_APPROACH; bx.n_delayed = 0;
+      wave_sync();
+      robot_chain_fk(dm_, lane, false);
+      eef_update(dm_);
+      shield_reset(dm_, lane);
+      wave_sync();
+      human_control(dm_, lane, gid);
+      lifting_mocap(dm_, lane);
+      lifting_place_board(dm_, lane);
+    }
+  } else
+#endif
 #if HRG_HANDOVER
   if (m.task == HRG_TASK_HANDOVER_R2H && !d) {
     if (goal_reached && !m.done_at_success) { // _on_goal_reached (robot_human_handover_cartesian_env.py:662-676): next placement, next animation, the human lets go
@@ -1199,6 +1337,11 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #define hrg_reset_kernel hrg_reset_kernel_ho
 #define hrg_box_launch_step hrg_ho_launch_step
 #define hrg_box_launch_reset hrg_ho_launch_reset
+#elif HRG_BOX && HRG_LIFT
+#define hrg_step_kernel hrg_step_kernel_lift
+#define hrg_reset_kernel hrg_reset_kernel_lift
+#define hrg_box_launch_step hrg_lift_launch_step
+#define hrg_box_launch_reset hrg_lift_launch_reset
 #elif HRG_BOX
 #define hrg_step_kernel hrg_step_kernel_box
 #define hrg_reset_kernel hrg_reset_kernel_box
@@ -1283,6 +1426,12 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_step(int n_e
                                                                           float* scratch_obs, hrg_box_state* boxes);
 extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                            int64_t env_id0, hrg_box_state* boxes);
+// ... and of the lifting variant (hrgym_lift.hip)
+extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                            float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                            float* scratch_obs, hrg_box_state* boxes);
+extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                             int64_t env_id0, hrg_box_state* boxes);
 #endif
 #if HRG_BOX
 extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
@@ -1297,6 +1446,8 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #ifdef HRG_STAMPS
 #if HRG_HANDOVER
 #define hrg_debug_stamps hrg_debug_stamps_ho
+#elif HRG_LIFT
+#define hrg_debug_stamps hrg_debug_stamps_lift
 #elif HRG_BOX
 #define hrg_debug_stamps hrg_debug_stamps_box
 #endif
@@ -1370,11 +1521,12 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_HANDOVER_R2H) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
-  if (desc->task >= HRG_TASK_HANDOVER_H2R)
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_LIFTING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task == HRG_TASK_LIFTING && !(desc->min_balance > -1 && desc->min_balance < 1)) return fail(HRG_ERR_INVALID, "CollaborativeLiftingCart: min_balance must lie in (-1, 1)");
+  if (HRG_IS_HANDOVER(desc->task))
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop2[c] >= 0 && clips->clip_n_loop2[c] <= HRG_MAX_LOOP)) return fail(HRG_ERR_INVALID, "HumanRobotHandoverCart: at most 4 loop sines per stage");
-  if (desc->task == HRG_TASK_INSPECTION || desc->task >= HRG_TASK_HANDOVER_H2R)
+  if (desc->task == HRG_TASK_INSPECTION || HRG_IS_HANDOVER(desc->task))
     for (int c = 0; c < clips->n_clips; c++)
       if (!(clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP && clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1]))
         return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");
@@ -1500,7 +1652,8 @@ void hrg_batch_destroy(hrg_batch* b) {
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
-  if (b->task >= HRG_TASK_HANDOVER_H2R) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   HIPCHK(hipGetLastError());
@@ -1516,7 +1669,10 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  if (b->task >= HRG_TASK_HANDOVER_H2R)
+  if (b->task == HRG_TASK_LIFTING)
+    hrg_lift_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+  else if (HRG_IS_HANDOVER(b->task))
     hrg_ho_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else if (b->task != HRG_TASK_REACH)

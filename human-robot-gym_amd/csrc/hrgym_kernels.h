@@ -399,6 +399,16 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
   }
 #endif
 #endif
+#if HRG_LIFT
+  if (m.task == HRG_TASK_LIFTING) { // CollaborativeLiftingCart._compute_animation_time (collaborative_lifting_cartesian_env.py:563-581): frozen at the last frame
+    const int len = dm->clips.clip_len[clip];
+    const bool complete = at >= len - 1;
+    if (complete) at = len - 1;
+    if (at < 0) at = 0;
+    wave_sync();
+    if (complete) L.bx.task_phase = HRG_PHASE_COMPLETE;
+  }
+#endif
   if (at > dm->clips.clip_len[clip] - 1) {
     anim_index = (anim_index + 1) % m.n_anim_ids; // human_env.py:1704-1708
     at = 0;

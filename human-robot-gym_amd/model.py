@@ -113,13 +113,33 @@ HANDOVER_R2H_ENV_KWARGS = dict(
     collision_reward=-1.0,
     done_at_success=True,
 )
-ENV_DEFAULTS = {"ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
+# CollaborativeLiftingCart constructor defaults (collaborative_lifting_cartesian_env.py:215-280) overlaid with
+# config/environment/(default/)collaborative_lifting_cart.yaml
+LIFTING_ENV_KWARGS = dict(
+    PICK_PLACE_ENV_KWARGS,
+    horizon=5000,
+    table_full_size=[0.4, 1.5, 0.05],
+    board_full_size=[1.0, 0.4, 0.03],
+    board_density=20.0,                 # BoxObject(name="board", density=20), 755-760
+    board_released_reward=-10.0,
+    imbalance_failure_reward=-10.0,
+    min_balance=0.8,
+    collision_reward=0,
+    reward_shaping=True,
+    done_at_success=True,
+    human_animation_freq=20,
+    human_rand=[0.0, 0.0, 0.0],
+    n_animations_sampled_per_100_steps=0.2,
+    safe_vel=0.001,
+    lift_anchors=[[-0.45, 0.25, 0.0], [-0.45, -0.25, 0.0]],   # l_anchor / r_anchor of _postprocess_model, 786-795
+)
+ENV_DEFAULTS = {"CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
                 "RobotHumanHandoverCart": HANDOVER_R2H_ENV_KWARGS,
                 "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
                 "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
-BOX_TASKS = ("PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart",
+BOX_TASKS = ("CollaborativeLiftingCart", "PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart",
              "RobotHumanHandoverCart")
-_TASK_OF = {"PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
+_TASK_OF = {"CollaborativeLiftingCart": "HRG_TASK_LIFTING", "PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
             "PickPlacePointingHumanCart": "HRG_TASK_POINTING", "HumanObjectInspectionCart": "HRG_TASK_INSPECTION",
             "HumanRobotHandoverCart": "HRG_TASK_HANDOVER_H2R", "RobotHumanHandoverCart": "HRG_TASK_HANDOVER_R2H"}
 # RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
@@ -511,12 +531,13 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     if env_id in BOX_TASKS:
         d.task = CONST[_TASK_OF[env_id]]
         d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616
-        size = [float(x) for x in kw["object_full_size"]]
+        lifting = env_id == "CollaborativeLiftingCart"
+        size = [float(x) for x in kw["board_full_size" if lifting else "object_full_size"]]
         if not all(x > 0 for x in size):
             raise ValueError("object_full_size must be positive")
         half = [0.5 * x for x in size]
         d.box_half[:] = half
-        d.box_mass = 1000.0 * size[0] * size[1] * size[2]        # BoxObject default density [UPSTREAM robosuite]
+        d.box_mass = (float(kw["board_density"]) if lifting else 1000.0) * size[0] * size[1] * size[2]   # BoxObject default density 1000 [UPSTREAM robosuite]
         inertia = [d.box_mass * (half[(a + 1) % 3] ** 2 + half[(a + 2) % 3] ** 2) / 3.0 for a in range(3)]
         if size[0] == size[1] == size[2]:                        # a cube: one value, so that the deviation from the mean is exactly zero
             inertia = [d.box_mass * size[0] ** 2 / 6.0] * 3
@@ -539,6 +560,17 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
             d.object_at_target_reward = float(kw["object_at_target_reward"])
             d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])
         # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]
+        if lifting:
+            # _reset_internal (673): the Schunk posture whose gripper straddles the board edge; the stand-in gripper closes along its own y axis, so
+            # the last joint is turned until that axis is vertical (-pi/2 instead of -pi/4)
+            d.init_qpos[:] = [0.0, math.pi * 19 / 48, -math.pi / 2 - 5 * math.pi / 48, 0.0, math.pi / 2, -math.pi / 2]
+            for hd in range(2):
+                d.lift_anchor[hd][:] = [float(x) for x in kw["lift_anchors"][hd]]
+            d.lift_grip_depth = 0.0
+            d.min_balance = float(kw["min_balance"])
+            d.imbalance_failure_reward = float(kw["imbalance_failure_reward"])
+            d.board_released_reward = float(kw["board_released_reward"])
+            d.table_half[:] = [0.0, 0.0]     # the 0.4 m table under the board's middle (737-747) is not modelled: nothing to rest on, the floor catches a dropped board
         d.obj_z = 0.8 + half[2]
         d.tgt_z = 0.8 + 0.5 * size[2] + half[2]
         d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)

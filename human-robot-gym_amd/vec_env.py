@@ -76,7 +76,8 @@ OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human
 # training/config/run/obs_keys of the pick-place experiments (e.g. PP-SAC): the observables the policy sees
 PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "gripper_aperture", "dist_eef_to_human_head",
                        "dist_eef_to_human_lh", "dist_eef_to_human_rh"]
-DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else PICK_PLACE_OBS_KEYS) for k in ENV_DEFAULTS}
+LIFTING_OBS_KEYS = ["board_quat", "dist_eef_to_human_head", "vec_eef_to_human_lh", "vec_eef_to_human_rh"]   # CL-SAC.yaml run.obs_keys
+DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else (LIFTING_OBS_KEYS if k == "CollaborativeLiftingCart" else PICK_PLACE_OBS_KEYS)) for k in ENV_DEFAULTS}
 # columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
 OBS_COLUMNS = {
     "object-state": range(0, 12), "goal_difference": range(12, 18), "robot0_joint_pos": range(18, 24),
@@ -88,6 +89,10 @@ OBS_COLUMNS = {
     "object_gripped": range(39, 40), "vec_eef_to_object": range(40, 43), "vec_eef_to_target": range(43, 46),
     "gripper_aperture": range(46, 47), "object_pos": range(47, 50), "target_pos": range(50, 53),
     "robot0_gripper_qpos": range(53, 55), "robot0_gripper_qvel": range(55, 57),
+    # CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py:982-1085): the board sits in the object columns, its balance in the
+    # first target column
+    "board_pos": range(47, 50), "vec_eef_to_board": range(40, 43), "board_gripped": range(39, 40), "board_balance": range(50, 51),
+    "board_quat": [43, 44, 45, 51],
 }
 
 
@@ -225,8 +230,8 @@ class HipVecEnv(_VecEnvBase):
         # the cube tasks [eef_pos, object_pos, object_gripped] vs target_pos (pick_place_human_cartesian_env.py:574-611)
         self.goal_env = bool(goal_env)
         if self.goal_env:
-            if env_id == "HumanObjectInspectionCart":
-                raise NotImplementedError("goal_env: the inspection task's success is a task phase, not a function of the goals")
+            if env_id in ("HumanObjectInspectionCart", "CollaborativeLiftingCart"):
+                raise NotImplementedError("goal_env: this task's success is a task phase, not a function of the goals")
             if obs_keys is None:  # goal_env_wrapper.py:62-71
                 obs_keys = ["object-state", "robot0_proprio-state", "desired_goal"]
             self._ag_cols = np.array(list(range(18, 24)) if env_id == "ReachHuman" else [30, 31, 32, 47, 48, 49, 39], dtype=np.int64)

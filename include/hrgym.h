@@ -105,7 +105,9 @@ enum { HRG_SHIELD_OFF = 0, HRG_SHIELD_SSM = 1, HRG_SHIELD_PFL = 2 };
 enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* HumanObjectInspectionCart */,
        HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */,
        HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */,
-       HRG_TASK_HANDOVER_R2H = 5 /* RobotHumanHandoverCart (robot_human_handover_cartesian_env.py) */ };
+       HRG_TASK_HANDOVER_R2H = 5 /* RobotHumanHandoverCart (robot_human_handover_cartesian_env.py) */,
+       HRG_TASK_LIFTING = 6 /* CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board together */ };
+#define HRG_IS_HANDOVER(task) ((task) == HRG_TASK_HANDOVER_H2R || (task) == HRG_TASK_HANDOVER_R2H)
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
 /* HumanRobotHandoverPhase, human_robot_handover_cartesian_env.py:50-56 (same numbering) */
@@ -239,6 +241,11 @@ typedef struct hrg_model_desc {
   double box_mass, box_inertia[3]; /* BoxObject default density 1000; principal inertia m (b^2 + c^2) / 3 per axis (half extents b, c) */
   double box_inertia_mean;      /* mean of box_inertia: the rotational inertia is handled as mean * identity + R diag(inertia - mean) R' */
   double box_invweight_rot;     /* body_invweight0 (rotation) of the free body: mean of 1 / box_inertia */
+  /* ---- CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py) ---- */
+  double lift_anchor[2][3];     /* board-frame anchors of the left / right hand grips: connect equalities to the hand mocap bodies (786-795, 924-958) */
+  double lift_grip_depth;       /* how far the board's robot-side edge reaches past the grip site along the gripper axis at a reset */
+  double min_balance;           /* episode ends when (board normal . world up) falls below (509-533) */
+  double imbalance_failure_reward, board_released_reward; /* _sparse_reward (446-478) */
   double obj_bin[4], tgt_bin[4]; /* xmin xmax ymin ymax of the sampling bins (843-875) */
   double obj_z, tgt_z;          /* z of a sampled object centre / target (UniformRandomSampler reference_pos + z_offset) */
   double object_gripped_reward;

@@ -89,11 +89,12 @@ typedef struct hrg_box_state {
   int32_t obj_index, tgt_index; /* _object_placements_list_index, _target_positions_index */
   int32_t gripped;              /* _check_grasp at the last substep */
   int32_t task_phase;           /* HRG_PHASE_* (HumanObjectInspectionCart) */
-  int32_t n_delayed;            /* _n_delayed_timesteps: frames the loop phase held the animation back */
+  int32_t n_delayed;            /* _n_delayed_timesteps: frames the loop phase held the animation back (lifting: _n_steps_without_gripped_board) */
   int32_t n_delayed2;           /* second entry of _n_delayed_timesteps (handover: delay accumulated in the WAIT loop) */
   int32_t weld_active;          /* eq_active of the object <-> hand mocap weld (handover tasks) */
   int32_t n_handed_over;        /* _n_object_handed_over */
-  double mocap_pos[3], mocap_quat[4]; /* pose of the mocap body at the human's holding hand (set once per cycle) */
+  double mocap_pos[3], mocap_quat[4]; /* pose of the mocap body at the human's holding hand (set once per cycle); lifting: mocap_pos = left-hand mocap body,
+                                       * weld_off = right-hand mocap body (positions only: connect equalities) */
   double weld_off[3], weld_rel[4];    /* relative pose of the weld: object origin in the mocap frame, q_mocap^-1 q_obj (identity when the human
                                        * picks the object up from its own hand; taken at the palm contact in RobotHumanHandoverCart, 730-748) */
 } hrg_box_state;

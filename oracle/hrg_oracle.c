@@ -424,6 +424,11 @@ static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hr
     if (at >= len - 1) { bx->task_phase = HRG_R2H_COMPLETE; at = len - 1; }
     if (at < 0) at = 0;
   }
+  if (m->task == HRG_TASK_LIFTING) { /* CollaborativeLiftingCart._compute_animation_time (collaborative_lifting_cartesian_env.py:563-581): frozen at the last frame */
+    const int len = b->clips.clip_len[clip];
+    if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+  }
   s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
     s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
@@ -1164,6 +1169,14 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const h
       obs[47 + a] = (float)bx->obs_pos[a];
       obs[50 + a] = (float)bx->target[a];
     }
+    if (m->task == HRG_TASK_LIFTING) { /* collaborative_lifting_cartesian_env.py:982-1085: board_pos / vec_eef_to_board / board_gripped sit in the object columns;
+                                        * board_balance takes the first target column, board_quat columns 43-45 and 51 (quat_eef_to_board: not served) */
+      double Rx[9];
+      quat2mat(Rx, bx->quat);
+      for (int a = 0; a < 3; a++) { obs[43 + a] = (float)bx->quat[1 + a]; obs[50 + a] = 0.0f; } /* board_quat, (x, y, z, w) like T.convert_quat(..., to="xyzw") */
+      obs[51] = (float)bx->quat[0];
+      obs[50] = (float)Rx[8];
+    }
   }
 }
 
@@ -1391,6 +1404,36 @@ static int palm_contact(const hrgo_batch* B, int64_t gid, const hrg_env_state* s
   return sqrt(seg_box(hk->cap1[body], hk->cap2[body], bx->pos, Rx, m->box_half, &t, cs, cb)) - m->hcap_r[body] < 0;
 }
 
+/* rotation matrix (row-major) -> unit quaternion (w, x, y, z), largest-component branch */
+static void mat2quat(double* q, const double* R) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { double s = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s; q[1] = (R[7] - R[5]) / s; q[2] = (R[2] - R[6]) / s; q[3] = (R[3] - R[1]) / s; }
+  else if (R[0] > R[4] && R[0] > R[8]) { double s = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s; q[1] = 0.25 * s; q[2] = (R[1] + R[3]) / s; q[3] = (R[2] + R[6]) / s; }
+  else if (R[4] > R[8]) { double s = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s; q[1] = (R[1] + R[3]) / s; q[2] = 0.25 * s; q[3] = (R[5] + R[7]) / s; }
+  else { double s = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s; q[1] = (R[2] + R[6]) / s; q[2] = (R[5] + R[7]) / s; q[3] = 0.25 * s; }
+}
+/* CollaborativeLiftingCart._reset_animation (collaborative_lifting_cartesian_env.py:644-657) puts the board at a fixed pose that the Schunk
+ * gripper's init_qpos (673) straddles; with the stand-in gripper the pose follows from the gripper frame instead: board x axis = from the
+ * board centre back to the robot (-gripper axis), board normal = the finger closing axis turned upwards, robot-side edge lift_grip_depth past
+ * the grip site.  At rest, no warm start. */
+static void lifting_place_board(const hrg_model_desc* m, const robot_kin* k, const double* eef, hrg_box_state* bx) {
+  const double* Re = k->R[NARM - 1];
+  double ze[3] = {Re[2], Re[5], Re[8]}, ye[3] = {Re[1], Re[4], Re[7]}, xb[3], yb[3], zb[3], Rb[9];
+  const double sg = ye[2] >= 0 ? 1.0 : -1.0;
+  for (int a = 0; a < 3; a++) { xb[a] = -ze[a]; zb[a] = sg * ye[a]; }
+  v3cross(yb, zb, xb);
+  for (int a = 0; a < 3; a++) { Rb[3 * a] = xb[a]; Rb[3 * a + 1] = yb[a]; Rb[3 * a + 2] = zb[a]; }
+  mat2quat(bx->quat, Rb);
+  for (int a = 0; a < 3; a++) bx->pos[a] = eef[a] + ze[a] * (m->box_half[0] - m->lift_grip_depth);
+  for (int a = 0; a < HRG_NBOXV; a++) { bx->vel[a] = 0; bx->acc_warmstart[a] = 0; }
+  v3cpy(bx->obs_pos, bx->pos);
+}
+/* _update_mocap_body_transforms (590-616): the two mocap bodies sit at the hand sites (their orientation does not enter a connect equality) */
+static void lifting_mocap(const hrg_model_desc* m, const hrg_env_state* s, hrg_box_state* bx) {
+  v3cpy(bx->mocap_pos, s->human_site[m->site_lhand]);
+  v3cpy(bx->weld_off, s->human_site[m->site_rhand]);
+}
+
 static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
   double t[3];
   m3mulv(t, k->R[NARM - 1], m->eef_pos);
@@ -1450,6 +1493,18 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
       handover_mocap(B, gid, s, bx, &hk);
       handover_pickup(bx);
     }
+    if (m->task == HRG_TASK_LIFTING) { /* _reset_internal (670-681): _control_human + _reset_animation; the human holds the board from the start (reset's
+                                        * deterministic branch, 696-700: the grasp-and-retry loop of 702-735 is not run) */
+      human_kin hk;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk, s->human_site);
+      lifting_mocap(m, s, bx);
+      lifting_place_board(m, &k, s->eef_pos, bx);
+      bx->weld_active = 1;
+      v3cpy(bx->target, bx->pos);
+    }
     if (m->task == HRG_TASK_HANDOVER_R2H) { /* _reset_animation (the human holds nothing) + _control_human (650-660, 700-706): object in its bin, hand = target */
       human_kin hk;
       double mp[3], mq[4];
@@ -1458,7 +1513,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
       human_fk(m, mp, mq, qh, &hk, s->human_site);
       handover_mocap(B, gid, s, bx, &hk);
     }
-    v3cpy(bx->obs_pos, bx->pos);
+    if (m->task != HRG_TASK_LIFTING) v3cpy(bx->obs_pos, bx->pos);
   } else goal_of(B, gid, s, 0, s->cur_goal);
   if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
 }
@@ -1470,6 +1525,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   const double h = m->timestep;
   if (m->ik_enabled) ik_action(m, s, action); /* IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373) */
   screen_action(B, gid, s, action); /* CollisionPreventionWrapper.step wraps env.step: uses the pre-step state */
+  if (m->task == HRG_TASK_LIFTING) action[NARM] = 1; /* CollaborativeLiftingCart.step (368-391): the gripper action is replaced by 'close' */
   s->timestep += 1; /* human_env.py:490 */
   int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
   robot_kin k;
@@ -1517,9 +1573,10 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     const double* qh;
     human_control(B, gid, s, bx, mp, mq, &qh);
     human_fk(m, mp, mq, qh, &hk, s->human_site);
+    if (m->task == HRG_TASK_LIFTING) lifting_mocap(m, s, bx); /* CollaborativeLiftingCart._control_human (583-588) */
     /* HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human
      * pose before it re-poses the hand mocap body: pass 0 = that step (no bookkeeping), pass 1 = the cycle's regular step */
-    for (int pass = m->task >= HRG_TASK_HANDOVER_H2R ? 0 : 1; pass < 2 && !crash; pass++) {
+    for (int pass = HRG_IS_HANDOVER(m->task) ? 0 : 1; pass < 2 && !crash; pass++) {
     /* ---- contacts + bookkeeping (human_env.py:522) ---- */
     contact_t con[HRG_NCON_MAX];
     int ncon = collide(m, &k, &hk, bx, con);
@@ -1614,7 +1671,24 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
         efc_add(m, &E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
       }
     }
-    if (bx && bx->weld_active) { /* weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
+    if (bx && bx->weld_active && m->task == HRG_TASK_LIFTING) { /* two connect equalities (collaborative_lifting_cartesian_env.py:924-958): the board's grip points follow the
+                                                                  * hand mocap bodies; residual = p_board + R anchor - p_mocap, velocity of the point = v + w x r */
+      double Rx[9];
+      quat2mat(Rx, bx->quat);
+      for (int hd = 0; hd < 2; hd++) {
+        double rr[3], pt[3];
+        const double* mp_ = hd ? bx->weld_off : bx->mocap_pos;
+        m3mulv(rr, Rx, m->lift_anchor[hd]);
+        v3add(pt, bx->pos, rr);
+        for (int a = 0; a < 3; a++) {
+          double J[NVT] = {0}, ea[3] = {a == 0, a == 1, a == 2}, rxe[3];
+          v3cross(rxe, rr, ea); /* (w x r) . e_a = w . (r x e_a) */
+          J[NV + a] = 1;
+          for (int b_ = 0; b_ < 3; b_++) J[NV + 3 + b_] = rxe[b_];
+          efc_add(m, &E, J, qd, ROW_EQUALITY, pt[a] - mp_[a], 0, 0, 1.0 / m->box_mass);
+        }
+      }
+    } else if (bx && bx->weld_active) { /* weld of the object frame onto the hand mocap frame (human_robot_handover_cartesian_env.py:870-903): residual =
                                   * [p_obj - p_mocap; rotation vector of q_obj q_mocap^-1]; the mocap body has no velocity; relpose = identity */
       double epos[3], erot[3], qt[4], qe[4], Rm[9], tp[3];
       quat2mat(Rm, bx->mocap_quat);
@@ -1700,6 +1774,12 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     if (m->task == HRG_TASK_INSPECTION || m->task == HRG_TASK_HANDOVER_H2R) { /* success = the animation ran to its end; human_object_inspection_cartesian_env.py:553-600, human_robot_handover_cartesian_env.py:485-528 */
       goal_reached = !crash && bx->task_phase == HRG_PHASE_COMPLETE;
       r = goal_reached ? m->task_reward : (in_zone ? m->object_at_target_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
+    } else if (m->task == HRG_TASK_LIFTING) { /* collaborative_lifting_cartesian_env.py:429-478: success = the animation ran to its end; base reward +1 */
+      double Rx[9];
+      quat2mat(Rx, bx->quat);
+      const double balance = Rx[8]; /* board normal . world up (board_balance, 1033-1041) */
+      goal_reached = !crash && bx->task_phase == HRG_PHASE_COMPLETE;
+      r = goal_reached ? m->task_reward : (balance < m->min_balance ? m->imbalance_failure_reward : (!bx->gripped ? m->board_released_reward : 1.0));
     } else if (m->task == HRG_TASK_HANDOVER_R2H) { /* robot_human_handover_cartesian_env.py:507-555 */
       goal_reached = !crash && bx->task_phase == HRG_R2H_COMPLETE;
       r = goal_reached ? m->task_reward : (bx->task_phase == HRG_R2H_RETREAT ? m->object_in_human_hand_reward : (bx->gripped ? m->object_gripped_reward : -1.0));
@@ -1708,6 +1788,12 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       r = goal_reached ? m->task_reward : (bx->gripped ? m->object_gripped_reward : -1.0); /* _sparse_reward, 471-500 */
     }
     dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1; /* _dense_reward, 502-526 */
+    if (m->task == HRG_TASK_LIFTING) { /* _dense_reward (480-507): balance angle normalised between arcsin(min_balance) and 1, minus 2 */
+      double Rx[9];
+      quat2mat(Rx, bx->quat);
+      const double ba = asin(clampd(Rx[8], -1.0, 1.0)) * 2 / PI, mba = asin(m->min_balance) * 2 / PI;
+      dense = (ba - mba) / (1 - mba) - 2.0;
+    }
   } else {
     for (int j = 0; j < NARM; j++) dist2 += (s->qpos[j] - goal[j]) * (s->qpos[j] - goal[j]);
     double dist = sqrt(dist2);
@@ -1725,6 +1811,12 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   else {
     if (m->done_at_collision && illegal) d = 1; /* human_env.py:835-858 */
     if (m->done_at_success && goal_reached) d = 1;
+    if (m->task == HRG_TASK_LIFTING) { /* _check_done (509-561): unbalanced, or the board out of the gripper for more than 5 steps in a row */
+      double Rx[9];
+      quat2mat(Rx, bx->quat);
+      bx->n_delayed = bx->gripped ? 0 : bx->n_delayed + 1;
+      if (Rx[8] < m->min_balance || bx->n_delayed > 5) d = 1;
+    }
   }
   int ncoll = s->n_collisions_static + s->n_collisions_robot + s->n_collisions_human + s->n_collisions_critical;
   info[HRG_INFO_COLLISION] = has_collision;
@@ -1741,7 +1833,29 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   info[HRG_INFO_TRUNCATED] = 0;
   info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
   info[HRG_INFO_N_OBJECT_HANDED_OVER] = bx ? bx->n_handed_over : 0;
-  if (bx && m->task == HRG_TASK_HANDOVER_R2H) {
+  if (bx && m->task == HRG_TASK_LIFTING) {
+    if (goal_reached && !m->done_at_success) { /* _on_goal_reached (631-642): the robot back at its initial posture (deterministic), controller reset, next
+                                                * animation, _control_human, board back in the gripper */
+      for (int j = 0; j < NARM; j++) { s->qpos[j] = m->init_qpos[j]; s->qvel[j] = 0; s->qacc_warmstart[j] = 0; }
+      for (int j = 0; j < HRG_NFINGER; j++) { s->qpos[NARM + j] = m->finger_init_qpos[j]; s->qvel[NARM + j] = 0; s->qacc_warmstart[NARM + j] = 0; }
+      s->grip_action = 0;
+      robot_fk(m, s->qpos, &k);
+      eef_of(m, &k, s->eef_pos);
+      shield_reset(m, s, s->qpos);
+      for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
+      s->anim_index = (s->anim_index + 1) % m->n_anim_ids;
+      s->animation_time = 0;
+      s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+      bx->task_phase = HRG_PHASE_APPROACH; bx->n_delayed = 0;
+      human_kin hk2;
+      double mp[3], mq[4];
+      const double* qh;
+      human_control(B, gid, s, bx, mp, mq, &qh);
+      human_fk(m, mp, mq, qh, &hk2, s->human_site);
+      lifting_mocap(m, s, bx);
+      lifting_place_board(m, &k, s->eef_pos, bx);
+    }
+  } else if (bx && m->task == HRG_TASK_HANDOVER_R2H) {
     if (goal_reached && !m->done_at_success) { /* _on_goal_reached (662-676): next placement, next animation, the human lets go */
       bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
       placement_of(B, gid, s->episode, bx->obj_index, 0, bx->pos);

@@ -1,0 +1,175 @@
+"""CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board; the human's end hangs on two connect
+equalities at the hand mocap bodies, the robot's end sits between the fingers.  PARITY UNPINNED: behaviour the reference
+documents (rewards, termination rules, success = animation complete) on the CPU oracle, oracle <-> HIP parity on the GPU."""
+import math
+
+import numpy as np
+import pytest
+
+import human_robot_gym_amd as hrg
+from human_robot_gym_amd import mixed
+from human_robot_gym_amd._cstruct import CONST
+from human_robot_gym_amd.animation import hand_sites, lifting_hands_nominal
+
+ENV = "CollaborativeLiftingCart"
+
+
+def _clips(n=3, lo=100, hi=150):
+    return mixed.task_clips(ENV, n, min_frames=lo, max_frames=hi)
+
+
+def _oracle(n, kw, clips):
+    from oracle.oracle import OracleBatch
+    d = hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=ENV)
+    return OracleBatch(d, clips, n), d
+
+
+def test_desc_follows_the_reference_defaults():
+    d = hrg.build_model_desc(None, env_id=ENV)
+    assert d.task == CONST["HRG_TASK_LIFTING"] and d.horizon == 5000 and d.n_anim_ids == 10      # collaborative_lifting_cart.yaml
+    assert list(d.box_half) == [0.5, 0.2, 0.015] and abs(d.box_mass - 20 * 1.0 * 0.4 * 0.03) < 1e-12   # board_full_size, density 20 (755-760)
+    assert d.min_balance == 0.8 and d.imbalance_failure_reward == -10 and d.board_released_reward == -10 and d.reward_shaping == 1
+    assert [list(a) for a in d.lift_anchor] == [[-0.45, 0.25, 0.0], [-0.45, -0.25, 0.0]]          # _postprocess_model, 786-795
+    assert abs(d.init_qpos[1] - math.pi * 19 / 48) < 1e-15 and abs(d.init_qpos[2] + math.pi / 2 + 5 * math.pi / 48) < 1e-15   # _reset_internal, 673
+
+
+def test_synthetic_lifting_clips_put_the_hands_at_the_board_grips():
+    d = hrg.build_model_desc(None, env_id=ENV)
+    nom = lifting_hands_nominal(d)
+    clips = _clips()
+    o = 0
+    for c in range(clips.n_clips):
+        lh, rh = hand_sites(clips.frames[o:o + clips.lengths[c]], clips.infos[c])
+        o += clips.lengths[c]
+        mid = 0.5 * (lh + rh)
+        assert np.allclose(mid[0], nom, atol=1e-9) and np.allclose(mid[-1], nom, atol=0.05)       # starts and ends at the board's rest height
+        assert 0.1 < mid[:, 2].max() - nom[2] < 0.26                                              # the lift in between
+        assert (lh[:, 1] < rh[:, 1]).all()                                                        # facing the robot: left hand at -y
+        assert 0.3 < np.linalg.norm(rh - lh, axis=1).min() and np.linalg.norm(rh - lh, axis=1).max() < 0.7
+
+
+def test_reset_puts_the_board_into_the_gripper_and_the_hands():
+    B, d = _oracle(3, dict(seed=3, horizon=200), _clips())
+    obs = B.reset()
+    for e in range(3):
+        bx, st = B.get_box(e), B.get_state(e)
+        assert bx.weld_active == 1 and bx.task_phase == 0 and bx.n_delayed == 0
+        assert obs[e, 50] > 0.995 and obs[e, 39] == 0                       # level (init noise 0.02 rad), not gripped yet: the fingers start open
+        eef, pos = np.array(list(st.eef_pos)), np.array(list(bx.pos))
+        assert abs(np.linalg.norm(pos - eef) - d.box_half[0]) < 1e-9        # robot-side edge at the grip site
+        assert np.linalg.norm(np.array(list(bx.mocap_pos)) - np.array(list(bx.weld_off))) > 0.3   # the two hand mocap bodies
+        assert np.allclose(obs[e, 47:50], pos, atol=1e-6) and np.allclose(obs[e, 40:43], pos - eef, atol=1e-6)
+    B.close()
+
+
+def test_holding_the_board_pays_the_balance_reward_and_losing_it_ends_the_episode():
+    B, d = _oracle(4, dict(seed=3, horizon=200), _clips())
+    B.reset()
+    held = 0
+    ended = {"imbalance": 0, "released": 0}
+    unheld = np.zeros(4, int)
+    for k in range(60):
+        obs, r, dn, info = B.step(np.zeros((4, 7)))                          # the gripper action is overridden by 'close' (368-391)
+        t = B.term_obs
+        for e in range(4):
+            bal, grip = float(t[e, 50]), t[e, 39] != 0
+            unheld[e] = 0 if grip else unheld[e] + 1
+            dense = (math.asin(min(bal, 1.0)) * 2 / math.pi - math.asin(0.8) * 2 / math.pi) / (1 - math.asin(0.8) * 2 / math.pi) - 2.0
+            sparse = -10.0 if bal < 0.8 else (-10.0 if not grip else 1.0)   # _sparse_reward, 446-478 (no success in this window)
+            assert abs(r[e] - (sparse + 1.0 + dense)) < 2e-5, (k, e, r[e], bal, grip)
+            assert bool(dn[e]) == (bal < 0.8 or unheld[e] > 5)               # _check_done, 509-561
+            if dn[e]:
+                ended["imbalance" if bal < 0.8 else "released"] += 1
+                unheld[e] = 0
+            held += int(grip and bal >= 0.8)
+        assert not info[:, 11].any()
+    assert held > 60 and ended["imbalance"] + ended["released"] > 0          # the robot stands still while the human lifts: the board slips out sooner or later
+    B.close()
+
+
+def test_animation_complete_is_the_success_and_starts_the_next_task():
+    clips = mixed.task_clips(ENV, 2, min_frames=20, max_frames=24)           # 20 Hz clips of 1.0-1.2 s: over after 10-12 policy steps
+    B, d = _oracle(2, dict(seed=5, horizon=200, done_at_success=False), clips)
+    B.reset()
+    wins, checked = np.zeros(2, int), 0
+    for k in range(40):
+        obs, r, dn, info = B.step(np.zeros((2, 7)))
+        for e in range(2):
+            if info[e, 9] > wins[e]:                                           # n_goal_reached went up: task_reward (+ shaping), robot and board back at the start
+                wins[e] = info[e, 9]
+                assert r[e] > -1.0                                  # task_reward + 1 + (normalised balance - 2); a failure would pay -10
+                if dn[e]:                                           # (the board may have slipped in the same step: _check_done is independent)
+                    continue
+                checked += 1
+                bx, st = B.get_box(e), B.get_state(e)
+                assert bx.task_phase == 0 and np.allclose(list(st.qpos)[:6], list(d.init_qpos), atol=1e-12) and max(abs(v) for v in st.qvel) == 0
+                assert abs(np.linalg.norm(np.array(list(bx.pos)) - np.array(list(st.eef_pos))) - d.box_half[0]) < 1e-9
+    assert (wins >= 1).all() and checked >= 1
+    B2, _ = _oracle(2, dict(seed=5, horizon=200, done_at_success=True), clips)
+    B2.reset()
+    done_on_success = 0
+    for k in range(30):
+        obs, r, dn, info = B2.step(np.zeros((2, 7)))
+        done_on_success += int(((info[:, 9] > 0) & (dn != 0)).sum())
+    assert done_on_success >= 1
+    B.close(); B2.close()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_on_the_lifting_task():
+    import torch
+    from helpers import ATOL, RTOL, assert_state_close, make_pair
+    clips = _clips(3, 100, 150)
+    O, G = make_pair(6, dict(seed=3, horizon=40, shield_type="SSM"), clips=clips, env_id=ENV)
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    for e in range(6):
+        assert_state_close(O.get_box(e), G.get_box(e), f"reset env {e} box")
+    rng = np.random.RandomState(0)
+    held = 0
+    for k in range(90):
+        a = rng.uniform(-0.3, 0.3, (6, 7))
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(G.term_obs.cpu().numpy(), O.term_obs, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        held += int(O.term_obs[:, 39].sum())
+        for e in range(6):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+            assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
+            if k % 4 == 3:      # three-point support with sliding finger contacts: resynchronise before rounding differences grow
+                G.set_state(e, O.get_state(e))
+                G.set_box(e, O.get_box(e))
+    assert held > 100
+    O.close(); G.close()
+
+
+@pytest.mark.gpu
+def test_lifting_long_run_stays_finite():
+    """Soak: 1024 envs x 200 policy steps of random arm actions with auto-resets: nothing turns non-finite, no simulation crashes, the board
+    stays a rigid body, boards are held for a good part of the time and episodes end for every documented reason."""
+    import torch
+    from human_robot_gym_amd._lib import HipBatch
+    n = 1024
+    clips = _clips(5, 200, 400)
+    d = hrg.build_model_desc(dict(seed=31, horizon=150), n_clips=clips.n_clips, env_id=ENV)
+    G = HipBatch(d, clips, n)
+    G.reset()
+    g = torch.Generator(device="cpu").manual_seed(4)
+    crashes = held = dones = 0
+    for k in range(200):
+        a = ((torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1) * 0.3).cuda()
+        obs, r, dn, info = G.step(a)
+        crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item())
+        if k % 40 == 39:
+            o, t = obs.cpu().numpy(), G.term_obs.cpu().numpy()
+            assert np.isfinite(o).all() and np.isfinite(t).all() and np.isfinite(r.cpu().numpy()).all()
+            held += int((t[:, 39] != 0).sum())
+            _, bx = G.get_states(np.arange(0, n, 16))
+            assert max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx) < 1e-12
+            assert all(b.weld_active == 1 for b in bx)
+    assert crashes == 0 and held > n and dones > 0
+    G.close()

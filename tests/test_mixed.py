@@ -8,11 +8,11 @@ from human_robot_gym_amd.model import ENV_DEFAULTS
 
 
 def test_even_split_and_task_table():
-    assert mixed.split_evenly(4096, 4) == [1024] * 4
+    assert mixed.split_evenly(4096, 4) == [1024] * 4 and len(mixed.ICRA_TASKS) == 5
     assert mixed.split_evenly(10, 4) == [3, 3, 2, 2] and sum(mixed.split_evenly(4097, 6)) == 4097
     for env_id, kw in mixed.ICRA_TASKS:
         assert env_id in ENV_DEFAULTS
-        assert kw["horizon"] == {"ReachHuman": 100}.get(env_id, 1000)          # icra_2024_run_experiments.sh:4-9
+        assert kw["horizon"] == {"ReachHuman": 100, "CollaborativeLiftingCart": 5000}.get(env_id, 1000)          # icra_2024_run_experiments.sh:4-9
         assert kw["shield_type"] == ("PFL" if "Handover" in env_id else "SSM")
         clips = mixed.task_clips(env_id, 2, min_frames=60, max_frames=80)
         assert clips.n_clips == 2
@@ -76,9 +76,9 @@ def test_mixed_vec_env_surface():
         for d, done in zip(infos, dones):
             assert ("terminal_observation" in d) == bool(done)
             if done:
-                assert d["terminal_observation"].shape == (57,) and d["episode"]["l"] == 5
+                assert d["terminal_observation"].shape == (57,) and d["episode"]["l"] <= 5
         n_done += int(dones.sum())
-    assert n_done == 12                                                         # horizon 5: every env timed out exactly once
+    assert n_done >= 12                                                         # horizon 5: every env timed out once (a board may also be dropped earlier)
     env2 = mixed.make_mixed_vec_env(8, obs_keys=["robot0_eef_pos", "dist_eef_to_human_head"], n_clips=2)
     assert env2.reset().shape == (8, 4)
     env.close()

@@ -16,10 +16,15 @@ clips = mixed.task_clips(env_id, 13)
 d = hrg.build_model_desc(dict(shield_type=shield, horizon=1000, seed=9), n_clips=clips.n_clips, env_id=env_id)
 G = HipBatch(d, clips, n)
 G.reset()
+torch.cuda.synchronize()
+print("reset done", flush=True)
 g = torch.Generator(device="cpu").manual_seed(0)
 acts = [(torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda() for _ in range(8)]
 for k in range(10):
     G.step(acts[k % 8])
+    if os.environ.get("HRG_TT_SYNC"):
+        torch.cuda.synchronize()
+        print("warm-up step", k, flush=True)
 torch.cuda.synchronize()
 G.kernel_time()
 t0 = time.time()
