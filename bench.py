@@ -45,7 +45,7 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     cores = min(avail, max_threads)  # a 1-GPU box is given a 16-core CPU share
     n = n_envs
-    clips = hrg.synthetic_clips(13, seed=clips_seed)
+    clips = _bench_clips(env_id, clips_seed)
     desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id, **(wrappers or {}))
     B = OracleBatch(desc, clips, n, 0)
     B.reset()
@@ -79,6 +79,23 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="
             "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} of {avail} host threads"}
 
 
+OTHER_TASKS = {  # --env values beyond the two benchmark configurations: (env kwargs, kernel) per training/icra_2024_run_experiments.sh:4-9
+    "HumanObjectInspectionCart": (dict(horizon=1000), "hrg_step_kernel_box"),
+    "HumanRobotHandoverCart": (dict(horizon=1000, shield_type="PFL"), "hrg_step_kernel_ho"),
+    "RobotHumanHandoverCart": (dict(horizon=1000, shield_type="PFL"), "hrg_step_kernel_ho"),
+    "CollaborativeLiftingCart": (dict(horizon=5000), "hrg_step_kernel_lift"),
+}
+
+
+def _bench_clips(env_id, seed=0):
+    """13 synthetic clips; the collaboration tasks get the animation info they read (mixed.task_clips)."""
+    import human_robot_gym_amd as hrg
+    if env_id in OTHER_TASKS:
+        from human_robot_gym_amd.mixed import task_clips
+        return task_clips(env_id, 13, seed=seed)
+    return hrg.synthetic_clips(13, seed=seed)
+
+
 class _stdout_to_stderr:
     """RCCL prints a version banner on stdout when its communicator comes up; the contract is ONE JSON line on stdout, so the file
     descriptor is pointed at stderr while the process group initialises and the warm-up steps run."""
@@ -102,8 +119,9 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
-    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart"],
-                    help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs)")
+    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart"] + sorted(OTHER_TASKS),
+                    help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs); "
+                         "the other tasks of the ICRA suite at 4096 envs (--shield is overridden by the suite's shield type where it names one)")
     ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
                     "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
@@ -133,15 +151,19 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ReachHuman training configuration: training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
-    pick_place = args.env == "PickPlaceHumanCart"
-    if pick_place:  # training/config/environment/pick_place_human_cart.yaml
+    pick_place = args.env != "ReachHuman"   # every other task carries the manipulation object's state block
+    if args.env in OTHER_TASKS:
+        env_kwargs = dict(shield_type=args.shield, control_freq=10, seed=1234)
+        env_kwargs.update(OTHER_TASKS[args.env][0])
+        args.shield = env_kwargs["shield_type"]
+    elif pick_place:  # training/config/environment/pick_place_human_cart.yaml
         env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=1000, done_at_success=False, goal_dist=0.1,
                           reward_shaping=False, collision_reward=0, object_gripped_reward=-0.25, seed=1234)
     else:
         env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
                           reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
-    n = args.envs_per_gpu or (8192 if pick_place else ENVS_PER_GPU)
-    clips = hrg.synthetic_clips(13, seed=0)
+    n = args.envs_per_gpu or (8192 if args.env == "PickPlaceHumanCart" else ENVS_PER_GPU)
+    clips = _bench_clips(args.env, 0)
     wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if args.ik else {}
     desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env, **wrappers)
     G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
@@ -216,7 +238,7 @@ def main():
         if pick_place or n != ENVS_PER_GPU:
             traffic = None  # the committed PMC capture is of the default workload's kernel
         out = {
-            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else "env steps/sec (whole node), PickPlaceHumanCart+shield 8192 envs",
+            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else f"env steps/sec (whole node), {args.env}+shield {n} envs",
             "value": world * n * args.steps / elapsed,
             "unit": "env steps/s",
             "n_gpus": world,
@@ -235,7 +257,7 @@ def main():
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if serial else " on a side stream") if gather is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "hrg_step_kernel_box" if pick_place else "hrg_step_kernel", "kernel_ms": kernel_ms, "launches": n_launch,
+                         "traffic": traffic, "kernel": OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel"), "kernel_ms": kernel_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": per_env * n},
         }
         if world == 1 and not args.no_cpu_baseline:
