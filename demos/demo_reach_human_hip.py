@@ -2,7 +2,7 @@
 """The reference's `demos/demo_reach_human_environment.py` loop on the HIP stepper: one ReachHuman env, SSM shield, random or scripted
 joint-space actions, the same 4-tuple gym API.  Needs an MI355X (there is no CPU fallback).
 
-    python demos/demo_reach_human_hip.py [--steps 200] [--env PickPlaceHumanCart] [--cartesian]
+    python demos/demo_reach_human_hip.py [--steps 200] [--env PickPlaceHumanCart|CollaborativeLiftingCart|...] [--cartesian]
 """
 import argparse
 import os
@@ -11,19 +11,19 @@ import sys
 import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import human_robot_gym_amd as hrg  # noqa: E402
 from human_robot_gym_amd.vec_env import HipVecEnv  # noqa: E402
 
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart", "PickPlaceCloseHumanCart",
-                                                             "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart"])
+    from human_robot_gym_amd.model import ENV_DEFAULTS
+    ap.add_argument("--env", default="ReachHuman", choices=sorted(ENV_DEFAULTS))
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--n-envs", type=int, default=4)
     ap.add_argument("--cartesian", action="store_true", help="[dx, dy, dz, gripper] actions through the in-kernel IK (config/wrappers/safe_ik.yaml)")
     args = ap.parse_args()
-    clips = hrg.synthetic_clips(4, seed=0, inspection=args.env == "HumanObjectInspectionCart", handover=args.env == "HumanRobotHandoverCart")
+    from human_robot_gym_amd.mixed import task_clips
+    clips = task_clips(args.env, 4)   # synthetic clips carrying the animation info the task reads
     wrappers = dict(collision_prevention=dict(replace_type=0, n_resamples=20))
     if args.cartesian:
         wrappers["ik_position_delta"] = dict(action_limit=0.15)

@@ -173,3 +173,66 @@ def test_lifting_long_run_stays_finite():
             assert all(b.weld_active == 1 for b in bx)
     assert crashes == 0 and held > n and dones > 0
     G.close()
+
+
+def test_board_on_its_two_connects_swings_like_a_physical_pendulum():
+    """Known answer for the connect rows (point Jacobian [1 | -[r]x]) and the anisotropic inertia: with the robot out of the way the board
+    hangs on the line through its two anchors; small swings have the period 2 pi sqrt((I_yy + m d^2) / (m g d)), d = 0.45 m."""
+    from human_robot_gym_amd.animation import ClipSet, _qpos_joint_order
+    from oracle.oracle import OracleBatch
+    src = _clips(1, 100, 120)
+    f0, order = src.frames[0], _qpos_joint_order()
+    n = 900
+    anim = {"Pelvis_pos_x": np.full(n, f0[0]), "Pelvis_pos_y": np.full(n, f0[1]), "Pelvis_pos_z": np.full(n, f0[2]), "Pelvis_quat": np.tile(f0[3:7], (n, 1))}
+    anim.update({name: np.full(n, f0[7 + k]) for k, name in enumerate(order)})
+    clips = ClipSet([(anim, src.infos[0])])                       # the human stands still: the hands (mocap bodies) are fixed points
+    d = hrg.build_model_desc(dict(seed=1, horizon=2000, control_freq=50, shield_type="OFF", min_balance=-0.99, done_at_success=False,
+                                  base_human_pos_offset=[0.0, 0.0, 0.6]), n_clips=1, env_id=ENV)      # the human on a 60 cm step: the 1 m board clears the floor
+    B = OracleBatch(d, clips, 1)
+    B.reset()
+    st, bx = B.get_state(0), B.get_box(0)
+    for j, q in enumerate([0.0, -1.2, 0.0, 0.0, 0.0, 0.0]):      # the arm folded back over the base, away from the board
+        st.qpos[j] = q
+    for k in range(len(st.ltt.q0)):
+        st.ltt.q0[k] = st.ltt.qT[k] = st.des_q[k] = st.goal_qpos[k] = st.new_goal_q[k] = st.qpos[k]
+    B.set_state(0, st)
+    hl, hr = np.array(list(bx.mocap_pos)), np.array(list(bx.weld_off))
+    c, u = 0.5 * (hl + hr), (hr - hl) / np.linalg.norm(hr - hl)
+
+    def rot(axis, ang):
+        K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+        return np.eye(3) + np.sin(ang) * K + (1 - np.cos(ang)) * (K @ K)
+
+    def quat_of(R):
+        w = 0.5 * np.sqrt(max(1 + R[0, 0] + R[1, 1] + R[2, 2], 1e-30))
+        return np.array([w, (R[2, 1] - R[1, 2]) / (4 * w), (R[0, 2] - R[2, 0]) / (4 * w), (R[1, 0] - R[0, 1]) / (4 * w)])
+
+    down = np.array([0.0, 0.0, -1.0]) - u * (np.array([0.0, 0.0, -1.0]) @ u)
+    down /= np.linalg.norm(down)
+    xb = rot(u, np.radians(10.0)) @ down                          # from the hinge line to the far edge: 10 degrees off the vertical
+    yb = -u                                                       # the left anchor (+y in the board frame) at the left hand
+    Rb = np.stack([xb, yb, np.cross(xb, yb)], 1)
+    best = (c + 0.45 * xb, quat_of(Rb))                           # the anchors' midpoint (-0.45, 0, 0) on the hands' midpoint
+    bx.pos[:] = best[0].tolist(); bx.quat[:] = best[1].tolist()
+    for a in range(6):
+        bx.vel[a] = 0.0; bx.acc_warmstart[a] = 0.0
+    B.set_box(0, bx)
+    phi = []
+    for k in range(200):                                          # 4 s
+        _, _, dn, info = B.step(np.zeros((1, 7)))
+        assert not info[0, 11] and not dn[0]
+        bx = B.get_box(0)
+        bx.n_delayed = 0                                          # (nobody grips the board here: keep _check_done's 5-step tolerance from ending the episode)
+        B.set_box(0, bx)
+        r = np.array(list(bx.pos)) - c
+        r -= u * (r @ u)
+        phi.append(np.arctan2(np.cross(np.array([0, 0, -1.0]), r) @ u, -r[2]))
+    phi = np.array(phi)
+    up = [k for k in range(1, len(phi)) if phi[k - 1] < 0 <= phi[k]]
+    assert len(up) >= 2 and 0.1 < np.abs(phi).max() < 0.25
+    t_cross = [(k - 1 + (0 - phi[k - 1]) / (phi[k] - phi[k - 1])) * 0.02 for k in up]
+    period = np.mean(np.diff(t_cross))
+    m, dcom = d.box_mass, 0.45
+    expect = 2 * np.pi * np.sqrt((d.box_inertia[1] + m * dcom ** 2) / (m * 9.81 * dcom))
+    assert abs(period - expect) < 0.03 * expect, (period, expect)
+    B.close()
