@@ -119,9 +119,10 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
-    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart"] + sorted(OTHER_TASKS),
+    ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart", "mixed"] + sorted(OTHER_TASKS),
                     help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs); "
-                         "the other tasks of the ICRA suite at 4096 envs (--shield is overridden by the suite's shield type where it names one)")
+                         "the other tasks of the ICRA suite at 4096 envs (--shield is overridden by the suite's shield type where it names one); "
+                         "mixed = BASELINE configs[4]: 4096 envs per GPU split evenly over the suite's tasks that are built (mixed.ICRA_TASKS)")
     ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
                     "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
@@ -163,10 +164,20 @@ def main():
         env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
                           reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
     n = args.envs_per_gpu or (8192 if args.env == "PickPlaceHumanCart" else ENVS_PER_GPU)
-    clips = _bench_clips(args.env, 0)
     wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if args.ik else {}
-    desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env, **wrappers)
-    G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
+    mixed_tasks = None
+    if args.env == "mixed":  # one HipBatch per task on its own stream, one packed output block (human_robot_gym_amd/mixed.py)
+        from human_robot_gym_amd import mixed
+        if args.ik:
+            raise SystemExit("--ik: the mixed batch takes joint-space actions")
+        mixed_tasks = [t[0] for t in mixed.ICRA_TASKS]
+        G = mixed.make_mixed_batch(n, seed=1234, env_id0=rank * n, device=local_rank)
+        desc = hrg.build_model_desc(dict(seed=1234), env_id="PickPlaceHumanCart")   # (substeps per step and the horizon field of the report only)
+        args.shield = "per task"
+    else:
+        clips = _bench_clips(args.env, 0)
+        desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env, **wrappers)
+        G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
     dev = G.device
     G.reset()
     gen = torch.Generator(device=dev)
@@ -228,6 +239,10 @@ def main():
     if rank == 0:
         state_bytes = load_library().hrg_state_bytes() + (load_library().hrg_box_bytes() if pick_place else 0)
         per_env = algorithmic_bytes_per_env_step(C, state_bytes, desc.n_cycles)
+        if mixed_tasks:  # ReachHuman's share moves no object block; the kernels overlap, so the launch duration is the step's wall time
+            n_reach = G.slices[G.env_ids.index("ReachHuman")].stop - G.slices[G.env_ids.index("ReachHuman")].start if "ReachHuman" in G.env_ids else 0
+            per_env = (per_env * n - n_reach * 2 * load_library().hrg_box_bytes()) / n
+            kernel_ms = 1e3 * elapsed / args.steps
         achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         traffic = None
         try:
@@ -238,7 +253,8 @@ def main():
         if pick_place or n != ENVS_PER_GPU:
             traffic = None  # the committed PMC capture is of the default workload's kernel
         out = {
-            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else f"env steps/sec (whole node), {args.env}+shield {n} envs",
+            "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else (
+                f"env steps/sec (whole node), mixed ICRA task batch {n} envs/GPU" if mixed_tasks else f"env steps/sec (whole node), {args.env}+shield {n} envs"),
             "value": world * n * args.steps / elapsed,
             "unit": "env steps/s",
             "n_gpus": world,
@@ -257,11 +273,15 @@ def main():
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if serial else " on a side stream") if gather is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel"), "kernel_ms": kernel_ms, "launches": n_launch,
+                         "traffic": traffic, "kernel": "all step kernels, concurrent (wall time per step)" if mixed_tasks else (
+                             OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel")), "kernel_ms": kernel_ms, "launches": n_launch,
                          "algorithmic_bytes_per_launch": per_env * n},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n, wrappers=wrappers)
+            if mixed_tasks:
+                out["config"]["tasks"] = mixed_tasks
+            else:
+                out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n, wrappers=wrappers)
         print(json.dumps(out), flush=True)
     G.close()
     if world > 1:

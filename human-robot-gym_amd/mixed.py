@@ -102,6 +102,12 @@ class MixedBatch:
         self._keep = actions
         return self.obs, self.reward, self.done, self.info
 
+    def kernel_time(self):
+        """(sum over the parts of their average step-kernel ms, launches per part) since the previous call; the first call arms the timers.
+        With `concurrent` the kernels overlap, so the sum exceeds the step's wall time."""
+        per = [b.kernel_time() for b in self.batches]
+        return sum(ms for ms, _ in per), (per[0][1] if per else 0)
+
     def part_of(self, env):
         """(part index, row within the part) of global row `env`."""
         for i, sl in enumerate(self.slices):
