@@ -223,6 +223,7 @@ def _mixed_cls():
             self._ep_len = np.zeros(batch.n, np.int64)
             self._t_start = time.time()
             self._actions = None
+            self._last_full = None
             self._task_of_row = [eid for eid, sl in zip(batch.env_ids, batch.slices) for _ in range(sl.stop - sl.start)]
 
         def _make_infos(self, info, dones, term_obs):
@@ -237,6 +238,8 @@ def _mixed_cls():
         def get_attr(self, attr_name, indices=None):
             if attr_name == "task":
                 return [self._task_of_row[i] for i in self._indices(indices)]
+            if attr_name == "joint_pos":
+                return HipVecEnv.get_attr(self, attr_name, indices)
             raise AttributeError(f"MixedHipVecEnv has no per-env attribute {attr_name!r}")
 
         def compute_reward(self, *a, **k):

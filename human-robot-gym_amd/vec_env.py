@@ -280,6 +280,7 @@ class HipVecEnv(_VecEnvBase):
         self._ep_len = np.zeros(n_envs, np.int64)
         self._t_start = time.time()
         self._actions = None
+        self._last_full = None
         self.horizon = int(self._desc.horizon)
 
     # ---- VecEnv API -------------------------------------------------------------------------------------
@@ -287,6 +288,7 @@ class HipVecEnv(_VecEnvBase):
         self._ep_ret[:] = 0
         self._ep_len[:] = 0
         full = np.asarray(self._backend.reset())
+        self._last_full = full
         if self.expert_obs_keys is not None:
             self._expert_cur = np.array(full, copy=True)
         return self._view(full)
@@ -303,6 +305,7 @@ class HipVecEnv(_VecEnvBase):
     def step_wait(self):
         obs, term_obs, reward, done, info = self._backend.step_wait()
         full = np.asarray(obs)
+        self._last_full = full
         obs, reward = self._view(full), np.array(reward, copy=True)
         dones = np.asarray(done).astype(bool)
         self._ep_ret += reward
@@ -359,7 +362,35 @@ class HipVecEnv(_VecEnvBase):
         idx = self._indices(indices)
         if attr_name in ("horizon", "env_kwargs"):
             return [getattr(self, attr_name)] * len(idx)
+        if attr_name == "joint_pos":   # env.robots[0].controller.joint_pos (ik_position_delta_wrapper.py:107): the arm's joint angles after the last step / reset
+            if self._last_full is None:
+                raise RuntimeError("joint_pos: call reset() first")
+            return [np.array(self._last_full[i, 18:24], np.float64) for i in idx]
         raise AttributeError(f"HipVecEnv has no per-env attribute {attr_name!r}")
+
+    # HumanEnv.get_environment_state / set_environment_state (human_env.py:588-627; used by the dataset / reference-state-initialisation wrappers):
+    # the stepper's state blocks, batched.  Each entry is (hrg_env_state, hrg_box_state or None); a restored episode keeps its own random streams.
+    def get_environment_state(self, indices=None):
+        batch = getattr(self._backend, "batch", None)
+        if batch is None or not hasattr(batch, "get_states"):
+            raise NotImplementedError("get_environment_state needs the HIP batch backend")
+        idx = self._indices(indices)
+        states, boxes = batch.get_states(np.asarray(idx, np.int32))
+        has_box = self.env_id != "ReachHuman"
+        return [(st, boxes[k] if has_box else None) for k, st in enumerate(states)]
+
+    def set_environment_state(self, states, indices=None):
+        batch = getattr(self._backend, "batch", None)
+        if batch is None or not hasattr(batch, "set_states"):
+            raise NotImplementedError("set_environment_state needs the HIP batch backend")
+        idx = self._indices(indices)
+        if len(states) != len(idx):
+            raise ValueError(f"{len(states)} states for {len(idx)} envs")
+        from ._cstruct import BoxState, EnvState
+        st_arr = (EnvState * len(idx))(*[st for st, _ in states])
+        boxes = [b for _, b in states]
+        bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and self.env_id != "ReachHuman" else None
+        batch.set_states(np.asarray(idx, np.int32), st_arr, bx_arr)
 
     def set_attr(self, attr_name, value, indices=None):
         raise NotImplementedError("per-env attributes are fixed at construction (hrg_model_desc)")

@@ -184,3 +184,32 @@ def test_batched_state_io_reference_state_initialisation():
     np.testing.assert_array_equal(rB[perm], rA[:4])
     np.testing.assert_array_equal(iB[perm], iA[:4])
     A.close(); B.close()
+
+
+@pytest.mark.gpu
+def test_vec_env_state_snapshots_and_joint_pos():
+    """HipVecEnv.get_environment_state / set_environment_state (HumanEnv.get/set_environment_state, human_env.py:588-627) and the
+    `joint_pos` attribute the IK wrapper reads (ik_position_delta_wrapper.py:107): restoring a snapshot replays the same steps."""
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    for env_id in ("ReachHuman", "PickPlaceHumanCart"):
+        clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+        env = HipVecEnv(6, env_id=env_id, env_kwargs=dict(seed=4, horizon=50), clips=clips, obs_keys=["robot0_joint_pos", "robot0_eef_pos"])
+        env.reset()
+        rng = np.random.RandomState(0)
+        acts = [rng.uniform(-1, 1, (6, 7)) for _ in range(8)]
+        for a in acts[:3]:
+            obs, _, _, _ = env.step(a)
+        np.testing.assert_allclose(np.stack(env.get_attr("joint_pos")), obs[:, :6], rtol=0, atol=1e-6)
+        assert len(env.get_attr("joint_pos", indices=[1, 4])) == 2
+        snap = env.get_environment_state()
+        assert len(snap) == 6 and (snap[0][1] is None) == (env_id == "ReachHuman")
+        first = [env.step(a)[0] for a in acts[3:]]
+        env.set_environment_state(snap)
+        again = [env.step(a)[0] for a in acts[3:]]
+        for x, y in zip(first, again):
+            np.testing.assert_array_equal(x, y)
+        part = env.get_environment_state(indices=[2, 5])
+        env.set_environment_state(part, indices=[0, 1])           # envs 0, 1 continue as copies of 2, 5 (the states carry their random streams)
+        o = env.step(np.tile(acts[0][:1], (6, 1)))[0]              # the same action everywhere
+        np.testing.assert_array_equal(o[0], o[2]); np.testing.assert_array_equal(o[1], o[5])
+        env.close()

@@ -9,8 +9,9 @@ import human_robot_gym_amd as hrg  # noqa: E402
 from human_robot_gym_amd import mixed  # noqa: E402
 from human_robot_gym_amd._lib import HipBatch  # noqa: E402
 
-n, steps = 2048, 300
-for env_id, shield in (("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL")):
+n, steps = 4096, 600
+for env_id, shield in (("PickPlaceHumanCart", "SSM"), ("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL"),
+                       ("CollaborativeLiftingCart", "SSM")):
     clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600)
     d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31), n_clips=clips.n_clips, env_id=env_id)
     G = HipBatch(d, clips, n)
@@ -22,7 +23,7 @@ for env_id, shield in (("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandove
         a = (torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda()
         obs, r, dn, info = G.step(a)
         crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item()); wins += int((r > 0).sum().item())
-        if k % 50 == 49:
+        if k % 100 == 99:
             o = obs.cpu().numpy()
             bad += int((~np.isfinite(o)).sum())
             z = o[:, 49]
