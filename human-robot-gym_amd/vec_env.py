@@ -368,7 +368,7 @@ class HipVecEnv(_VecEnvBase):
             return [np.array(self._last_full[i, 18:24], np.float64) for i in idx]
         raise AttributeError(f"HipVecEnv has no per-env attribute {attr_name!r}")
 
-    # HumanEnv.get_environment_state / set_environment_state (human_env.py:588-627; used by the dataset / reference-state-initialisation wrappers):
+    # HumanEnv.get_environment_state / set_environment_state (human_env.py:1845-1900; used by the dataset / reference-state-initialisation wrappers):
     # the stepper's state blocks, batched.  Each entry is (hrg_env_state, hrg_box_state or None); a restored episode keeps its own random streams.
     def get_environment_state(self, indices=None):
         batch = getattr(self._backend, "batch", None)

@@ -188,7 +188,7 @@ def test_batched_state_io_reference_state_initialisation():
 
 @pytest.mark.gpu
 def test_vec_env_state_snapshots_and_joint_pos():
-    """HipVecEnv.get_environment_state / set_environment_state (HumanEnv.get/set_environment_state, human_env.py:588-627) and the
+    """HipVecEnv.get_environment_state / set_environment_state (HumanEnv.get/set_environment_state, human_env.py:1845-1900) and the
     `joint_pos` attribute the IK wrapper reads (ik_position_delta_wrapper.py:107): restoring a snapshot replays the same steps."""
     from human_robot_gym_amd.vec_env import HipVecEnv
     for env_id in ("ReachHuman", "PickPlaceHumanCart"):
