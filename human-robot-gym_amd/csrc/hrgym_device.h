@@ -433,6 +433,50 @@ DI double seg_box(PA p1, PB p2, PC c, PR R, const double* hb, double* on_seg, do
   }
   return e2;
 }
+
+// A capsule lying along a box face touches it in a stretch, not a point (MuJoCo's capsule-box generates two contacts there): kn = the box axis the
+// closest pair (cs on the capsule axis, cb on the box) is separated along; the stretch = the part of the axis whose other two box coordinates stay
+// inside the box.  Returns true with the axis / box point pair at end `which` of the stretch when both ends are closer than r and at least 1 mm apart.
+template <class PA, class PB, class PC, class PR>
+DI bool cap_box_two(PA p1, PB p2, PC c, PR R, const double* hb, double r, const double* cs, const double* cb, int which, double* s_out, double* b_out) {
+  double a[3], d[3], v[3], t0[3];
+  v3sub(t0, p1, c);
+  for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  v3sub(t0, p2, p1);
+  for (int k = 0; k < 3; k++) d[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  v3sub(t0, cs, cb);
+  for (int k = 0; k < 3; k++) v[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  int kn = 0;
+  for (int k = 1; k < 3; k++) if (fabs(v[k]) > fabs(v[kn])) kn = k;
+  double lo = 0, hi = 1;
+  bool ok = true;
+  for (int k = 0; k < 3; k++) {
+    if (k == kn) continue;
+    if (fabs(d[k]) < 1e-12) { if (fabs(a[k]) > hb[k]) ok = false; }
+    else {
+      double ta = (-hb[k] - a[k]) / d[k], tb = (hb[k] - a[k]) / d[k];
+      if (ta > tb) { const double t = ta; ta = tb; tb = t; }
+      if (ta > lo) lo = ta;
+      if (tb < hi) hi = tb;
+    }
+  }
+  if (!ok || !(hi > lo)) return false;
+  if ((hi - lo) * sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 1e-3) return false;
+  for (int e = 0; e < 2; e++) {
+    const double t = e ? hi : lo;
+    double x[3], y[3], e2 = 0;
+    for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb[k], hb[k]); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+    const double dd = sqrt(e2);
+    if (!(dd - r < 0) || !(dd > 1e-9)) return false;
+    if (e == which)
+      for (int k = 0; k < 3; k++) {
+        s_out[k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
+        b_out[k] = c[k] + R[3 * k] * y[0] + R[3 * k + 1] * y[1] + R[3 * k + 2] * y[2];
+      }
+  }
+  return true;
+}
+
 #endif
 
 // ------------------------------------------------------------------------------------------------ profiles

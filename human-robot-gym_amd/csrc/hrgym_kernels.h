@@ -748,14 +748,19 @@ HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out
     Contact c;
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
     const double hb[3] = {m.box_half[0], m.box_half[1], m.box_half[2]};
-    if (lane < HRG_NRCAP) {
-      const int i = lane;
+    if (lane < HRG_NRCAP || (lane >= 40 && lane < 40 + HRG_NRCAP)) {   // lanes 40..: the second contact of a capsule lying along a face (behind the corner contacts)
+      const bool second = lane >= 40;
+      const int i = second ? lane - 40 : lane;
       if (m.rcap_body[i] >= 0) {
         double cs[3], cb[3];
-        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, cs, cb), dd = sqrt(e2);
+        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, cs, cb);
+        double dd = sqrt(e2);
         double dist = dd - m.rcap_r[i];
         if (dist < 0) {
-          hit = true;
+          double s2[3], b2[3];
+          const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, m.rcap_r[i], cs, cb, second ? 1 : 0, s2, b2);
+          if (two) { v3cpy(cs, s2); v3cpy(cb, b2); double dv[3]; v3sub(dv, cb, cs); dd = v3norm(dv); dist = dd - m.rcap_r[i]; }
+          hit = two || !second;
           if (dd > 1e-9) { v3sub(c.n, cb, cs); v3scl(c.n, c.n, 1.0 / dd); }
           else { // capsule axis inside the cube: push out through the nearest face
             double loc[3], rel[3], best = 1e300;

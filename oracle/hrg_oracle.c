@@ -871,6 +871,47 @@ static double seg_box(const double* p1, const double* p2, const double* c, const
   return e2;
 }
 
+/* A capsule lying along a box face touches it in a stretch, not a point (MuJoCo's capsule-box generates two contacts there): kn = the box axis the
+ * closest pair (cs on the capsule axis, cb on the box) is separated along; the stretch = the part of the axis whose other two box coordinates stay
+ * inside the box.  Returns 1 with the axis / box point pairs at both ends of the stretch when both are closer than r and at least 1 mm apart. */
+static int cap_box_two(const double* p1, const double* p2, const double* c, const double* R, const double* hb, double r, const double* cs, const double* cb,
+                       double s2[2][3], double b2[2][3]) {
+  double a[3], d[3], v[3], t0[3];
+  v3sub(t0, p1, c);
+  for (int k = 0; k < 3; k++) a[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  v3sub(t0, p2, p1);
+  for (int k = 0; k < 3; k++) d[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  v3sub(t0, cs, cb);
+  for (int k = 0; k < 3; k++) v[k] = R[k] * t0[0] + R[3 + k] * t0[1] + R[6 + k] * t0[2];
+  int kn = 0;
+  for (int k = 1; k < 3; k++) if (fabs(v[k]) > fabs(v[kn])) kn = k;
+  double lo = 0, hi = 1;
+  for (int k = 0; k < 3; k++) {
+    if (k == kn) continue;
+    if (fabs(d[k]) < 1e-12) { if (fabs(a[k]) > hb[k]) return 0; }
+    else {
+      double ta = (-hb[k] - a[k]) / d[k], tb = (hb[k] - a[k]) / d[k];
+      if (ta > tb) { double t = ta; ta = tb; tb = t; }
+      if (ta > lo) lo = ta;
+      if (tb < hi) hi = tb;
+    }
+  }
+  if (!(hi > lo)) return 0;
+  if ((hi - lo) * sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 1e-3) return 0;
+  for (int e = 0; e < 2; e++) {
+    const double t = e ? hi : lo;
+    double x[3], y[3], e2 = 0;
+    for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb[k], hb[k]); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
+    const double dd = sqrt(e2);
+    if (!(dd - r < 0) || !(dd > 1e-9)) return 0;
+    for (int k = 0; k < 3; k++) {
+      s2[e][k] = c[k] + R[3 * k] * x[0] + R[3 * k + 1] * x[1] + R[3 * k + 2] * x[2];
+      b2[e][k] = c[k] + R[3 * k] * y[0] + R[3 * k + 1] * y[1] + R[3 * k + 2] * y[2];
+    }
+  }
+  return 1;
+}
+
 static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, const hrg_box_state* bx, contact_t* con) {
   double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3];
   double Rb[9];
@@ -926,11 +967,19 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
     double Rx[9];
     quat2mat(Rx, bx->quat);
     const double* hb = m->box_half;
+    int n_second = 0, second_i[HRG_NRCAP];
+    double second_s[HRG_NRCAP][3], second_b[HRG_NRCAP][3];
     for (int i = 0; i < HRG_NRCAP; i++) {
       if (m->rcap_body[i] < 0) continue;
-      double t, cs[3], cb[3], nn[3], pos[3];
+      double t, cs[3], cb[3], nn[3], pos[3], s2[2][3], b2[2][3];
       double e2 = seg_box(rp1[i], rp2[i], bx->pos, Rx, hb, &t, cs, cb), dd = sqrt(e2), dist = dd - m->rcap_r[i];
       if (!(dist < 0)) continue;
+      if (dd > 1e-9 && cap_box_two(rp1[i], rp2[i], bx->pos, Rx, hb, m->rcap_r[i], cs, cb, s2, b2)) { /* along a face: both ends of the stretch; the second
+                                                                                                       * one joins the contact list behind the corner contacts */
+        v3cpy(cs, s2[0]); v3cpy(cb, b2[0]);
+        v3sub(nn, cb, cs); dd = v3norm(nn); dist = dd - m->rcap_r[i];
+        second_i[n_second] = i; v3cpy(second_s[n_second], s2[1]); v3cpy(second_b[n_second], b2[1]); n_second++;
+      }
       if (dd > 1e-9) { v3sub(nn, cb, cs); v3scl(nn, nn, 1.0 / dd); }
       else { /* capsule axis inside the cube: push out through the nearest face */
         double loc[3], best = 1e300; int ax = 0;
@@ -955,6 +1004,15 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
           EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_BOX, -1, BODY_BOX, dist, nn, pos);
         }
       }
+    for (int q = 0; q < n_second; q++) {
+      const int i = second_i[q];
+      double nn[3], pos[3];
+      v3sub(nn, second_b[q], second_s[q]);
+      const double dd = v3norm(nn), dist = dd - m->rcap_r[i];
+      v3scl(nn, nn, 1.0 / dd);
+      v3madd(pos, second_s[q], nn, m->rcap_r[i] + 0.5 * dist);
+      EMIT(i, GEOM_BOX, m->rcap_body[i], BODY_BOX, dist, nn, pos);
+    }
   }
 #undef EMIT
   return n;
