@@ -10,7 +10,7 @@ import pytest
 import human_robot_gym_amd as hrg
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-from tools_cases import CASES  # noqa: E402
+from tools_cases import CASES, GPU_CASES  # noqa: E402
 
 
 from make_golden import clips_for as _clips  # noqa: E402
@@ -55,10 +55,13 @@ def test_oracle_reproduces_golden(name):
         p, nc = B.contacts()
         np.testing.assert_array_equal(nc, g["ncon"][k])
         np.testing.assert_array_equal(p, g["pairs"][k].astype(np.int32))
+        if "phase" in g:
+            bxs = [B.get_box(e) for e in range(n)]
+            np.testing.assert_array_equal(np.array([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs]), g["phase"][k])
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("name", sorted(CASES))
+@pytest.mark.parametrize("name", sorted(GPU_CASES))
 def test_hip_reproduces_golden(name):
     import torch
     from human_robot_gym_amd._lib import HipBatch
@@ -84,5 +87,8 @@ def test_hip_reproduces_golden(name):
         p, nc = B.contacts()
         np.testing.assert_array_equal(nc[live], g["ncon"][k][live])                                   # contact-pair indices bit-exact
         np.testing.assert_array_equal(p[live], g["pairs"][k].astype(np.int32)[live])
+        if "phase" in g:
+            bxs = [B.get_box(e) for e in range(n)]
+            np.testing.assert_array_equal(np.array([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs])[live], g["phase"][k][live])
     assert live.mean() >= 0.75
     B.close()

@@ -4,4 +4,4 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tools"))
-from make_golden import CASES  # noqa: E402,F401
+from make_golden import CASES, GPU_CASES  # noqa: E402,F401

@@ -22,12 +22,24 @@ CASES = {
     "contact_static": dict(shield_type="OFF", horizon=60, done_at_collision=False, collision_reward=-10),
     # PickPlaceHumanCart (BASELINE config 4 shape): the cube pops out of the table, rests, gets re-placed after a delivery
     "pick_place_ssm": dict(env_id="PickPlaceHumanCart", shield_type="SSM", reward_shaping=True, horizon=30),
+    # the collaboration tasks (short clips, so that their phase machines move within 40 steps); small arm actions keep them out of chaotic regimes
+    "inspection_ssm": dict(env_id="HumanObjectInspectionCart", shield_type="SSM", horizon=60),
+    "handover_h2r_pfl": dict(env_id="HumanRobotHandoverCart", shield_type="PFL", horizon=60),
+    "handover_r2h_pfl": dict(env_id="RobotHumanHandoverCart", shield_type="PFL", horizon=60),
+    "lifting_ssm": dict(env_id="CollaborativeLiftingCart", shield_type="SSM", horizon=60),
 }
+# cases whose free-running GPU rollout is compared against the fixture (tests/test_golden.py); the lifting task's finger / board contacts chatter,
+# its oracle <-> HIP parity is checked with re-synchronisation in tests/test_lifting.py
+GPU_CASES = [k for k in CASES if k != "lifting_ssm"]
 
 
 def clips_for(name):
     if name == "contact_static":  # T-pose human whose left hand is 0.3 m from the upright arm (collision scenario)
         return hrg.static_clip(600, pelvis=(-0.8, 1.0, 0.3))
+    env_id = CASES[name].get("env_id", "ReachHuman")
+    if env_id not in ("ReachHuman", "PickPlaceHumanCart"):
+        from human_robot_gym_amd.mixed import task_clips
+        return task_clips(env_id, 3, min_frames=120, max_frames=160)
     return hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
 
 
@@ -39,9 +51,11 @@ def run(name, kw, n_envs=8, n_steps=40, seed=11):
     B = OracleBatch(d, clips, n_envs)
     out = dict(obs0=B.reset())
     rng = np.random.RandomState(seed)
-    acts, obs, rew, done, info, qpos, qvel, ncon, pairs, box = [], [], [], [], [], [], [], [], [], []
+    acts, obs, rew, done, info, qpos, qvel, ncon, pairs, box, phase = [], [], [], [], [], [], [], [], [], [], []
     for k in range(n_steps):
         a = rng.uniform(-1, 1, (n_envs, 7))
+        if env_id not in ("ReachHuman", "PickPlaceHumanCart"):
+            a[:, :6] *= 0.2
         if env_id == "PickPlaceHumanCart" and k == 20:  # a delivery: cube teleported next to its target
             for e in range(n_envs):
                 bx = B.get_box(e)
@@ -58,13 +72,18 @@ def run(name, kw, n_envs=8, n_steps=40, seed=11):
         ncon.append(n); pairs.append(p)
         bxs = [B.get_box(e) for e in range(n_envs)]
         box.append([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs])
+        phase.append([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs])
+    out.update(phase=np.array(phase, np.int32))
     out.update(actions=np.array(acts), obs=np.array(obs), reward=np.array(rew), done=np.array(done), info=np.array(info),
                qpos=np.array(qpos), qvel=np.array(qvel), ncon=np.array(ncon), pairs=np.array(pairs).astype(np.int8), box=np.array(box))
     return out
 
 
 if __name__ == "__main__":
+    only = sys.argv[1:]
     for name, kw in CASES.items():
+        if only and name not in only:
+            continue
         out = run(name, kw, n_steps=24 if name == "contact_static" else 40)
         np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"{name}.npz"), **out)
         print(name, {k: v.shape for k, v in out.items()}, "dones", int(out["done"].sum()), "failsafe", int(out["info"][-1, :, 8].sum()))
