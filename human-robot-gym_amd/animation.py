@@ -135,7 +135,7 @@ def hand_sites(frames, info):
     return out[0], out[1]
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None):
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None, lift_height=0.7):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -159,11 +159,11 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         yaw = band(0.4, 0.2)
         anim["Pelvis_quat"] = np.stack([np.zeros(n), np.sin(yaw / 2), np.zeros(n), np.cos(yaw / 2)], 1)  # about Y (up)
         for name in order:
-            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else (0.05 if lifting is not None else 0.3)  # convert_bvh.py:55-72 None joints
+            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else (0.0 if lifting is not None else 0.3)  # convert_bvh.py:55-72 None joints (lifting: a rigid posture, the motion is the pelvis track)
             mean = {"L_Shoulder_z": -1.1, "R_Shoulder_z": 1.1}.get(name, 0.0)  # arms hang down instead of the T-pose
             if lifting is not None:  # ... and a little closer: the hands half a metre apart, like the board's grips
                 mean = {"L_Shoulder_z": -1.43, "R_Shoulder_z": 1.43}.get(name, 0.0)
-            anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.zeros(n)
+            anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.full(n, mean if lifting is not None else 0.0)
         # the clip's info file places the human at the table edge in front of the robot: BVH +z maps to world +x
         # under human_base_quat (human_env.py:373), so 1.2 m along z = 1.2 m in front of the robot base
         info = {"position_offset": [0.0, 0.0, stand_off], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
@@ -180,8 +180,8 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         if lifting is not None:
             # stand-in for the CollaborativeLifting/* recordings: a human facing the robot who raises and lowers the far end of the board.
             # `lifting` = world position of the middle between the two hands at the first frame (where the board's grips are at a reset);
-            # the pelvis track is shifted frame by frame so that the middle of the hands follows a smooth lift of up to 25 cm with a
-            # little sideways sway, while the (small) arm motion tilts the board
+            # the pelvis track is shifted frame by frame so that the middle of the hands follows a smooth lift of 60-70 cm with a
+            # little sideways sway; the posture itself is rigid and symmetric, so the hands stay level and half a metre apart
             anim["Pelvis_quat"] = np.tile(np.array([0.0, 1.0, 0.0, 0.0]), (n, 1))   # half a turn about the vertical: facing the robot, left hand at -y
             F = np.zeros((n, FRAME_DIM))
             F[:, 0], F[:, 1], F[:, 2] = anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"]
@@ -190,7 +190,7 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
                 F[:, 7 + k] = anim[name]
             lh, rh = hand_sites(F, info)
             u = t / t[-1]
-            lift = 0.25 * np.sin(np.pi * u) ** 2 * rng.uniform(0.5, 1.0)
+            lift = lift_height * np.sin(np.pi * u) ** 2 * rng.uniform(0.85, 1.0)   # default 0.6-0.7 m: a robot that does not follow tips the board past min_balance
             sway = 0.04 * np.sin(2 * np.pi * u * rng.uniform(0.5, 1.5))
             want = np.asarray(lifting, float)[None, :] + np.stack([0.0 * u, sway, lift], 1)
             Rb = _quat_xyzw_to_mat(np.array([0.5, 0.5, 0.5, 0.5])) @ _quat_xyzw_to_mat(np.asarray(info["orientation_quat"], float))
