@@ -213,3 +213,33 @@ def test_vec_env_state_snapshots_and_joint_pos():
         o = env.step(np.tile(acts[0][:1], (6, 1)))[0]              # the same action everywhere
         np.testing.assert_array_equal(o[0], o[2]); np.testing.assert_array_equal(o[1], o[5])
         env.close()
+
+
+@pytest.mark.gpu
+def test_batch_sizes_from_one_env_to_65536():
+    """Edge sizes: a single env, a ragged count (not a multiple of anything), and 65 536 envs (16 x the benchmark batch) run the same episodes as the
+    corresponding rows of a 64-env batch; a batch of zero envs is refused."""
+    import torch
+    from human_robot_gym_amd._lib import HipBatch, HrgError
+    kw = dict(shield_type="SSM", horizon=20, reward_shaping=True, seed=12)
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=200, max_frames=300)
+    mk = lambda n: HipBatch(hrg.build_model_desc(kw, n_clips=3), clips, n)  # noqa: E731
+    with pytest.raises(HrgError):
+        mk(0)
+    ref, one, ragged, big = mk(64), mk(1), mk(37), mk(65536)
+    gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+    o = ref.reset().clone()
+    torch.testing.assert_close(one.reset(), o[:1], rtol=0, atol=0)
+    torch.testing.assert_close(ragged.reset(), o[:37], rtol=0, atol=0)
+    torch.testing.assert_close(big.reset()[:64], o, rtol=0, atol=0)
+    for k in range(6):
+        a = torch.rand((65536, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        ref.step(a[:64].clone()); one.step(a[:1].clone()); ragged.step(a[:37].clone()); big.step(a)
+        torch.cuda.synchronize()
+        for name in ("obs", "reward", "done", "info"):
+            torch.testing.assert_close(getattr(one, name), getattr(ref, name)[:1], rtol=0, atol=0)
+            torch.testing.assert_close(getattr(ragged, name), getattr(ref, name)[:37], rtol=0, atol=0)
+            torch.testing.assert_close(getattr(big, name)[:64], getattr(ref, name), rtol=0, atol=0)
+        assert torch.isfinite(big.obs).all() and torch.isfinite(big.reward).all()
+    for x in (ref, one, ragged, big):
+        x.close()
