@@ -266,3 +266,35 @@ def test_a_following_robot_carries_the_board_through_and_a_resting_one_tips_it()
         B.close()
     assert outcome[True][0] >= 6 and outcome[True][1] == 0 and outcome[True][2] > 0.9, outcome
     assert outcome[False][0] == 0 and outcome[False][1] >= 6, outcome
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_through_success_and_the_next_task():
+    """done_at_success=False: when the animation completes, _on_goal_reached puts the robot back to its initial posture, resets the controller / shield
+    memory, starts the next animation and puts the board back into the gripper, inside the same episode."""
+    import torch
+    from helpers import ATOL, RTOL, assert_state_close, make_pair
+    nominal = lifting_hands_nominal(hrg.build_model_desc(None, env_id=ENV))
+    clips = hrg.synthetic_clips(3, fps=20.0, lifting=nominal, lift_height=0.1, min_frames=20, max_frames=26)
+    O, G = make_pair(4, dict(seed=5, horizon=200, done_at_success=False, shield_type="SSM"), clips=clips, env_id=ENV)
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    rng = np.random.RandomState(1)
+    goals = 0
+    for k in range(45):
+        a = rng.uniform(-0.2, 0.2, (4, 7))
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        goals = max(goals, int(i_o[:, 9].max()))
+        for e in range(4):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+            assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
+            if k % 4 == 3:
+                G.set_state(e, O.get_state(e))
+                G.set_box(e, O.get_box(e))
+    assert goals >= 2          # several tasks in a row within one episode
+    O.close(); G.close()
