@@ -298,3 +298,38 @@ def test_hip_matches_oracle_through_success_and_the_next_task():
                 G.set_box(e, O.get_box(e))
     assert goals >= 2          # several tasks in a row within one episode
     O.close(); G.close()
+
+
+@pytest.mark.gpu
+def test_hip_matches_oracle_with_cartesian_actions_and_the_follower():
+    """The IK front-end + collision prevention in front of the lifting task (config/wrappers/safe_ik.yaml), driven by the scripted follower."""
+    import torch
+    from helpers import ATOL, RTOL, assert_state_close, make_pair
+    clips = _clips(2, 100, 130)
+    O, G = make_pair(4, dict(seed=7, horizon=200), clips=clips, env_id=ENV, ik_position_delta=dict(action_limit=0.15),
+                     collision_prevention=dict(replace_type=0, n_resamples=20))
+    obs = O.reset()
+    np.testing.assert_allclose(G.reset().cpu().numpy(), obs, rtol=RTOL, atol=ATOL)
+    held = 0
+    for k in range(48):
+        mid = 0.5 * (obs[:, 0:3] + obs[:, 4:7])
+        a = np.zeros((4, 7))
+        a[:, 0], a[:, 1], a[:, 2] = np.clip(mid[:, 0] - 0.95, -0.15, 0.15), np.clip(mid[:, 1], -0.15, 0.15), np.clip(1.5 * mid[:, 2], -0.15, 0.15)
+        ag = torch.from_numpy(a.copy()).cuda()
+        obs, r_o, d_o, i_o = O.step(a)                       # (both rewrite the action rows in place with the executed joint action)
+        o_g, r_g, d_g, i_g = G.step(ag)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(ag.cpu().numpy(), a, rtol=1e-6, atol=1e-9, err_msg=f"executed action, step {k}")
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), obs, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=2e-6, err_msg=f"step {k}")
+        held += int(O.term_obs[:, 39].sum())
+        for e in range(4):
+            assert_state_close(O.get_state(e), G.get_state(e), f"step {k} env {e}")
+            assert_state_close(O.get_box(e), G.get_box(e), f"step {k} env {e} box")
+            if k % 4 == 3:
+                G.set_state(e, O.get_state(e))
+                G.set_box(e, O.get_box(e))
+    assert held > 4 * 30
+    O.close(); G.close()
