@@ -20,6 +20,7 @@ EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
     "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box", "hrg_batch_get_states", "hrg_batch_set_states",
+    "hrg_batch_check_actions",
 ]
 
 
@@ -67,6 +68,7 @@ def load_library():
     lib.hrg_batch_get_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_enable_taps.argtypes = [vp, i32]
+    lib.hrg_batch_check_actions.argtypes = [vp, vp, vp, vp]
     lib.hrg_batch_kernel_time.argtypes = [vp, ctypes.POINTER(ctypes.c_double), ctypes.POINTER(i64)]
     if lib.hrg_state_bytes() != ctypes.sizeof(EnvState):
         raise RuntimeError("hrg_env_state layout mismatch between header mirror and library: rebuild")
@@ -157,6 +159,20 @@ class HipBatch:
                                                    vp(self.reward.data_ptr()), vp(self.done.data_ptr()), vp(self.info.data_ptr()), self._stream()))
         self._keep = actions
         return self.obs, self.reward, self.done, self.info
+
+    def check_actions(self, actions):
+        """HumanEnv.check_collision_action for the whole batch: uint8 tensor [n], 1 where the joint-space action's goal configuration collides
+        with the static scene or the robot itself (nothing is stepped)."""
+        t = self.torch
+        if actions.dtype != t.float64 or actions.device != self.device or not actions.is_contiguous():
+            actions = actions.to(device=self.device, dtype=t.float64).contiguous()
+        if tuple(actions.shape) != (self.n, CONST["HRG_ACT_DIM"]):
+            raise ValueError(f"actions must be [{self.n}, {CONST['HRG_ACT_DIM']}]")
+        out = t.empty(self.n, dtype=t.uint8, device=self.device)
+        with t.cuda.device(self.device):
+            _check(self.lib, self.lib.hrg_batch_check_actions(self.h, ctypes.c_void_p(actions.data_ptr()), ctypes.c_void_p(out.data_ptr()), self._stream()))
+        self._keep_chk = actions
+        return out
 
     def get_state(self, e):
         s = EnvState()

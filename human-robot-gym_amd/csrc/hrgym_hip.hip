@@ -1413,6 +1413,26 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const D
 #endif
 }
 
+#if !HRG_BOX
+// HumanEnv.check_collision_action for every env: goal configuration of the action at the env's current joint angles -> pre-check capsule model.
+// The check reads the robot part of the state only, so one kernel serves every task.
+__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
+                                                                          uint8_t* __restrict__ collides) {
+  Lds& L = g_L;
+  const int e = blockIdx.x, lane = threadIdx.x;
+  const double* src = (const double*)(states + e);
+  double* dst = (double*)&L.st;
+  constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
+  for (int k = lane; k < NW; k += 64) dst[k] = src[k];
+  if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? actions[(size_t)e * HRG_ACT_DIM + lane] : 0.0;
+  wave_sync();
+  const ModelPtr dm = uniform_model(dm_);
+  action_goal(dm, lane, L.act);
+  const bool hit = config_collides(dm_, lane);
+  if (lane == 0) collides[e] = hit ? 1 : 0;
+}
+#endif
+
 // launch shims of the cube variant: defined by hrgym_box.hip (this file compiled with HRG_BOX=1), called by the host side below
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                            float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -1656,6 +1676,13 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  HIPCHK(hipGetLastError());
+  return HRG_OK;
+}
+
+int hrg_batch_check_actions(hrg_batch* b, const double* actions_dev, uint8_t* collides_dev, void* stream) {
+  if (!b || !actions_dev || !collides_dev) return fail(HRG_ERR_INVALID, "null argument");
+  hipLaunchKernelGGL(hrg_check_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, actions_dev, collides_dev);
   HIPCHK(hipGetLastError());
   return HRG_OK;
 }

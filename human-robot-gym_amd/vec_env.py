@@ -392,6 +392,16 @@ class HipVecEnv(_VecEnvBase):
         bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and self.env_id != "ReachHuman" else None
         batch.set_states(np.asarray(idx, np.int32), st_arr, bx_arr)
 
+    def check_collision_action(self, actions):
+        """HumanEnv.check_collision_action (human_env.py:588-627) for every env: bool array, True where the joint-space action would drive the robot
+        into the static scene or itself.  Nothing is stepped."""
+        batch = getattr(self._backend, "batch", None)
+        if batch is None or not hasattr(batch, "check_actions"):
+            raise NotImplementedError("check_collision_action needs the HIP batch backend")
+        a = np.asarray(actions, np.float64).reshape(self.num_envs, CONST["HRG_ACT_DIM"])
+        import torch
+        return batch.check_actions(torch.from_numpy(np.ascontiguousarray(a))).cpu().numpy().astype(bool)
+
     def set_attr(self, attr_name, value, indices=None):
         raise NotImplementedError("per-env attributes are fixed at construction (hrg_model_desc)")
 
@@ -427,6 +437,11 @@ class HipVecEnv(_VecEnvBase):
         return float(r[0]) if isinstance(info, dict) and np.ndim(achieved_goal) == 1 else r.astype(np.float32)
 
     def env_method(self, method_name, *method_args, indices=None, **method_kwargs):
+        if method_name == "check_collision_action":   # per-env call of the reference: env_method("check_collision_action", action, indices=[i])
+            idx = self._indices(indices)
+            acts = np.zeros((self.num_envs, CONST["HRG_ACT_DIM"]))
+            acts[idx] = np.asarray(method_args[0], np.float64)
+            return [bool(x) for x in self.check_collision_action(acts)[idx]]
         if method_name == "compute_reward":   # SB3 HerReplayBuffer: env_method("compute_reward", achieved, desired, infos, indices=[0])
             return [self.compute_reward(*method_args, **method_kwargs) for _ in self._indices(indices)]
         raise NotImplementedError(f"env_method({method_name!r}) is not available on the batched stepper")

@@ -348,6 +348,12 @@ size_t hrg_box_bytes(void);
 int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 
+/* HumanEnv.check_collision_action (human_env.py:588-627; called by CollisionPreventionWrapper, wrappers/collision_prevention_wrapper.py:38-51, and
+ * utils/training_utils.py:362-366): would the joint-space action drive the robot into the static scene or itself?  The goal configuration the
+ * controller would set for each env (current joint angles + scaled action, clipped to the joint limits) is tested with the pre-check capsule
+ * model; nothing is stepped.  actions: device, [n_envs][HRG_ACT_DIM] f64 (not modified); collides: device, [n_envs] u8 (1 = collision). */
+int hrg_batch_check_actions(hrg_batch* b, const double* actions_dev, uint8_t* collides_dev, void* hip_stream);
+
 /* Kernel timing hook for bench.py: records HIP events on the launch stream around every step kernel
  * since the last call; returns average kernel milliseconds and the number of launches measured. */
 int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches);

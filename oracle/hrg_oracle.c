@@ -2053,6 +2053,11 @@ int hrgo_set_box(hrgo_batch* B, int e, const void* buf, size_t bytes) {
 size_t hrgo_state_bytes(void) { return sizeof(hrg_env_state); }
 size_t hrgo_box_bytes(void) { return sizeof(hrg_box_state); }
 size_t hrgo_desc_bytes(void) { return sizeof(hrg_model_desc); }
+/* HumanEnv.check_collision_action for every env (human_env.py:588-627): goal configuration of the action at the current joint angles -> pre-check model */
+int hrgo_check_actions(hrgo_batch* B, const double* actions, uint8_t* collides) {
+  for (int e = 0; e < B->n_envs; e++) collides[e] = (uint8_t)(action_collides(&B->m, &B->st[e], actions + (size_t)e * HRG_ACT_DIM) != 0);
+  return 0;
+}
 int hrgo_contacts(hrgo_batch* B, int32_t* pairs, int32_t* ncon) {
   for (int e = 0; e < B->n_envs; e++) {
     ncon[e] = B->st[e].ncon;

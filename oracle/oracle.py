@@ -91,6 +91,12 @@ class OracleBatch:
     def set_box(self, e, s):
         assert self.lib.hrgo_set_box(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
 
+    def check_actions(self, actions):
+        a = np.ascontiguousarray(actions, np.float64)
+        out = np.zeros(self.n, np.uint8)
+        self.lib.hrgo_check_actions(self.h, _p(a), _p(out))
+        return out
+
     def contacts(self):
         pairs = np.zeros((self.n, self.C["HRG_NCON_MAX"], 2), np.int32)
         ncon = np.zeros(self.n, np.int32)

@@ -106,3 +106,34 @@ def test_hip_matches_oracle_with_collision_prevention(replace_type):
         tot += int(i_o[:, 12].max())
     assert tot > 0
     O.close(); G.close()
+
+
+@pytest.mark.gpu
+def test_batched_check_collision_action_matches_the_oracle():
+    """hrg_batch_check_actions = HumanEnv.check_collision_action (human_env.py:588-627) for every env at its current joint angles."""
+    import torch
+    from helpers import make_pair
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    O, G = make_pair(256, dict(shield_type="OFF", horizon=50, seed=3))
+    O.reset(); G.reset()
+    rng = np.random.RandomState(0)
+    for e in range(0, 256, 2):                                    # every other env close to the folded-over posture that meets the table
+        st = O.get_state(e)
+        for j, q in enumerate([0.0, 1.65, -0.75, 0.0, 0.0, 0.0] + rng.uniform(-0.1, 0.1, 6) * np.array([1, 1, 1, 1, 1, 1])):
+            st.qpos[j] = float(q)
+        O.set_state(e, st); G.set_state(e, st)
+    hits = 0
+    for k in range(6):
+        probe = rng.uniform(-1, 1, (256, 7)) * 3.0                # (clipped to [-1, 1] by the controller's input scaling)
+        co, cg = O.check_actions(probe), G.check_actions(torch.from_numpy(probe).cuda()).cpu().numpy()
+        np.testing.assert_array_equal(cg, co, err_msg=f"step {k}")
+        hits += int(co.sum())
+    assert 100 < hits < 6 * 200                                   # goal configurations near the table collide, the ones from the initial posture do not
+    O.close(); G.close()
+    env = HipVecEnv(8, env_kwargs=dict(seed=1))
+    env.reset()
+    acts = rng.uniform(-1, 1, (8, 7))
+    flags = env.check_collision_action(acts)
+    assert flags.dtype == bool and flags.shape == (8,)
+    assert env.env_method("check_collision_action", acts[3], indices=[3]) == [bool(flags[3])]
+    env.close()
