@@ -945,6 +945,34 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   wave_sync();
 }
 
+#if HRG_HANDOVER
+// end of the handover tasks' first physics pass: time, grip site, the hand mocap body re-posed (_update_mocap_body_transform, 609-633), then the robot
+// terms of sim.forward() for the second pass.  A real function: its temporaries stay out of the cycle body's register allocation.
+__device__ __noinline__ void handover_first_pass_tail(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+      s.time = s.time + m.timestep;
+  eef_update(dm_);
+  const int hl = dm->clips.clip_holding_hand[clip_of(dm, gid, s.episode, s.anim_index)];
+  const int site = hl ? m.site_lhand : m.site_rhand;
+  wave_sync();
+  if (lane < 3) {
+    const double mp = s.human_site[site][lane] + L.hand_off[lane];
+    L.bx.mocap_pos[lane] = mp;
+    if (m.task == HRG_TASK_HANDOVER_R2H) L.bx.target[lane] = mp;   // target_pos property: the hand the object has to reach (448-450)
+  }
+  if (lane < 4) L.bx.mocap_quat[lane] = L.hand_q[lane];
+  wave_sync();
+  robot_chain_fk(dm_, lane, false);
+  robot_dynamics_terms(dm_, lane);
+  // the human capsules share their LDS with the solver scratch of the step above: lay them out again for the second collision phase
+  for (int k = lane; k < HRG_NHB * 6; k += 64) (&L.hcap[0][0])[k] = (&L.hcap_keep[0][0])[k];
+  wave_sync();
+}
+#endif
+
 // one shield cycle (human_env.py:503-526): controller goal on policy steps, shield, dynamics terms, PD+ torque,
 // human playback, contacts, integration.  Returns 1 when the simulation diverged.
 #if HRG_CYCLEFN
@@ -1029,23 +1057,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
     crash = dynamics_step(dm_, lane, ncon);
     STAMP(7);
     if (pass == 0 && !crash) {
-      s.time = s.time + m.timestep;
-      eef_update(dm_);
-      const int hl = dm->clips.clip_holding_hand[clip_of(dm, gid, s.episode, s.anim_index)];
-      const int site = hl ? m.site_lhand : m.site_rhand;
-      wave_sync();
-      if (lane < 3) {
-        const double mp = s.human_site[site][lane] + L.hand_off[lane];
-        L.bx.mocap_pos[lane] = mp;
-        if (m.task == HRG_TASK_HANDOVER_R2H) L.bx.target[lane] = mp;   // target_pos property: the hand the object has to reach (448-450)
-      }
-      if (lane < 4) L.bx.mocap_quat[lane] = L.hand_q[lane];
-      wave_sync();
-      robot_chain_fk(dm_, lane, false);
-      robot_dynamics_terms(dm_, lane);
-      // the human capsules share their LDS with the solver scratch of the step above: lay them out again for the second collision phase
-      for (int k = lane; k < HRG_NHB * 6; k += 64) (&L.hcap[0][0])[k] = (&L.hcap_keep[0][0])[k];
-      wave_sync();
+      handover_first_pass_tail(dm_, lane, gid);
       STAMP(27);
     }
   }
