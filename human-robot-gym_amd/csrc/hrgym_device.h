@@ -74,6 +74,40 @@
 #else
 #define HRG_BIGPHASE HRG_PHASE
 #endif
+// tuning experiments: HRG_NI_MASK makes single phases real functions (1 dynamics terms, 2 human, 4 shield, 8 collide, 16 classify, 32 dynamics step)
+#ifndef HRG_NI_MASK
+#define HRG_NI_MASK 0
+#endif
+#if (HRG_NI_MASK) & 1
+#define PH_DYNTERMS __device__ __noinline__
+#else
+#define PH_DYNTERMS HRG_PHASE
+#endif
+#if (HRG_NI_MASK) & 2
+#define PH_HUMAN __device__ __noinline__
+#else
+#define PH_HUMAN HRG_BIGPHASE
+#endif
+#if (HRG_NI_MASK) & 4
+#define PH_SHIELD __device__ __noinline__
+#else
+#define PH_SHIELD HRG_BIGPHASE
+#endif
+#if (HRG_NI_MASK) & 8
+#define PH_COLLIDE __device__ __noinline__
+#else
+#define PH_COLLIDE HRG_PHASE
+#endif
+#if (HRG_NI_MASK) & 16
+#define PH_CLASSIFY __device__ __noinline__
+#else
+#define PH_CLASSIFY HRG_PHASE
+#endif
+#if (HRG_NI_MASK) & 32
+#define PH_DYNSTEP __device__ __noinline__
+#else
+#define PH_DYNSTEP HRG_BIGPHASE
+#endif
 #define HRG_PI 3.14159265358979323846
 #define SIXTH (1.0 / 6.0)   // cubic term of the constant-jerk profiles: a product, not an FP64 division per segment
 

@@ -61,7 +61,7 @@ DI double box_Mrow(double mass, int a, const double* v) {
   return L.bMr[r + (a - 3)] * v[a] + L.bMr[r + (a - 2) % 3] * v[3 + (a - 2) % 3] + L.bMr[r + (a - 1) % 3] * v[3 + (a - 1) % 3];
 }
 #endif
-HRG_BIGPHASE int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
+PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;

@@ -79,7 +79,7 @@ DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_o
 //   lane = body k : composite inertia and joint force = sums over the descendants of k
 //   lane = (i,j)  : M_ij = S_i . (Ic_j S_j)
 // -> three hand-offs through LDS, no serial LDS read-modify-write chains.
-HRG_PHASE void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) {
+PH_DYNTERMS void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -324,7 +324,7 @@ DI double layered_sines(ModelPtr dm, int64_t gid, int episode, int ai, int clip,
 }
 #endif
 
-HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+PH_HUMAN void human_control(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -427,7 +427,7 @@ HRG_BIGPHASE void human_control(const DevModel* __restrict__ dm_, int lane, int6
 // SafetyShield.humanMeasurement + step (controllers/failsafe_controller/failsafe_controller/failsafe_controller.py:310,329),
 // restated as in oracle/hrg_oracle.c: candidate = one recovery step + fail-safe brake; robot reach capsules;
 // human reach capsules (ACC/VEL/POS) on lanes; swept-capsule test lanes x 7 robot capsules; __ballot verdict.
-HRG_BIGPHASE void shield_step(const DevModel* __restrict__ dm_, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
+PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, double* __restrict__ dbg_r, double* __restrict__ dbg_h, int32_t* __restrict__ dbg_nh) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -625,7 +625,7 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 
 // ================================================================================================ contacts
 // Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
-HRG_PHASE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out) {
+PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -828,7 +828,7 @@ DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TAB
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
-HRG_PHASE void classify(const DevModel* __restrict__ dm_, int ncon, int* has_collision, int* collision_type) {
+PH_CLASSIFY void classify(const DevModel* __restrict__ dm_, int ncon, int* has_collision, int* collision_type) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
