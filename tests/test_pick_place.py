@@ -280,3 +280,34 @@ def test_box_object_with_three_different_edges():
         ax = int(np.argmax(np.abs(R[2])))
         assert abs(abs(R[2, ax]) - 1) < 1e-3 and abs(bx.pos[2] - (d.table_top_z + h[ax])) < 1e-3 and max(abs(v) for v in bx.vel) < 0.05
     B.close()
+
+
+def test_scripted_expert_picks_the_cube_up_and_delivers_it():
+    """The task end to end through the Cartesian front-end (IKPositionDeltaWrapper actions [dx, dy, dz, gripper]): hover over the cube, descend,
+    close, carry it to the target (experts/pick_place_human_cart_expert.py plays this role in the reference).  With the stand-in gripper's two
+    point contacts per finger and MuJoCo's default friction about half of the carries lose the cube; the deliveries that get through pay the
+    task reward and the next object / target are drawn."""
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=600, max_frames=900)
+    d = hrg.build_model_desc(dict(seed=4, horizon=300, shield_type="OFF"), n_clips=clips.n_clips, ik_position_delta=dict(action_limit=0.15), **PP)
+    n = 6
+    B = OracleBatch(d, clips, n)
+    obs = B.reset()
+    wins, grip_steps, paid = np.zeros(n, int), 0, 0
+    for k in range(250):
+        v_obj, v_tgt, gr = obs[:, 40:43].astype(float), obs[:, 43:46].astype(float), obs[:, 39] != 0
+        a = np.zeros((n, 7))
+        for e in range(n):
+            if not gr[e]:
+                over = np.linalg.norm(v_obj[e, :2]) <= 0.012
+                tgt = np.array([v_obj[e, 0], v_obj[e, 1], v_obj[e, 2] + (0.0 if over else 0.08)])
+                g = 1.0 if over and abs(v_obj[e, 2]) < 0.02 else -1.0            # the fingertips reach the table 1.6 cm before the grip site reaches the cube's centre
+            else:
+                far = np.linalg.norm(v_tgt[e, :2]) > 0.03
+                tgt, g = np.array([v_tgt[e, 0], v_tgt[e, 1], max(v_tgt[e, 2] + 0.06, 0.0) if far else v_tgt[e, 2] + 0.03]), 1.0
+            a[e, :3], a[e, 3] = np.clip(tgt, -0.05, 0.05), g
+        obs, r, dn, info = B.step(a)
+        assert not info[:, 11].any()
+        paid += int((r > 0).sum())
+        wins, grip_steps = np.maximum(wins, info[:, 9]), grip_steps + int(gr.sum())
+    assert (wins >= 1).sum() >= 3 and paid >= 3 and grip_steps > 300, (wins, paid, grip_steps)
+    B.close()
