@@ -864,7 +864,7 @@ DI void lifting_place_board(const DevModel* __restrict__ dm_, int lane) {
   const auto& m = dm->m;
   hrg_box_state& bx = L.bx;
   double Re[9], Rb[9], q[4], xb[3], yb[3], zb[3], ze[3], pos[3];
-  for (int a = 0; a < 9; a++) Re[a] = L.kR[NARM - 1][a];
+  for (int a = 0; a < 9; a++) Re[a] = L.kR[NARM][a];   // a finger body's frame = the hand frame (right_hand is turned -45 deg about link 6's axis): y = closing axis
   const double sg = Re[7] >= 0 ? 1.0 : -1.0;
   for (int a = 0; a < 3; a++) { ze[a] = Re[3 * a + 2]; xb[a] = -ze[a]; zb[a] = sg * Re[3 * a + 1]; }
   v3cross(yb, zb, xb);

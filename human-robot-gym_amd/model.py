@@ -561,9 +561,8 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
             d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])
         # UniformRandomSampler: z = reference_pos[2] (0.8) + z_offset - bottom_offset (= -half edge) [UPSTREAM robosuite]
         if lifting:
-            # _reset_internal (673): the Schunk posture whose gripper straddles the board edge; the stand-in gripper closes along its own y axis, so
-            # the last joint is turned until that axis is vertical (-pi/2 instead of -pi/4)
-            d.init_qpos[:] = [0.0, math.pi * 19 / 48, -math.pi / 2 - 5 * math.pi / 48, 0.0, math.pi / 2, -math.pi / 2]
+            # _reset_internal (673): the Schunk posture whose gripper straddles the board edge (the hand frame's closing axis is vertical there)
+            d.init_qpos[:] = [0.0, math.pi * 19 / 48, -math.pi / 2 - 5 * math.pi / 48, 0.0, math.pi / 2, -math.pi / 4]
             for hd in range(2):
                 d.lift_anchor[hd][:] = [float(x) for x in kw["lift_anchors"][hd]]
             d.lift_grip_depth = 0.0

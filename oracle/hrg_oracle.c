@@ -1475,7 +1475,7 @@ static void mat2quat(double* q, const double* R) {
  * board centre back to the robot (-gripper axis), board normal = the finger closing axis turned upwards, robot-side edge lift_grip_depth past
  * the grip site.  At rest, no warm start. */
 static void lifting_place_board(const hrg_model_desc* m, const robot_kin* k, const double* eef, hrg_box_state* bx) {
-  const double* Re = k->R[NARM - 1];
+  const double* Re = k->R[NARM]; /* a finger body's frame = the hand frame (right_hand is turned -45 deg about link 6's axis, robot.xml:61): y = closing axis, z = gripper axis */
   double ze[3] = {Re[2], Re[5], Re[8]}, ye[3] = {Re[1], Re[4], Re[7]}, xb[3], yb[3], zb[3], Rb[9];
   const double sg = ye[2] >= 0 ? 1.0 : -1.0;
   for (int a = 0; a < 3; a++) { xb[a] = -ze[a]; zb[a] = sg * ye[a]; }

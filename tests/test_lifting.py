@@ -30,7 +30,7 @@ def test_desc_follows_the_reference_defaults():
     assert list(d.box_half) == [0.5, 0.2, 0.015] and abs(d.box_mass - 20 * 1.0 * 0.4 * 0.03) < 1e-12   # board_full_size, density 20 (755-760)
     assert d.min_balance == 0.8 and d.imbalance_failure_reward == -10 and d.board_released_reward == -10 and d.reward_shaping == 1
     assert [list(a) for a in d.lift_anchor] == [[-0.45, 0.25, 0.0], [-0.45, -0.25, 0.0]]          # _postprocess_model, 786-795
-    assert abs(d.init_qpos[1] - math.pi * 19 / 48) < 1e-15 and abs(d.init_qpos[2] + math.pi / 2 + 5 * math.pi / 48) < 1e-15   # _reset_internal, 673
+    assert np.allclose(list(d.init_qpos), [0, math.pi * 19 / 48, -math.pi / 2 - 5 * math.pi / 48, 0, math.pi / 2, -math.pi / 4], atol=1e-15)   # _reset_internal, 673
 
 
 def test_synthetic_lifting_clips_put_the_hands_at_the_board_grips():
