@@ -284,11 +284,10 @@ def test_box_object_with_three_different_edges():
 
 def test_scripted_expert_picks_the_cube_up_and_delivers_it():
     """The task end to end through the Cartesian front-end (IKPositionDeltaWrapper actions [dx, dy, dz, gripper]): hover over the cube, descend,
-    close, carry it to the target (experts/pick_place_human_cart_expert.py plays this role in the reference).  With the stand-in gripper's two
-    point contacts per finger and MuJoCo's default friction about half of the carries lose the cube; the deliveries that get through pay the
-    task reward and the next object / target are drawn."""
-    clips = hrg.synthetic_clips(2, seed=0, min_frames=600, max_frames=900)
-    d = hrg.build_model_desc(dict(seed=4, horizon=300, shield_type="OFF"), n_clips=clips.n_clips, ik_position_delta=dict(action_limit=0.15), **PP)
+    close, carry it to the target (experts/pick_place_human_cart_expert.py plays this role in the reference).  With the human standing out of
+    the way every env delivers its cube: the task reward is paid and the next object / target are drawn."""
+    clips = hrg.static_clip(900, pelvis=(0.0, 1.0, 2.5))                          # 2.5 m in front of the robot
+    d = hrg.build_model_desc(dict(seed=4, horizon=300, shield_type="SSM"), n_clips=clips.n_clips, ik_position_delta=dict(action_limit=0.15), **PP)
     n = 6
     B = OracleBatch(d, clips, n)
     obs = B.reset()
@@ -306,8 +305,8 @@ def test_scripted_expert_picks_the_cube_up_and_delivers_it():
                 tgt, g = np.array([v_tgt[e, 0], v_tgt[e, 1], max(v_tgt[e, 2] + 0.06, 0.0) if far else v_tgt[e, 2] + 0.03]), 1.0
             a[e, :3], a[e, 3] = np.clip(tgt, -0.05, 0.05), g
         obs, r, dn, info = B.step(a)
-        assert not info[:, 11].any()
+        assert not info[:, 11].any() and not (info[:, 1] & (4 | 8 | 16)).any()    # no crash, no illegal collision on the way
         paid += int((r > 0).sum())
         wins, grip_steps = np.maximum(wins, info[:, 9]), grip_steps + int(gr.sum())
-    assert (wins >= 1).sum() >= 3 and paid >= 3 and grip_steps > 300, (wins, paid, grip_steps)
+    assert (wins >= 1).all() and paid >= n and grip_steps > 400, (wins, paid, grip_steps)
     B.close()
