@@ -135,7 +135,8 @@ def hand_sites(frames, info):
     return out[0], out[1]
 
 
-def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None, lift_height=0.7):
+def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None, lift_height=0.7,
+                    choreographed=False):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -177,6 +178,25 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
             info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        if handover and choreographed:
+            # a handover one can act on: the human stands still 1.2 m in front of the robot, facing it, arms down; between the keyframes the
+            # holding arm is stretched out over the table (hand ~0.63 m in front of the robot base, 1.18 m high), blending in before the first
+            # keyframe and out after the second
+            k0, k1 = info["keyframes"]
+            f = np.arange(n, dtype=float)
+            up = np.clip((f - 0.5 * k0) / max(0.5 * k0, 1.0), 0.0, 1.0)
+            down = np.clip((f - k1) / max(0.5 * (n - k1), 1.0), 0.0, 1.0)
+            w = (up * up * (3 - 2 * up)) * (1 - down * down * (3 - 2 * down))
+            left = info["object_holding_hand"] == "left"
+            for name in order:
+                anim[name] = np.zeros(n)
+            anim["L_Shoulder_z"], anim["R_Shoulder_z"] = np.full(n, -1.43), np.full(n, 1.43)
+            side, sg = ("L", -1.0) if left else ("R", 1.0)
+            anim[f"{side}_Shoulder_z"] = sg * (1.43 + w * (0.5 - 1.43))
+            anim[f"{side}_Shoulder_y"] = sg * 1.5 * w
+            anim[f"{side}_Shoulder_x"] = -1.5 * w
+            anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"] = np.zeros(n), np.ones(n), np.zeros(n)
+            anim["Pelvis_quat"] = np.tile(np.array([0.0, 1.0, 0.0, 0.0]), (n, 1))
         if lifting is not None:
             # stand-in for the CollaborativeLifting/* recordings: a human facing the robot who raises and lowers the far end of the board.
             # `lifting` = world position of the middle between the two hands at the first frame (where the board's grips are at a reset);

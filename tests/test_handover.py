@@ -239,3 +239,23 @@ def test_collaboration_tasks_long_run_stays_finite(env_id, shield):
     assert crashes == 0
     assert phases[1:].sum() > 0, phases                                       # beyond APPROACH
     G.close()
+
+
+def test_choreographed_handover_clips_hold_the_hand_out_within_reach():
+    """synthetic_clips(handover=..., choreographed=True): the human stands still, facing the robot, and stretches the holding arm out over the table
+    between the keyframes (the stand-in for what the HumanRobotHandover / RobotHumanHandover recordings do)."""
+    from human_robot_gym_amd.animation import hand_sites
+    for ho in (True, "r2h"):
+        clips = hrg.synthetic_clips(2, seed=0, min_frames=300, max_frames=400, fps=90.0, handover=ho, choreographed=True)
+        o = 0
+        for c in range(2):
+            F, info = clips.frames[o:o + clips.lengths[c]], clips.infos[c]
+            o += clips.lengths[c]
+            lh, rh = hand_sites(F, info)
+            k0, k1 = info["keyframes"]
+            left = info["object_holding_hand"] == "left"
+            h, other = (lh, rh) if left else (rh, lh)
+            assert np.allclose(h[k0:k1 + 1], h[k0]) and 0.55 < h[k0][0] < 0.7 and 1.1 < h[k0][2] < 1.25 and abs(abs(h[k0][1]) - 0.18) < 0.03   # held out, over the table
+            assert (h[k0][1] < 0) == left                                       # facing the robot: left hand at -y
+            assert h[0][0] > 1.2 and h[-1][0] > 1.2 and h[0][2] < 0.7           # arms down at the start and the end
+            assert np.allclose(other, other[0])                                 # the other arm never moves
