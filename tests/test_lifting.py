@@ -333,3 +333,31 @@ def test_hip_matches_oracle_with_cartesian_actions_and_the_follower():
                 G.set_box(e, O.get_box(e))
     assert held > 4 * 30
     O.close(); G.close()
+
+
+@pytest.mark.gpu
+def test_follower_succeeds_on_the_hip_stepper_end_to_end():
+    """The product path alone (HipVecEnv + in-kernel IK front-end, no oracle in the loop): the scripted follower of demos/demo_lifting_follower_hip.py
+    carries the board through on (nearly) every env; a resting robot never does."""
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    clips = mixed.task_clips(ENV, 4, min_frames=200, max_frames=260)
+    n = 32
+    out = {}
+    for follow in (True, False):
+        env = HipVecEnv(n, env_id=ENV, env_kwargs=dict(seed=0, horizon=400), clips=clips, ik_position_delta=dict(action_limit=0.15),
+                        obs_keys=["vec_eef_to_human_lh", "vec_eef_to_human_rh", "board_balance", "board_gripped"])
+        obs = env.reset()
+        wins = fails = 0
+        for t in range(150):
+            mid = 0.5 * (obs[:, 0:3] + obs[:, 3:6])
+            a = np.zeros((n, 4))
+            if follow:
+                a[:, 0], a[:, 1], a[:, 2] = np.clip(mid[:, 0] - 0.95, -0.15, 0.15), np.clip(mid[:, 1], -0.15, 0.15), np.clip(1.5 * mid[:, 2], -0.15, 0.15)
+            obs, rew, done, infos = env.step(a)
+            assert np.isfinite(obs).all()
+            for i in np.nonzero(done)[0]:
+                wins, fails = wins + int(infos[i]["n_goal_reached"] > 0), fails + int(infos[i]["n_goal_reached"] == 0)
+        out[follow] = (wins, fails)
+        env.close()
+    assert out[True][0] >= n - 3 and out[True][1] <= 3, out
+    assert out[False][0] == 0 and out[False][1] >= n, out
