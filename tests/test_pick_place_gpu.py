@@ -231,3 +231,32 @@ def test_long_run_stays_finite_and_on_the_table():
         assert abs(np.linalg.norm(list(b.quat)) - 1.0) < 1e-9 and np.isfinite(list(b.vel)).all()
     assert dones >= 2 * n and crashes <= 0.002 * n * 300, (dones, crashes)
     G.close()
+
+
+def test_scripted_expert_delivers_on_the_hip_stepper_end_to_end():
+    """The product path alone (HipVecEnv + in-kernel IK front-end, no oracle in the loop): the scripted pick-and-place expert of
+    tests/test_pick_place.py delivers its cube on (nearly) every env while the human stands out of the way."""
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    n = 32
+    env = HipVecEnv(n, env_id="PickPlaceHumanCart", env_kwargs=dict(seed=4, horizon=300, shield_type="SSM"), clips=hrg.static_clip(900, pelvis=(0.0, 1.0, 2.5)),
+                    obs_keys=["vec_eef_to_object", "vec_eef_to_target", "object_gripped"], ik_position_delta=dict(action_limit=0.15))
+    obs = env.reset()
+    wins = np.zeros(n, int)
+    for k in range(260):
+        v_obj, v_tgt, gr = obs[:, 0:3].astype(float), obs[:, 3:6].astype(float), obs[:, 6] != 0
+        a = np.zeros((n, 4))
+        for e in range(n):
+            if not gr[e]:
+                over = np.linalg.norm(v_obj[e, :2]) <= 0.012
+                tgt = np.array([v_obj[e, 0], v_obj[e, 1], v_obj[e, 2] + (0.0 if over else 0.08)])
+                g = 1.0 if over and abs(v_obj[e, 2]) < 0.02 else -1.0
+            else:
+                far = np.linalg.norm(v_tgt[e, :2]) > 0.03
+                tgt, g = np.array([v_tgt[e, 0], v_tgt[e, 1], max(v_tgt[e, 2] + 0.06, 0.0) if far else v_tgt[e, 2] + 0.03]), 1.0
+            a[e, :3], a[e, 3] = np.clip(tgt, -0.05, 0.05), g
+        obs, rew, done, infos = env.step(a)
+        assert np.isfinite(obs).all() and not done.any()
+        wins = np.maximum(wins, [i["n_goal_reached"] for i in infos])
+    assert (wins >= 1).sum() >= n - 2, wins
+    env.close()
