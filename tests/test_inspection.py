@@ -8,6 +8,8 @@ import human_robot_gym_amd as hrg
 from human_robot_gym_amd._cstruct import CONST
 from pp_scenarios import put_box
 
+ENV = "HumanObjectInspectionCart"
+
 INSP = dict(env_id="HumanObjectInspectionCart")
 APPROACH, READY, INSPECTION, RETREAT, COMPLETE = range(5)
 
@@ -109,3 +111,60 @@ def test_hip_matches_oracle_on_the_inspection_task():
                 G.set_box(e, O.get_box(e))
     assert successes >= 3
     O.close(); G.close()
+
+
+def _inspection_expert(obs_obj, obs_tgt, gripped):
+    """Cartesian expert: hover over the cube, descend, close, carry it to the inspection target and hold it there."""
+    n = len(gripped)
+    a = np.zeros((n, 4))
+    for e in range(n):
+        v_obj, v_tgt = obs_obj[e].astype(float), obs_tgt[e].astype(float)
+        if not gripped[e]:
+            over = np.linalg.norm(v_obj[:2]) <= 0.012
+            tgt = np.array([v_obj[0], v_obj[1], v_obj[2] + (0.0 if over else 0.08)])
+            g = 1.0 if over and abs(v_obj[2]) < 0.02 else -1.0
+        else:
+            tgt, g = np.array([v_tgt[0], v_tgt[1], v_tgt[2] + 0.017]), 1.0     # the cube hangs 1.7 cm below the grip site
+        a[e, :3], a[e, 3] = np.clip(tgt, -0.05, 0.05), g
+    return a
+
+
+def test_scripted_expert_brings_the_object_to_the_inspection_and_the_task_completes():
+    """HumanObjectInspectionCart end to end on the oracle: the expert holds the cube in the target zone, the human's phase machine runs
+    APPROACH -> READY -> INSPECTION -> RETREAT -> COMPLETE and the success is counted (SSM shield on, it intervenes on the way)."""
+    from human_robot_gym_amd import mixed
+    from oracle.oracle import OracleBatch
+    clips = mixed.task_clips(ENV, 2, min_frames=2400, max_frames=3000)          # 120 Hz: 20-25 s
+    d = hrg.build_model_desc(dict(seed=4, horizon=400, shield_type="SSM"), n_clips=clips.n_clips, env_id=ENV, ik_position_delta=dict(action_limit=0.15))
+    n = 6
+    B = OracleBatch(d, clips, n)
+    obs = B.reset()
+    wins, seen = np.zeros(n, int), set()
+    for k in range(340):
+        a = np.zeros((n, 7))
+        a[:, :4] = _inspection_expert(obs[:, 40:43], obs[:, 43:46], obs[:, 39] != 0)
+        obs, r, dn, info = B.step(a)
+        assert not info[:, 11].any()
+        wins = np.maximum(wins, info[:, 9])
+        seen |= {B.get_box(e).task_phase for e in range(n)}
+    assert (wins >= 1).sum() >= 4 and {0, 1, 2, 3} <= seen, (wins, seen)
+    B.close()
+
+
+@pytest.mark.gpu
+def test_scripted_expert_completes_inspections_on_the_hip_stepper_end_to_end():
+    """The same on the product path alone (HipVecEnv + in-kernel IK front-end)."""
+    from human_robot_gym_amd import mixed
+    from human_robot_gym_amd.vec_env import HipVecEnv
+    clips = mixed.task_clips(ENV, 2, min_frames=2400, max_frames=3000)
+    n = 24
+    env = HipVecEnv(n, env_id=ENV, env_kwargs=dict(seed=4, horizon=400, shield_type="SSM"), clips=clips, ik_position_delta=dict(action_limit=0.15),
+                    obs_keys=["vec_eef_to_object", "vec_eef_to_target", "object_gripped"])
+    obs = env.reset()
+    wins = np.zeros(n, int)
+    for k in range(340):
+        obs, rew, done, infos = env.step(_inspection_expert(obs[:, 0:3], obs[:, 3:6], obs[:, 6] != 0))
+        assert np.isfinite(obs).all()
+        wins = np.maximum(wins, [i["n_goal_reached"] for i in infos])
+    assert (wins >= 1).sum() >= n // 2, wins
+    env.close()
