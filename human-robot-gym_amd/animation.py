@@ -180,7 +180,7 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
         if handover and choreographed:
             # a handover one can act on: the human stands still 1.2 m in front of the robot, facing it, arms down; between the keyframes the
-            # holding arm is stretched out over the table (hand ~0.63 m in front of the robot base, 1.18 m high), blending in before the first
+            # holding arm is stretched out over the table (hand ~0.66 m in front of the robot base at the default stand-off, 1.02 m high), blending in before the first
             # keyframe and out after the second
             k0, k1 = info["keyframes"]
             f = np.arange(n, dtype=float)
@@ -192,9 +192,9 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
                 anim[name] = np.zeros(n)
             anim["L_Shoulder_z"], anim["R_Shoulder_z"] = np.full(n, -1.43), np.full(n, 1.43)
             side, sg = ("L", -1.0) if left else ("R", 1.0)
-            anim[f"{side}_Shoulder_z"] = sg * (1.43 + w * (0.5 - 1.43))
-            anim[f"{side}_Shoulder_y"] = sg * 1.5 * w
-            anim[f"{side}_Shoulder_x"] = -1.5 * w
+            anim[f"{side}_Shoulder_z"] = sg * (1.43 + w * (1.25 - 1.43))
+            anim[f"{side}_Shoulder_y"] = sg * 1.25 * w
+            anim[f"{side}_Shoulder_x"] = -0.75 * w
             anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"] = np.zeros(n), np.ones(n), np.zeros(n)
             anim["Pelvis_quat"] = np.tile(np.array([0.0, 1.0, 0.0, 0.0]), (n, 1))
         if lifting is not None:

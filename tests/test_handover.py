@@ -255,7 +255,7 @@ def test_choreographed_handover_clips_hold_the_hand_out_within_reach():
             k0, k1 = info["keyframes"]
             left = info["object_holding_hand"] == "left"
             h, other = (lh, rh) if left else (rh, lh)
-            assert np.allclose(h[k0:k1 + 1], h[k0]) and 0.55 < h[k0][0] < 0.7 and 1.1 < h[k0][2] < 1.25 and abs(abs(h[k0][1]) - 0.18) < 0.03   # held out, over the table
+            assert np.allclose(h[k0:k1 + 1], h[k0]) and 0.6 < h[k0][0] < 0.72 and 0.95 < h[k0][2] < 1.08 and abs(abs(h[k0][1]) - 0.2) < 0.04   # held out, over the table
             assert (h[k0][1] < 0) == left                                       # facing the robot: left hand at -y
             assert h[0][0] > 1.2 and h[-1][0] > 1.2 and h[0][2] < 0.7           # arms down at the start and the end
             assert np.allclose(other, other[0])                                 # the other arm never moves
