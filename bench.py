@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
-"""bench.py — env (policy) steps/sec of the batched ReachHuman stepper, one process per GPU.
+"""bench.py — env (policy) steps/sec of the batched human-robot-gym stepper, one process per GPU.
 
     python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N ...          (no WORLD_SIZE in the env: this process spawns the N ranks itself and never touches a GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -10,23 +11,32 @@ cycles of 4 ms per policy step), synthetic random actions U(-1,1)^7, synthetic h
 One "step" = one `hrg_batch_step` launch over the rank's 4096 envs (+ one RCCL all-gather of the packed
 outputs when N > 1).  Envs shard embarrassingly: rank r owns global env ids [r*4096, (r+1)*4096).
 
+STEADY STATE.  Before the W warm-up steps the batch is rolled, untimed, for `preroll` steps (one horizon, at most 1000:
+`config.preroll_steps`), so that episode phases are spread over the batch whatever --warmup says; a batch timed right
+after reset is ~25 % faster than the one a training run sees (fewer envs braking or in contact).
+
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     — HBM roofline of the step kernel: ALGORITHMIC bytes per launch / average kernel time measured
-                 live with HIP events on the launch stream (hrg_batch_kernel_time).
-  cpu_baseline — the CPU oracle (oracle/hrg_oracle.c, kind "port") timed on the host cores on a bounded sample.
+                 live with HIP events on the launch stream (hrg_batch_kernel_time).  `traffic`, `valu_*` and `fp64_*`
+                 are PMC figures of a committed capture of this same command (`traffic_source` names the file): a
+                 counter pass slows the kernel and cannot run inside the timed region.
+  cpu_baseline — the CPU oracle (oracle/hrg_oracle.c, kind "port") on the host: P worker threads pinned one per
+                 physical core of the affinity mask, barrier per vec-step (the SubprocVecEnv shape), bounded sample.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector peak (SURVEY.md §8d)
+DEFAULT_PMC = os.path.join(ROOT, "profiles", "r02_pmc.json")
 
 
 def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
@@ -36,47 +46,63 @@ def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
     return 2 * state_bytes + n_cycles * frame + C["HRG_ACT_DIM"] * 8 + out
 
 
-def cpu_baseline(env_kwargs, clips_seed, budget_s=12.0, max_threads=16, env_id="ReachHuman", n_envs=ENVS_PER_GPU, wrappers=None):
-    """Oracle on the host cores: P threads (ctypes releases the GIL) x n/P envs each, barrier per vec-step —
-    the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per step)."""
+def physical_cores():
+    """(logical cpus of this process's affinity mask, one logical cpu per physical core of that mask)."""
+    avail = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    seen, firsts = set(), []
+    for c in avail:
+        key = None
+        try:
+            with open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list") as f:
+                key = f.read().strip()
+        except OSError:
+            key = str(c)
+        if key not in seen:
+            seen.add(key)
+            firsts.append(c)
+    return avail, firsts
+
+
+def cpu_baseline(env_kwargs, clips_seed, budget_s=10.0, env_id="ReachHuman", n_envs=ENVS_PER_GPU, wrappers=None, preroll=100):
+    """Oracle on the host cores, the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per vec-step):
+    P pthreads inside the oracle library, each stepping n/P envs, pthread barrier per vec-step.  Timed twice: P = physical cores of the
+    affinity mask (the headline figure) and P = 16 (the CPU share gpurun documents for a 1-GPU box)."""
     import numpy as np
     import human_robot_gym_amd as hrg
     from oracle.oracle import OracleBatch
-    avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cores = min(avail, max_threads)  # a 1-GPU box is given a 16-core CPU share
+    avail, firsts = physical_cores()
     n = n_envs
     clips = _bench_clips(env_id, clips_seed)
     desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id, **(wrappers or {}))
     B = OracleBatch(desc, clips, n, 0)
     B.reset()
     rng = np.random.RandomState(1234)
-    bounds = [(n * i // cores, n * (i + 1) // cores) for i in range(cores)]
+    pool = rng.uniform(-1, 1, (16, n, 7))
+    if wrappers:
+        pool[:, :, :3] *= 0.15
 
-    def vec_step(a):
-        ts = [threading.Thread(target=B.step_range, args=(lo, hi, a)) for lo, hi in bounds]
-        for t in ts:
-            t.start()
-        for t in ts:
-            t.join()
+    def timed(workers, cpus, budget):
+        B.rollout_parallel(pool, 2, workers, cpus)   # warm-up of the thread team / caches
+        t0 = time.perf_counter()
+        k = 0
+        chunk = 4
+        while True:
+            B.rollout_parallel(pool, chunk, workers, cpus)
+            k += chunk
+            el = time.perf_counter() - t0
+            if el >= budget:
+                return n * k / el, k, el
 
-    def draw():
-        a = rng.uniform(-1, 1, (n, 7))
-        if wrappers:
-            a[:, :3] *= 0.15
-        return a
-
-    vec_step(draw())  # warm-up
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        vec_step(draw())
-        k += 1
-        el = time.perf_counter() - t0
-        if el >= budget_s and k >= 2:
-            break
+    # the same pre-roll as the GPU leg, so that both time the steady state (bounded: the CPU is ~20-30x slower)
+    B.rollout_parallel(pool, min(preroll, 24), len(firsts), firsts)
+    v_all, k_all, el_all = timed(len(firsts), firsts, budget_s)
+    p16 = min(16, len(avail))
+    v16, k16, el16 = timed(p16, None, 0.6 * budget_s)
     B.close()
-    return {"value": n * k / el, "unit": "env steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {k} vec-steps ({el:.1f} s), oracle/hrg_oracle.c on {cores} of {avail} host threads"}
+    return {"value": v_all, "unit": "env steps/s", "cores": len(firsts), "kind": "port",
+            "sample": f"{n} envs x {k_all} vec-steps ({el_all:.1f} s), oracle/hrg_oracle.c, {len(firsts)} pthreads pinned one per physical core "
+                      f"({len(avail)} logical cpus in the affinity mask), barrier per vec-step",
+            "value_16_threads": v16, "sample_16_threads": f"{n} envs x {k16} vec-steps ({el16:.1f} s) on {p16} unpinned threads"}
 
 
 OTHER_TASKS = {  # --env values beyond the two benchmark configurations: (env kwargs, kernel) per training/icra_2024_run_experiments.sh:4-9
@@ -113,30 +139,74 @@ class _stdout_to_stderr:
         return False
 
 
+def make_gather(G, world, mode="serial"):
+    """The N > 1 exchange of one step: every rank's packed head (obs, reward, info, done) to all ranks with ONE RCCL all-gather.
+    Returns (publish(k), finish(), gathered tensor or None).  Factored out so that tests/test_api_gpu.py can run it in-process."""
+    import torch
+    import torch.distributed as dist
+    from human_robot_gym_amd.dist import OverlappedGather
+    if mode == "overlap":   # side stream; measured slower on one GPU (DESIGN.md §7): kept as an experiment
+        og = OverlappedGather(G.packed_head, world)
+        return (lambda k: og.publish(G.packed_head, k)), og.finish, None
+    gathered = torch.empty(world * G.packed_head.numel(), dtype=torch.uint8, device=G.device)
+    return (lambda k: dist.all_gather_into_tensor(gathered, G.packed_head)), (lambda: None), gathered
+
+
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their env).
+    This parent never initialises torch.cuda or HIP and never execs; rank 0's stdout (the one JSON line) is passed through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for p in procs:
+        rc = max(rc, abs(p.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--preroll", type=int, default=None, help="untimed steps before the warm-up that spread the episode phases (default: one horizon, at most 1000)")
     ap.add_argument("--shield", default="SSM", choices=["SSM", "OFF"])
     ap.add_argument("--env", default="ReachHuman", choices=["ReachHuman", "PickPlaceHumanCart", "mixed"] + sorted(OTHER_TASKS),
                     help="ReachHuman = the configuration BASELINE.json's metric is quoted on (default); PickPlaceHumanCart = its config 4 (8192 envs); "
                          "the other tasks of the ICRA suite at 4096 envs (--shield is overridden by the suite's shield type where it names one); "
-                         "mixed = BASELINE configs[4]: 4096 envs per GPU split evenly over the suite's tasks that are built (mixed.ICRA_TASKS)")
+                         "mixed = BASELINE configs[4]: 4096 envs per GPU split evenly over the suite's tasks (mixed.ICRA_TASKS)")
     ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
                     "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=16)
-    ap.add_argument("--traffic-json", default=os.path.join(ROOT, "profiles", "r01_pmc_traffic.json"))
+    ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (the 16-thread leg gets 0.6 x)")
+    ap.add_argument("--pmc-json", default=DEFAULT_PMC, help="committed PMC capture of this command (tools/profile_capture.sh): source of roofline.traffic / valu_* / fp64_*")
+    ap.add_argument("--variant-lib", default=None, help="tuning experiments only: time another build of the library; echoed as `variant_lib` in the JSON line")
+    ap.add_argument("--force-gather", action="store_true", help="rehearse the N > 1 all-gather on one GPU (world size 1)")
+    ap.add_argument("--gather-mode", default="serial", choices=["serial", "overlap"])
     args = ap.parse_args()
 
-    import numpy as np
+    for var in ("HRG_PHASE_MASK", "HRG_LIB_PATH"):   # round-1 tuning switches: refuse rather than print a number that means something else
+        if os.environ.get(var):
+            print(f"bench.py: {var} is set; unset it (a variant build is timed with --variant-lib, and is reported as such)", file=sys.stderr)
+            raise SystemExit(2)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    import numpy as np  # noqa: F401
     import torch
     import human_robot_gym_amd as hrg
+    from human_robot_gym_amd import _lib
     from human_robot_gym_amd._cstruct import CONST as C
+    if args.variant_lib:
+        _lib.use_variant_library(args.variant_lib)
     from human_robot_gym_amd._lib import HipBatch, load_library
-    from human_robot_gym_amd.dist import OverlappedGather
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -147,9 +217,14 @@ def main():
     dist = None
     quiet = _stdout_to_stderr()
     quiet.__enter__()   # until the warm-up is over (RCCL banner)
-    if world > 1:
+    force = args.force_gather or os.environ.get("HRG_BENCH_FORCE_GATHER") == "1"
+    if world > 1 or force:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     # ReachHuman training configuration: training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
     pick_place = args.env != "ReachHuman"   # every other task carries the manipulation object's state block
@@ -188,33 +263,27 @@ def main():
             a[:, :3] *= 0.15
     fresh = [torch.empty_like(pool[0]) for _ in range(2)]  # the kernel rewrites action rows in place when wrappers are on
     # N > 1: every rank's packed outputs are published to all ranks with one RCCL all-gather per step on the compute stream.
-    # HRG_BENCH_GATHER_MODE=overlap moves it to a side stream (dist.OverlappedGather); measured on one MI355X that is SLOWER: the
-    # step kernel fills every workgroup slot of the chip (4096 = 256 CUs x 16), so a concurrent copy / RCCL kernel pushes part of it
-    # into a second round (2.31 instead of 1.96 ms).  HRG_BENCH_FORCE_GATHER=1 rehearses the gather path on one GPU (world size 1)
-    force = os.environ.get("HRG_BENCH_FORCE_GATHER") == "1"
-    if force and world == 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
-    serial = os.environ.get("HRG_BENCH_GATHER_MODE", "serial") != "overlap"
-    gather = (True if serial else OverlappedGather(G.packed_head, world)) if (world > 1 or force) else None
-    gathered = torch.empty(world * G.packed_head.numel(), dtype=torch.uint8, device=dev) if (gather is not None and serial) else None
+    publish = finish = None
+    if world > 1 or force:
+        publish, finish, _ = make_gather(G, world, args.gather_mode)
 
-    def one_step(k):
+    def one_step(k, exchange=True):
         if args.ik:
             a = fresh[k & 1]
             a.copy_(pool[k % len(pool)])
             G.step(a)
         else:
             G.step(pool[k % len(pool)])
-        if gather is not None and serial:
-            dist.all_gather_into_tensor(gathered, G.packed_head)  # obs, reward, info, done of every rank (1.0 MB per rank)
-        elif gather is not None:
-            gather.publish(G.packed_head, k)  # one fused RCCL all-gather of obs/reward/done/info on a side stream
+        if publish is not None and exchange:
+            publish(k)
 
+    # pre-roll: spread the episode phases (a fresh batch has every env at timestep 0, nobody braking, no contacts yet)
+    preroll = args.preroll if args.preroll is not None else min(int(desc.horizon), 1000)
+    for k in range(preroll):
+        one_step(k, exchange=False)
     for k in range(args.warmup):
-        one_step(k)
-    if gather is not None and args.warmup == 0:
+        one_step(preroll + k)
+    if publish is not None and args.warmup == 0:
         one_step(0)      # the first collective brings the communicator up: never inside the timed region
     torch.cuda.synchronize()
     quiet.__exit__(None, None, None)
@@ -225,8 +294,8 @@ def main():
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
-    if gather is not None and not serial:
-        gather.finish()
+    if finish is not None:
+        finish()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -244,14 +313,28 @@ def main():
             per_env = (per_env * n - n_reach * 2 * load_library().hrg_box_bytes()) / n
             kernel_ms = 1e3 * elapsed / args.steps
         achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
-        traffic = None
-        try:
-            with open(args.traffic_json) as f:
-                traffic = json.load(f).get("hbm_bytes_per_launch")
-        except Exception:
-            pass
-        if pick_place or n != ENVS_PER_GPU:
-            traffic = None  # the committed PMC capture is of the default workload's kernel
+        kernel_name = "all step kernels, concurrent (wall time per step)" if mixed_tasks else (
+            OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel"))
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                "traffic_source": None, "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_env * n}
+        # PMC figures: from the committed capture of the default workload's kernel (never from this run: a counter pass perturbs the timing)
+        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib
+        if default_workload:
+            try:
+                with open(args.pmc_json) as f:
+                    pmc = json.load(f)
+                src = os.path.relpath(args.pmc_json, ROOT)
+                roof["traffic"] = pmc.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = f"{src}: {pmc.get('command', 'rocprofv3 --pmc passes of this command')} (committed capture, per launch; not collected by this run)"
+                for key in ("valu_insts_per_substep", "valu_busy_frac", "valu_lane_utilisation", "fp64_flops_per_launch"):
+                    if key in pmc:
+                        roof[key] = pmc[key]
+                if "fp64_flops_per_launch" in pmc and kernel_ms > 0:
+                    roof["fp64_tflops_est"] = pmc["fp64_flops_per_launch"] / (kernel_ms * 1e-3) / 1e12
+                    roof["fp64_vector_peak_tflops"] = FP64_VECTOR_PEAK_TF
+                    roof["fp64_frac_est"] = roof["fp64_tflops_est"] / FP64_VECTOR_PEAK_TF
+            except Exception as ex:  # no capture committed yet: the fields stay null
+                roof["traffic_source"] = f"unavailable ({type(ex).__name__})"
         out = {
             "metric": "env steps/sec (whole node), ReachHuman+shield 4096 envs" if not pick_place else (
                 f"env steps/sec (whole node), mixed ICRA task batch {n} envs/GPU" if mixed_tasks else f"env steps/sec (whole node), {args.env}+shield {n} envs"),
@@ -266,22 +349,21 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.env}, {n} envs/GPU, sara-shield {args.shield}, control_freq 10 (25 x 4 ms shield cycles per step), "
-                                   + ("Cartesian random actions through the IK front-end + collision prevention, " if args.ik else "random actions U(-1,1)^7, ")
-                                   + "13 synthetic human clips, auto-reset",
+            "config": {"workload": f"{args.env}, {n} envs/GPU, shield {args.shield}, 25 x 4 ms cycles/step, "
+                                   + ("Cartesian random actions via IK + collision prevention" if args.ik else "random actions U(-1,1)^7")
+                                   + f", 13 synthetic clips, auto-reset, steady state ({preroll}-step pre-roll)",
                        "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
-                       "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if serial else " on a side stream") if gather is not None else "")},
+                       "preroll_steps": preroll,
+                       "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if args.gather_mode == "serial" else " on a side stream") if publish is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "all step kernels, concurrent (wall time per step)" if mixed_tasks else (
-                             OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel")), "kernel_ms": kernel_ms, "launches": n_launch,
-                         "algorithmic_bytes_per_launch": per_env * n},
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            if mixed_tasks:
-                out["config"]["tasks"] = mixed_tasks
-            else:
-                out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, max_threads=args.cpu_threads, env_id=args.env, n_envs=n, wrappers=wrappers)
+        if mixed_tasks:
+            out["config"]["tasks"] = mixed_tasks
+        if args.variant_lib:
+            out["variant_lib"] = os.path.abspath(args.variant_lib)
+        if world == 1 and not args.no_cpu_baseline and not mixed_tasks:
+            out["cpu_baseline"] = cpu_baseline(env_kwargs, 0, budget_s=args.cpu_budget, env_id=args.env, n_envs=n, wrappers=wrappers, preroll=preroll)
         print(json.dumps(out), flush=True)
     G.close()
     if world > 1:

@@ -17,6 +17,9 @@ def __getattr__(name):
     if name == "make_vec_env":
         from .env_util import make_vec_env
         return make_vec_env
+    if name in ("create_training_vec_env", "compose_environment_kwargs", "wrapper_kwargs_from_config"):
+        from . import training_utils
+        return getattr(training_utils, name)
     if name in ("MixedBatch", "MixedHipVecEnv", "make_mixed_batch", "make_mixed_vec_env", "ICRA_TASKS"):
         from . import mixed
         return getattr(mixed, name)

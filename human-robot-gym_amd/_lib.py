@@ -10,7 +10,8 @@ import subprocess
 from ._cstruct import CONST, EnvState, BoxState, ModelDesc, ClipTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("HRG_LIB_PATH") or os.path.join(_HERE, "libhrgym_hip.so")  # override: tuning experiments only
+LIB_PATH = os.path.join(_HERE, "libhrgym_hip.so")   # the one shipping library; no environment variable redirects it
+_variant = None   # tuning experiments only: set through use_variant_library(), reported by bench.py as "variant_lib"
 SRC = os.path.join(_HERE, "csrc", "hrgym_hip.hip")
 SRC_BOX = os.path.join(_HERE, "csrc", "hrgym_box.hip")   # the same sources compiled with the manipulation object (PickPlaceHumanCart)
 SRC_HO = os.path.join(_HERE, "csrc", "hrgym_handover.hip")   # ... and once more with the object <-> hand weld of the handover tasks
@@ -40,15 +41,32 @@ def build_library(force=False, verbose=False):
 _lib = None
 
 
+def use_variant_library(path):
+    """Tuning experiments only (tools/): load another build of the library instead of the shipping one.  Must be called before the first
+    batch is created; `variant_library()` tells callers (bench.py echoes it in its JSON line) that results are not the shipping build's."""
+    global _variant
+    if _lib is not None:
+        raise RuntimeError("use_variant_library() must be called before the library is loaded")
+    _variant = os.path.abspath(path)
+
+
+def variant_library():
+    return _variant
+
+
 def load_library():
     """dlopen the HIP library and declare signatures. Raises if it is missing (no fallback)."""
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise RuntimeError(f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
+    for var in ("HRG_LIB_PATH", "HRG_PHASE_MASK"):   # round-1 tuning switches: a stale variable must not change what runs
+        if os.environ.get(var):
+            raise RuntimeError(f"{var} is set: the library no longer honours it (use _lib.use_variant_library() / a -DHRG_STAMPS diagnostic build); unset it")
+    path = _variant or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (hipcc --offload-arch=gfx950). "
                            "There is no CPU fallback for the stepper.")
-    lib = ctypes.CDLL(LIB_PATH)
+    lib = ctypes.CDLL(path)
     vp, i32, i64 = ctypes.c_void_p, ctypes.c_int32, ctypes.c_int64
     lib.hrg_last_error.restype = ctypes.c_char_p
     lib.hrg_version.restype = ctypes.c_char_p

@@ -150,7 +150,7 @@ struct DevModel {
   double rcap_hl[HRG_NRCAP], hcap_hl[HRG_NHB];  // half lengths of the collision capsules (rigid: constants of the model)
   int32_t hb_njump;                      // rounds of pointer jumping that cover the deepest path
   int32_t hb_jump[4][HRG_NHB];           // ancestor 2^s levels up (-1: beyond the root)
-  int32_t phase_mask;        // timing experiments (HRG_PHASE_MASK); 0xff = everything on
+  int32_t phase_mask;        // read by the -DHRG_STAMPS diagnostic build only (HRG_PHASE_MASK); the shipping kernels ignore it
   hrg_path brake_full;       // fail-safe profile from the steady state (s'=1, s''=0): constant per model
   double brake_T, brake_ds;
   // human reach capsule table (one entry per lane): kind 0 ACC, 1 VEL, 2 POS ball, 3 POS part

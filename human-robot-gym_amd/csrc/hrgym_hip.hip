@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -1001,7 +1002,11 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
     wave_sync();
   }
   // humanMeasurement + SafetyShield.step; also runs the chain kinematics of sim.forward() #1
-  const int pm = dm->phase_mask;
+#ifdef HRG_STAMPS
+  const int pm = dm->phase_mask;   // diagnostic build only (tools/phase_timing.sh): phases can be switched off for timing, results are then invalid
+#else
+  constexpr int pm = 0xff;         // shipping build: every phase always runs; there is no switch
+#endif
   if (pm & 1) shield_step(dm_, lane, e, dbg_r, dbg_h, dbg_nh); else robot_chain_fk(dm_, lane, false);
   STAMP(1);
   if (pm & 2) robot_dynamics_terms(dm_, lane);
@@ -1571,8 +1576,16 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   hrg_batch* b = new hrg_batch();
   b->device = device; b->n_envs = n_envs; b->env_id0 = env_id0; b->task = desc->task;
   // ---- device model ----
-  DevModel* hm = new DevModel();
+  std::unique_ptr<DevModel> hm_own(new DevModel());
+  DevModel* hm = hm_own.get();
   memset(hm, 0, sizeof *hm);
+  // every early return below releases the batch and whatever device buffers it already owns
+  auto bail = [&](int code, const std::string& msg) { hrg_batch_destroy(b); return fail(code, msg); };
+#define HIPCHK_C(x)                                                                                       \
+  do {                                                                                                    \
+    hipError_t _e = (x);                                                                                  \
+    if (_e != hipSuccess) return bail(HRG_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(_e));        \
+  } while (0)
   hm->m = *desc;
   mat_from_quat(hm->Rbase, desc->base_quat);
   for (int i = 0; i < NV; i++) {
@@ -1601,7 +1614,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     for (int a = 0; a < 3; a++) d2 += (desc->hcap_p2[c][a] - desc->hcap_p1[c][a]) * (desc->hcap_p2[c][a] - desc->hcap_p1[c][a]);
     hm->hcap_hl[c] = 0.5 * sqrt(d2);
   }
-  if (maxd + 1 > 16) { delete hm; delete b; return fail(HRG_ERR_INVALID, "human tree deeper than 15"); }
+  if (maxd + 1 > 16) { return bail(HRG_ERR_INVALID, "human tree deeper than 15"); }
   for (int i = 0; i < HRG_NHB; i++) hm->hb_jump[0][i] = desc->hb_parent[i];
   for (int s = 1; s < 4; s++)
     for (int i = 0; i < HRG_NHB; i++) { const int a = hm->hb_jump[s - 1][i]; hm->hb_jump[s][i] = a < 0 ? -1 : hm->hb_jump[s - 1][a]; }
@@ -1613,11 +1626,11 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int k = 0; k < desc->n_extremity; k++, n++) { hm->hc_kind[n] = 2; hm->hc_j1[n] = desc->ext_joint[k]; hm->hc_j2[n] = desc->ext_joint[k]; hm->hc_th[n] = desc->ext_thickness[k]; hm->hc_v[n] = desc->ext_vmax[k]; hm->hc_len[n] = desc->ext_length[k]; }
   for (int k = 0; k < desc->n_bodypart; k++) {
     if (!desc->bp_in_pos[k]) continue;
-    if (n >= HRG_NHCAP_MAX) { delete hm; delete b; return fail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
+    if (n >= HRG_NHCAP_MAX) { return bail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
     hm->hc_kind[n] = 3; hm->hc_j1[n] = desc->bp_joint[k][0]; hm->hc_j2[n] = desc->bp_joint[k][1]; hm->hc_th[n] = desc->bp_thickness[k]; hm->hc_v[n] = desc->bp_vmax[k];
     n++;
   }
-  if (n > HRG_NHCAP_MAX) { delete hm; delete b; return fail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
+  if (n > HRG_NHCAP_MAX) { return bail(HRG_ERR_INVALID, "more than 64 human reach capsules"); }
   hm->hc_n = n;
   int ns = 0;
   for (int i = 0; i < HRG_NRCAP; i++)
@@ -1637,37 +1650,39 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     path_eval(&hm->brake_full, hm->brake_T, desc->failsafe_sdot, &se, &ve, &ae);
     hm->brake_ds = se;
   }
-  if (const char* pm = getenv("HRG_PHASE_MASK")) hm->phase_mask = atoi(pm); // timing experiments only: results are invalid
+#ifdef HRG_STAMPS
+  if (const char* pm = getenv("HRG_PHASE_MASK")) hm->phase_mask = atoi(pm); // diagnostic build only: results are invalid
+#endif
   // clips
   const size_t fbytes = sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames;
   int64_t tot = 0;
   for (int c = 0; c < clips->n_clips; c++) {
-    if (clips->clip_len[c] < 1 || clips->clip_offset[c] != tot) { delete hm; delete b; return fail(HRG_ERR_INVALID, "clip table must be densely packed"); }
+    if (clips->clip_len[c] < 1 || clips->clip_offset[c] != tot) { return bail(HRG_ERR_INVALID, "clip table must be densely packed"); }
     tot += clips->clip_len[c];
   }
-  if (tot != clips->total_frames) { delete hm; delete b; return fail(HRG_ERR_INVALID, "clip table total_frames mismatch"); }
-  HIPCHK(hipMalloc(&b->d_frames, fbytes));
-  HIPCHK(hipMemcpy(b->d_frames, clips->frames, fbytes, hipMemcpyHostToDevice));
+  if (tot != clips->total_frames) { return bail(HRG_ERR_INVALID, "clip table total_frames mismatch"); }
+  HIPCHK_C(hipMalloc(&b->d_frames, fbytes));
+  HIPCHK_C(hipMemcpy(b->d_frames, clips->frames, fbytes, hipMemcpyHostToDevice));
   hm->clips = *clips;
   hm->clips.frames = b->d_frames;
-  HIPCHK(hipMalloc(&b->d_model, sizeof(DevModel)));
-  HIPCHK(hipMemcpy(b->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice));
-  delete hm;
+  HIPCHK_C(hipMalloc(&b->d_model, sizeof(DevModel)));
+  HIPCHK_C(hipMemcpy(b->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice));
   // ---- state ----
-  HIPCHK(hipMalloc(&b->d_states, sizeof(hrg_env_state) * (size_t)n_envs));
+  HIPCHK_C(hipMalloc(&b->d_states, sizeof(hrg_env_state) * (size_t)n_envs));
   std::vector<hrg_env_state> init((size_t)n_envs);
   memset(init.data(), 0, sizeof(hrg_env_state) * (size_t)n_envs);
   for (auto& s : init) s.episode = -1;
-  HIPCHK(hipMemcpy(b->d_states, init.data(), sizeof(hrg_env_state) * (size_t)n_envs, hipMemcpyHostToDevice));
-  HIPCHK(hipMalloc(&b->d_rcaps, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
-  HIPCHK(hipMalloc(&b->d_hcaps, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
-  HIPCHK(hipMalloc(&b->d_nh, sizeof(int32_t) * (size_t)n_envs));
-  HIPCHK(hipMalloc(&b->d_scratch_obs, sizeof(float) * HRG_OBS_DIM * (size_t)n_envs));
-  HIPCHK(hipMemset(b->d_rcaps, 0, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
-  HIPCHK(hipMemset(b->d_hcaps, 0, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
-  HIPCHK(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
-  HIPCHK(hipMalloc(&b->d_boxes, sizeof(hrg_box_state) * (size_t)n_envs));
-  HIPCHK(hipMemset(b->d_boxes, 0, sizeof(hrg_box_state) * (size_t)n_envs));
+  HIPCHK_C(hipMemcpy(b->d_states, init.data(), sizeof(hrg_env_state) * (size_t)n_envs, hipMemcpyHostToDevice));
+  HIPCHK_C(hipMalloc(&b->d_rcaps, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
+  HIPCHK_C(hipMalloc(&b->d_hcaps, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
+  HIPCHK_C(hipMalloc(&b->d_nh, sizeof(int32_t) * (size_t)n_envs));
+  HIPCHK_C(hipMalloc(&b->d_scratch_obs, sizeof(float) * HRG_OBS_DIM * (size_t)n_envs));
+  HIPCHK_C(hipMemset(b->d_rcaps, 0, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)n_envs));
+  HIPCHK_C(hipMemset(b->d_hcaps, 0, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)n_envs));
+  HIPCHK_C(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
+  HIPCHK_C(hipMalloc(&b->d_boxes, sizeof(hrg_box_state) * (size_t)n_envs));
+  HIPCHK_C(hipMemset(b->d_boxes, 0, sizeof(hrg_box_state) * (size_t)n_envs));
+#undef HIPCHK_C
   *out = b;
   return HRG_OK;
 }
@@ -1684,6 +1699,7 @@ void hrg_batch_destroy(hrg_batch* b) {
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
   if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
@@ -1694,6 +1710,7 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
 
 int hrg_batch_check_actions(hrg_batch* b, const double* actions_dev, uint8_t* collides_dev, void* stream) {
   if (!b || !actions_dev || !collides_dev) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
   hipLaunchKernelGGL(hrg_check_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, actions_dev, collides_dev);
   HIPCHK(hipGetLastError());
   return HRG_OK;
@@ -1701,6 +1718,7 @@ int hrg_batch_check_actions(hrg_batch* b, const double* actions_dev, uint8_t* co
 
 int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* term_obs_dev, float* reward_dev, uint8_t* done_dev, int32_t* info_dev, void* stream) {
   if (!b || !actions_dev || !obs_dev || !reward_dev || !done_dev || !info_dev) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
   hipStream_t st = (hipStream_t)stream;
   std::pair<hipEvent_t, hipEvent_t> ev;
   if (b->timing) {
@@ -1727,6 +1745,7 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
 
 int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   std::vector<hrg_env_state> st((size_t)b->n_envs);
   HIPCHK(hipMemcpy(st.data(), b->d_states, sizeof(hrg_env_state) * (size_t)b->n_envs, hipMemcpyDeviceToHost));
@@ -1739,6 +1758,7 @@ int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host) {
 
 int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int32_t* n_human_host) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(robot_host, b->d_rcaps, sizeof(double) * 7 * HRG_NSHIELD_RCAP * (size_t)b->n_envs, hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(human_host, b->d_hcaps, sizeof(double) * 7 * HRG_NHCAP_MAX * (size_t)b->n_envs, hipMemcpyDeviceToHost));
@@ -1748,6 +1768,7 @@ int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int
 
 int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_env_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(buf_host, b->d_states + env, bytes, hipMemcpyDeviceToHost));
   return HRG_OK;
@@ -1755,6 +1776,7 @@ int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes)
 
 int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_env_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(b->d_states + env, buf_host, bytes, hipMemcpyHostToDevice));
   return HRG_OK;
@@ -1762,6 +1784,7 @@ int hrg_batch_set_state(hrg_batch* b, int32_t env, const void* buf_host, size_t 
 
 int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_box_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(buf_host, b->d_boxes + env, bytes, hipMemcpyDeviceToHost));
   return HRG_OK;
@@ -1769,6 +1792,7 @@ int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
 
 int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
   if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_box_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(b->d_boxes + env, buf_host, bytes, hipMemcpyHostToDevice));
   return HRG_OK;
@@ -1776,6 +1800,7 @@ int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t by
 
 int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void* states_host, void* boxes_host) {
   if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   for (int32_t k = 0; k < n; k++) {
     const int32_t e = envs_host[k];
@@ -1789,6 +1814,7 @@ int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void
 
 int hrg_batch_set_states(hrg_batch* b, const int32_t* envs_host, int32_t n, const void* states_host, const void* boxes_host) {
   if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
   HIPCHK(hipDeviceSynchronize());
   for (int32_t k = 0; k < n; k++) {
     const int32_t e = envs_host[k];
@@ -1809,6 +1835,7 @@ int hrg_batch_enable_taps(hrg_batch* b, int32_t on) {
 
 int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
+  HIPCHK(hipSetDevice(b->device));
   double tot = 0;
   int64_t n = 0;
   for (auto& p : b->events) {

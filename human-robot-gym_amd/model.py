@@ -248,6 +248,33 @@ IK_DEFAULTS = dict(action_limit=0.15, x_output_max=1, x_position_limits=None, re
 IK_EE_OFFSET = [0.0, 0.0, 0.17]   # models/assets/robots/schunk/robot_pybullet.urdf:226-228 (fixed_gripper_joint)
 
 
+# Reference constructor keys that have no effect on the state the stepper computes (rendering, cameras, robosuite plumbing): accepted silently
+_NO_EFFECT_KEYS = frozenset((
+    "use_camera_obs", "use_object_obs", "has_renderer", "has_offscreen_renderer", "render_camera", "render_collision_mesh", "render_visual_mesh",
+    "render_gpu_device_id", "camera_names", "camera_heights", "camera_widths", "camera_depths", "camera_segmentations", "renderer", "renderer_config",
+    "visualize_failsafe_controller", "visualize_pinocchio", "verbose", "hard_reset", "ignore_done", "controller_configs"))
+# Reference constructor keys that DO change the episode but are not implemented: accepted only at the value listed (the reference's default), else raise
+_DEFAULT_ONLY_KEYS = dict(
+    env_configuration="default", gripper_types="default", initialization_noise="default", table_friction=[1.0, 5e-3, 1e-4],
+    randomize_initial_pos=False, init_joint_pos=None, object_placement_initializer=None, target_placement_initializer=None,
+    obstacle_placement_initializer=None)
+
+
+def _check_env_kwargs(env_id, known, given):
+    """Refuse environment keyword arguments that would change the reference's behaviour but are not implemented here, instead of ignoring them
+    (`human_animation_names` is the exception: clips are handed over as a ClipSet, the names only select files of the absent animation package)."""
+    for k, v in given.items():
+        if k in known or k in _NO_EFFECT_KEYS or k == "human_animation_names":
+            continue
+        if k in _DEFAULT_ONLY_KEYS:
+            want = _DEFAULT_ONLY_KEYS[k]
+            same = (list(v) == list(want)) if isinstance(want, list) and isinstance(v, (list, tuple)) else (v == want)
+            if not same:
+                raise NotImplementedError(f"{env_id}: env kwarg {k}={v!r} is not implemented by the HIP stepper (only the reference default {want!r})")
+            continue
+        raise NotImplementedError(f"{env_id}: unknown env kwarg {k!r} (known: {sorted(known)})")
+
+
 def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True,
                      env_id="ReachHuman", ik_position_delta=None):
     """Return a filled `ModelDesc` for `env_id` ("ReachHuman" or "PickPlaceHumanCart") on the Schunk arm.
@@ -261,6 +288,7 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     if env_id not in ENV_DEFAULTS:
         raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)}")
     kw = dict(ENV_DEFAULTS[env_id])
+    _check_env_kwargs(env_id, kw, env_kwargs or {})
     kw.update(env_kwargs or {})
     sp = dict(SHIELD_DEFAULTS)
     sp.update(shield_params or {})

@@ -13,6 +13,7 @@ flattening to `[object-state, goal_difference]` (human_reach_ppo_parallel.yaml:1
 If stable-baselines3 / gym are installed the classes subclass their ABCs; otherwise light stand-ins with the same
 attributes are used (neither package is available in the build image).
 """
+import os
 import time
 from collections import OrderedDict
 
@@ -221,7 +222,7 @@ class HipVecEnv(_VecEnvBase):
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
-                 expert_obs_keys=None, goal_env=False):
+                 expert_obs_keys=None, goal_env=False, obs_norm=None, monitor_dir=None, monitor_kwargs=None):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
@@ -263,6 +264,8 @@ class HipVecEnv(_VecEnvBase):
         self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id,
                                       ik_position_delta=ik_position_delta)
         self._device, self._env_id0 = device, env_id0
+        if backend is not None and (isinstance(backend, type) or not hasattr(backend, "step_async")):   # a factory (desc, clips, n_envs, env_id0) -> backend: the caller cannot build the
+            backend = backend(self._desc, self._clips, n_envs, env_id0)    # backend itself when the model description is composed here (create_training_vec_env)
         self._backend = backend if backend is not None else _TorchBackend(self._desc, self._clips, n_envs, env_id0, device)
         obs_space = _Box(-np.inf, np.inf, shape=(len(self._cols),), dtype=np.float32)
         if self.goal_env:
@@ -282,6 +285,35 @@ class HipVecEnv(_VecEnvBase):
         self._actions = None
         self._last_full = None
         self.horizon = int(self._desc.horizon)
+        # DatasetObsNormWrapper (wrappers/dataset_wrapper.py:160-300): (obs - mean) / std, optionally tanh(squash_factor * .), applied to the policy's
+        # flat observation (and to terminal observations); std == 0 -> 1; shorter / longer statistics are padded / cut when allowed (223-239)
+        self._norm = None
+        if obs_norm is not None:
+            if self.goal_env:
+                raise NotImplementedError("obs_norm with goal_env: the reference normalises flat observations only")
+            mean, std = np.array(obs_norm["mean"], np.float64), np.array(obs_norm["std"], np.float64)
+            k = len(self._cols)
+            if mean.shape != (k,) or std.shape != (k,):
+                if not obs_norm.get("allow_different_observation_shapes", False):
+                    raise ValueError(f"obs_norm: statistics of length {mean.shape[0]} for an observation of length {k} (Environment and dataset observation space do not match!)")
+                mean = np.concatenate([mean, np.zeros(max(0, k - len(mean)))])[:k]
+                std = np.concatenate([std, np.ones(max(0, k - len(std)))])[:k]
+            std[std == 0] = 1
+            self._norm = (mean, std, obs_norm.get("squash_factor"))
+            if self._norm[2] is not None:
+                self.observation_space = _Box(-1.0, 1.0, shape=(k,), dtype=np.float32)
+        # Monitor (SB3 [UPSTREAM]; utils/env_util_SB3.py:60-66 gives every worker <monitor_dir>/<rank>.monitor.csv): ONE csv for the batch, same header and
+        # r,l,t rows (+ info_keywords columns), which stable_baselines3.common.monitor.load_results() reads like any other *.monitor.csv
+        self._monitor = None
+        if monitor_dir is not None:
+            import json
+            os.makedirs(monitor_dir, exist_ok=True)
+            self._monitor_keys = tuple((monitor_kwargs or {}).get("info_keywords", ()))
+            path = os.path.join(monitor_dir, f"hip_batch_{int(env_id0)}.monitor.csv")
+            self._monitor = open(path, "w", newline="")
+            self._monitor.write("#" + json.dumps({"t_start": self._t_start, "env_id": env_id, "n_envs": int(n_envs)}) + "\n")
+            self._monitor.write(",".join(("r", "l", "t") + self._monitor_keys) + "\n")
+            self._monitor.flush()
 
     # ---- VecEnv API -------------------------------------------------------------------------------------
     def reset(self):
@@ -339,9 +371,17 @@ class HipVecEnv(_VecEnvBase):
                 set_(d, "TimeLimit.truncated", tr)
                 set_(d, "terminal_observation", self._view(np.array(term_obs[i])))
                 set_(d, "episode", {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": now})
+                if self._monitor is not None:
+                    extra = [str(d[k]) for k in self._monitor_keys]
+                    self._monitor.write(",".join([f"{round(float(self._ep_ret[i]), 6)}", str(int(self._ep_len[i])), str(now)] + extra) + "\n")
+            if self._monitor is not None:
+                self._monitor.flush()
         return infos
 
     def close(self):
+        if getattr(self, "_monitor", None) is not None:
+            self._monitor.close()
+            self._monitor = None
         self._backend.close()
 
     def seed(self, seed=None):
@@ -409,7 +449,14 @@ class HipVecEnv(_VecEnvBase):
         """Policy view of rows of the observation superset: flat array, or the goal-env dict."""
         full = np.asarray(full)
         if not self.goal_env:
-            return full[..., self._cols]
+            v = full[..., self._cols]
+            if getattr(self, "_norm", None) is not None:
+                mean, std, squash = self._norm
+                v = (v - mean) / std
+                if squash is not None:
+                    v = np.tanh(squash * v)
+                v = v.astype(np.float32)
+            return v
         return {"observation": full[..., self._cols], "achieved_goal": full[..., self._ag_cols], "desired_goal": full[..., self._dg_cols]}
 
     def compute_reward(self, achieved_goal, desired_goal, info):

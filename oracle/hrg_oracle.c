@@ -15,7 +15,10 @@
  * the HIP kernels, plus analytic known-answer tests of the pieces — NOT agreement with MuJoCo/sara-shield.
  * Deviations from the reference stack that are deliberate in this round are listed in DESIGN.md §4.
  */
+#define _GNU_SOURCE /* pthread_setaffinity_np (CPU-baseline harness) */
 #include <math.h>
+#include <pthread.h>
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -2028,6 +2031,42 @@ int hrgo_step_range(hrgo_batch* B, int e0, int e1, double* actions, float* obs, 
     float tmp[HRG_OBS_DIM];
     env_step(B, e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tmp, reward + e, done + e, info + (size_t)e * HRG_INFO_DIM);
   }
+  return 0;
+}
+/* CPU-baseline harness (bench.py's cpu_baseline leg): the shape of the reference's SubprocVecEnv (utils/env_util_SB3.py:75-87) -- P workers, each
+ * stepping its share of the envs, synchronised once per vec-step.  n_steps vec-steps with actions cycled from a pool [n_pool][n_envs][HRG_ACT_DIM];
+ * cpus (or NULL) pins worker w to logical cpu cpus[w] (one per physical core). */
+typedef struct {
+  hrgo_batch* B; int w, nw, n_steps, n_pool; const double* pool; float* obs; float* reward; uint8_t* done; int32_t* info; pthread_barrier_t* bar; int cpu;
+} hrgo_worker_t;
+static void* hrgo_worker(void* arg) {
+  hrgo_worker_t* W = (hrgo_worker_t*)arg;
+  if (W->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(W->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
+  const int n = W->B->n_envs, e0 = (int)((long long)n * W->w / W->nw), e1 = (int)((long long)n * (W->w + 1) / W->nw);
+  double act[HRG_ACT_DIM];
+  for (int k = 0; k < W->n_steps; k++) {
+    const double* a = W->pool + (size_t)(k % W->n_pool) * n * HRG_ACT_DIM;
+    for (int e = e0; e < e1; e++) {
+      float tmp[HRG_OBS_DIM];
+      memcpy(act, a + (size_t)e * HRG_ACT_DIM, sizeof act); /* the wrappers rewrite the action row in place: work on a copy of the pool */
+      env_step(W->B, e, act, W->obs + (size_t)e * HRG_OBS_DIM, tmp, W->reward + e, W->done + e, W->info + (size_t)e * HRG_INFO_DIM);
+    }
+    pthread_barrier_wait(W->bar); /* VecEnv.step_wait: every worker has finished the step */
+  }
+  return NULL;
+}
+int hrgo_rollout_parallel(hrgo_batch* B, int n_workers, const int32_t* cpus, int n_steps, const double* pool, int n_pool, float* obs, float* reward, uint8_t* done, int32_t* info) {
+  if (n_workers < 1 || n_workers > 1024 || n_pool < 1) return -1;
+  pthread_t th[1024];
+  static hrgo_worker_t W[1024];
+  pthread_barrier_t bar;
+  pthread_barrier_init(&bar, NULL, (unsigned)n_workers);
+  for (int w = 0; w < n_workers; w++) {
+    W[w] = (hrgo_worker_t){B, w, n_workers, n_steps, n_pool, pool, obs, reward, done, info, &bar, cpus ? cpus[w] : -1};
+    if (pthread_create(&th[w], NULL, hrgo_worker, &W[w]) != 0) return -2;
+  }
+  for (int w = 0; w < n_workers; w++) pthread_join(th[w], NULL);
+  pthread_barrier_destroy(&bar);
   return 0;
 }
 int hrgo_get_state(hrgo_batch* B, int e, void* buf, size_t bytes) {

@@ -74,6 +74,16 @@ class OracleBatch:
         a = np.ascontiguousarray(actions, np.float64)
         self.lib.hrgo_step_range(self.h, ctypes.c_int(e0), ctypes.c_int(e1), _p(a), _p(self.obs), _p(self.reward), _p(self.done), _p(self.info))
 
+    def rollout_parallel(self, pool, n_steps, n_workers, cpus=None):
+        """n_steps vec-steps on n_workers pthreads (barrier per vec-step), actions cycled from pool [n_pool, n, 7]: the CPU-baseline harness."""
+        pool = np.ascontiguousarray(pool, np.float64)
+        assert pool.ndim == 3 and pool.shape[1:] == (self.n, self.C["HRG_ACT_DIM"])
+        cp = None if cpus is None else np.ascontiguousarray(cpus, np.int32)
+        assert cp is None or len(cp) >= n_workers
+        rc = self.lib.hrgo_rollout_parallel(self.h, ctypes.c_int(n_workers), None if cp is None else _p(cp), ctypes.c_int(n_steps), _p(pool), ctypes.c_int(len(pool)),
+                                            _p(self.obs), _p(self.reward), _p(self.done), _p(self.info))
+        assert rc == 0, rc
+
     def get_state(self, e):
         s = self.EnvState()
         assert self.lib.hrgo_get_state(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0

@@ -11,6 +11,24 @@ RTOL = 1e-5
 ATOL = 1e-7
 
 
+def record_live(test, live, floor):
+    """Free-running comparisons drop an env once its oracle trajectory turns violent (|qvel| > 5 rad/s or a crash: chaotic from then on).  The fraction
+    that stayed in is printed, appended to gpurun_out/parity_live.jsonl (so that the floors below are the levels the runs actually achieve) and
+    asserted against `floor`."""
+    import json
+    import os
+    frac = float(np.mean(live))
+    print(f"[parity] {test}: {int(np.sum(live))}/{len(live)} envs compared to the end (live fraction {frac:.3f}, floor {floor})")
+    try:
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_live.jsonl"), "a") as f:
+            f.write(json.dumps(dict(test=test, live=frac, n=int(len(live)), floor=floor)) + "\n")
+    except OSError:
+        pass
+    assert frac >= floor, f"{test}: too many envs dropped as chaotic: live fraction {frac:.3f} < {floor}"
+
+
 def make_pair(n_envs, env_kwargs=None, n_clips=3, clip_seed=0, env_id0=0, clips=None, **desc_kw):
     """(OracleBatch, HipBatch) on identical model / clips / seeds."""
     from oracle.oracle import OracleBatch

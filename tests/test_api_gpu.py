@@ -243,3 +243,39 @@ def test_batch_sizes_from_one_env_to_65536():
         assert torch.isfinite(big.obs).all() and torch.isfinite(big.reward).all()
     for x in (ref, one, ragged, big):
         x.close()
+
+
+@pytest.mark.gpu
+def test_bench_gather_branch_in_process():
+    """bench.py's N > 1 exchange (`make_gather`: one RCCL all-gather of the packed head per step) run in-process with world size 1 — the only
+    multi-GPU rehearsal this one-GPU box allows: the gathered block equals `packed_head` byte for byte, for the single-task and the mixed batch.
+    No 1 -> 8 scaling curve exists yet."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import bench
+    from human_robot_gym_amd import mixed
+    from human_robot_gym_amd._lib import HipBatch
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29541")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        clips = hrg.synthetic_clips(3, seed=0, min_frames=200, max_frames=300)
+        G = HipBatch(hrg.build_model_desc(dict(shield_type="SSM", horizon=20, seed=1), n_clips=3), clips, 256)
+        M = mixed.make_mixed_batch(66, seed=1, n_clips=3)
+        for B in (G, M):
+            B.reset()
+            publish, finish, gathered = bench.make_gather(B, 1, "serial")
+            gen = torch.Generator(device="cuda"); gen.manual_seed(0)
+            for k in range(3):
+                B.step(torch.rand((B.n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1)
+                publish(k)
+            finish()
+            torch.cuda.synchronize()
+            assert gathered.numel() == B.packed_head.numel() and torch.equal(gathered, B.packed_head)
+            from human_robot_gym_amd.dist import unpack
+            u = unpack(gathered.cpu().numpy(), B.n)
+            np.testing.assert_array_equal(u["obs"], B.obs.cpu().numpy())
+            np.testing.assert_array_equal(u["done"], B.done.cpu().numpy())
+            B.close()
+    finally:
+        dist.destroy_process_group()

@@ -2,12 +2,12 @@
 import numpy as np
 import pytest
 
-from helpers import ATOL, RTOL, assert_state_close, make_pair
+from helpers import ATOL, RTOL, assert_state_close, make_pair, record_live
 
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(kw, n_envs, n_steps, seed, resync, clips=None, action_fn=None, min_live=0.6):
+def _rollout(kw, n_envs, n_steps, seed, resync, clips=None, action_fn=None, min_live=0.9, name=""):
     """Step oracle and HIP side by side.  An env whose oracle trajectory turns violent (|qvel| > 5 rad/s, e.g. after a
     deep human-robot penetration, or a simulation crash) is chaotic: bit-level agreement of later event counters is
     not a meaningful expectation, so in free-running mode such an env is dropped from then on (counted, bounded)."""
@@ -48,7 +48,7 @@ def _rollout(kw, n_envs, n_steps, seed, resync, clips=None, action_fn=None, min_
                 assert_state_close(post[e], G.get_state(e), f"{msg} env {e}")
             if resync:
                 G.set_state(e, post[e])
-    assert live.mean() > min_live, f"too many envs dropped as chaotic: {live.mean()}"
+    record_live(f"test_parity_gpu::{name or kw.get('shield_type')}{'' if resync else '_free'}", live, min_live)
     O.close(); G.close()
     return n_coll
 
@@ -79,5 +79,5 @@ def test_contacts_and_collisions_occur():
         a[:, 1] = np.where(np.arange(len(a)) % 2 == 0, 1.0, -1.0)  # tilt the arm towards / away from the hand
         a[:, [0, 2, 3, 4, 5]] *= 0.2
         return a
-    n_coll = _rollout(kw, n_envs=16, n_steps=22, seed=5, resync=True, clips=clips, action_fn=act, min_live=0.0)
+    n_coll = _rollout(kw, n_envs=16, n_steps=22, seed=5, resync=True, clips=clips, action_fn=act, min_live=0.0, name="contacts")
     assert n_coll > 0, "scenario was meant to produce collisions"

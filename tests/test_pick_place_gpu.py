@@ -2,13 +2,13 @@
 import numpy as np
 import pytest
 
-from helpers import ATOL, RTOL, assert_state_close, make_pair
+from helpers import ATOL, RTOL, assert_state_close, make_pair, record_live
 from pp_scenarios import PP, deliver, grasp_and_carry, random_actions, tumble
 
 pytestmark = pytest.mark.gpu
 
 
-def _rollout(kw, n_envs, n_steps, seed, scenario, resync, min_live=0.7, **desc_kw):
+def _rollout(kw, n_envs, n_steps, seed, scenario, resync, min_live=0.9, name="", **desc_kw):
     """Oracle and HIP side by side.  resync=True copies the oracle's state into the HIP batch after every step (per-step
     parity); free-running mode drops an env once its oracle trajectory turned violent (see test_parity_gpu._rollout)."""
     import torch
@@ -52,7 +52,7 @@ def _rollout(kw, n_envs, n_steps, seed, scenario, resync, min_live=0.7, **desc_k
             if resync:
                 G.set_state(e, post[e])
                 G.set_box(e, pbox[e])
-    assert live.mean() >= min_live, f"too many envs dropped as chaotic: {live.mean()}"
+    record_live(f"test_pick_place_gpu::{name or getattr(scenario, '__name__', 'scenario')}_{kw.get('shield_type')}{'' if resync else '_free'}", live, min_live)
     desc = O.lib  # keep the library alive until both are closed
     O.close(); G.close()
     del desc
@@ -80,7 +80,7 @@ def test_grasp_free_running_parity():
     import human_robot_gym_amd as hrg
     kw = dict(shield_type="SSM", horizon=200, seed=4)
     d = hrg.build_model_desc(kw, n_clips=3, **PP)
-    st = _rollout(kw, 4, 24, 0, lambda k, b, rng, n: grasp_and_carry(k, b, rng, n, d), resync=False, min_live=0.5)
+    st = _rollout(kw, 4, 24, 0, lambda k, b, rng, n: grasp_and_carry(k, b, rng, n, d), resync=False, min_live=0.5, name="grasp_free")
     assert st["gripped"] > 0
 
 

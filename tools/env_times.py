@@ -1,10 +1,11 @@
 """Diagnostic (-DHRG_STAMPS build): distribution of per-env wave lifetimes within one step launch."""
 import os, sys, ctypes, numpy as np
-os.environ["HRG_LIB_PATH"] = os.path.abspath("human-robot-gym_amd/variant_stamps.so")
 sys.path.insert(0, '.')
 import torch
 import human_robot_gym_amd as hrg
+from human_robot_gym_amd import _lib
 from human_robot_gym_amd._lib import HipBatch, load_library
+_lib.use_variant_library("human-robot-gym_amd/variant_stamps.so")   # the -DHRG_STAMPS diagnostic build
 lib = load_library()
 n = 4096
 clips = hrg.synthetic_clips(13, seed=0)

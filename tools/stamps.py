@@ -1,10 +1,11 @@
 """Diagnostic: per-phase share of wave cycles from the -DHRG_STAMPS build (human-robot-gym_amd/variant_stamps.so)."""
 import os, sys, ctypes, numpy as np
-os.environ["HRG_LIB_PATH"] = os.path.abspath("human-robot-gym_amd/variant_stamps.so")
 sys.path.insert(0, '.')
 import torch
 import human_robot_gym_amd as hrg
+from human_robot_gym_amd import _lib
 from human_robot_gym_amd._lib import HipBatch, load_library
+_lib.use_variant_library("human-robot-gym_amd/variant_stamps.so")   # the -DHRG_STAMPS diagnostic build
 lib = load_library()
 env_id = sys.argv[2] if len(sys.argv) > 2 else "ReachHuman"
 from human_robot_gym_amd.mixed import task_clips

@@ -1,4 +1,4 @@
-"""Kernel time of one task's step at a batch size: python tools/task_time.py ENV_ID N_ENVS [SHIELD] (HRG_LIB_PATH selects a variant build)."""
+"""Kernel time of one task's step at a batch size: python tools/task_time.py ENV_ID N_ENVS [SHIELD] (HRG_TT_LIB=path times a variant build through _lib.use_variant_library)."""
 import os
 import sys
 import time
@@ -7,7 +7,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 import human_robot_gym_amd as hrg  # noqa: E402
 from human_robot_gym_amd import mixed  # noqa: E402
+from human_robot_gym_amd import _lib  # noqa: E402
 from human_robot_gym_amd._lib import HipBatch  # noqa: E402
+
+if os.environ.get("HRG_TT_LIB"):
+    _lib.use_variant_library(os.environ["HRG_TT_LIB"])
 
 env_id = sys.argv[1] if len(sys.argv) > 1 else "HumanRobotHandoverCart"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
@@ -33,5 +37,5 @@ for k in range(40):
 torch.cuda.synchronize()
 dt = time.time() - t0
 ms, nl = G.kernel_time()
-print(f"{env_id} {shield} n={n} lib={os.path.basename(os.environ.get('HRG_LIB_PATH', 'default'))}: {n * 40 / dt / 1e6:.3f} M env steps/s, kernel {ms:.3f} ms x{nl}", flush=True)
+print(f"{env_id} {shield} n={n} lib={os.path.basename(_lib.variant_library() or 'default')}: {n * 40 / dt / 1e6:.3f} M env steps/s, kernel {ms:.3f} ms x{nl}", flush=True)
 G.close()

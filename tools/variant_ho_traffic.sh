@@ -4,13 +4,13 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 for L in "$@"; do
   N=$(basename $L .so)
-  export HRG_LIB_PATH=$R/$L
+  V="--variant-lib $R/$L"
   cd /tmp
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/vho_${N}_fetch -- python3 $R/bench.py --env HumanRobotHandoverCart --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/vho_${N}_fetch.log 2>&1
-  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/vho_${N}_write -- python3 $R/bench.py --env HumanRobotHandoverCart --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/vho_${N}_write.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/vho_${N}_fetch -- python3 $R/bench.py $V --env HumanRobotHandoverCart --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/vho_${N}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/vho_${N}_write -- python3 $R/bench.py $V --env HumanRobotHandoverCart --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/vho_${N}_write.log 2>&1
   cd $R
-  python3 bench.py --env HumanRobotHandoverCart --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/vho_${N}_bench.json
-  python3 bench.py --env RobotHumanHandoverCart --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/vho_${N}_bench_r2h.json
+  python3 bench.py $V --env HumanRobotHandoverCart --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/vho_${N}_bench.json
+  python3 bench.py $V --env RobotHumanHandoverCart --steps 100 --warmup 20 --no-cpu-baseline 2>/dev/null > gpurun_out/vho_${N}_bench_r2h.json
   python3 - <<PY
 import csv, glob, json, os
 v={}

@@ -5,7 +5,7 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 for v in "$@"; do
   for c in WRITE_SIZE FETCH_SIZE; do
     rm -rf /tmp/pmc_$v_$c
-    (cd /tmp && HRG_LIB_PATH=$R/human-robot-gym_amd/variant_$v.so rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${v}_$c -- python3 $R/bench.py --steps 30 --warmup 100 --no-cpu-baseline > /dev/null 2>&1)
+    (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/pmc_${v}_$c -- python3 $R/bench.py --variant-lib $R/human-robot-gym_amd/variant_$v.so --steps 30 --warmup 100 --no-cpu-baseline > /dev/null 2>&1)
     python3 - <<PY
 import csv, glob
 f = glob.glob("/tmp/pmc_${v}_$c/*/*_counter_collection.csv")[0]

@@ -3,13 +3,13 @@
 set -e
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
-export HRG_LIB_PATH=$1
+V="--variant-lib $1"
 T=$2
 cd /tmp
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_fetch -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${T}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_write -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${T}_write.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_fetch -- python3 $R/bench.py $V --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${T}_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${T}_write -- python3 $R/bench.py $V --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${T}_write.log 2>&1
 cd $R
-python3 bench.py --no-cpu-baseline | cut -c1-160
+python3 bench.py $V --no-cpu-baseline | cut -c1-160
 python3 - <<PY
 import csv, glob
 for sub in ("fetch", "write"):
