@@ -219,6 +219,9 @@ class HipVecEnv(_VecEnvBase):
     Args mirror the reference factory (`utils/env_util_SB3.py:19-87`): `env_kwargs` is the dict composed at
     `utils/training_utils.py:71-88`; `seed` plays the role of `seed + rank` (per-env streams are keyed by the
     global env id, so sharding does not change results)."""
+    _norm = None      # (mean, std, squash_factor) of DatasetObsNormWrapper, when configured
+    _monitor = None   # open Monitor csv, when monitor_dir is given
+    _monitor_keys = ()
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,

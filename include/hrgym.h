@@ -72,6 +72,11 @@ extern "C" {
 #define HRG_NCON_DYN_BOX 8 /* ... for tasks with the manipulation object (rows 24 + 32 still fit one wavefront) */
 #define HRG_NBOXV 6       /* free-joint DoF of the manipulation object */
 #define HRG_NVT (HRG_NV + HRG_NBOXV)
+#define HRG_NCUBE 4       /* CollaborativeStackingCart: manipulation_object_a, manipulation_object_b, human_l_cube, human_r_cube
+                           * (collaborative_stacking_cartesian_env.py:1151-1178) */
+#define HRG_NV_STACK (HRG_NV + HRG_NCUBE * HRG_NBOXV) /* DoF of the stacking task's constrained system: robot tree + four free joints */
+#define HRG_NCON_DYN_STACK 23 /* contacts that enter its solve: 8 + 16 + 12 + 4 x 23 = 128 constraint rows = two per lane of a wavefront */
+#define HRG_NROW_STACK 128
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
 #define HRG_MAX_LOOP 4     /* layered sines of an animation loop (utils/animation_utils.py:91-119) */
@@ -91,7 +96,8 @@ enum {
   HRG_INFO_TRUNCATED = 10, /* TimeLimit.truncated (time_limit.py:42) */
   HRG_INFO_SIM_CRASH = 11,
   HRG_INFO_ACTION_RESAMPLES = 12, /* CollisionPreventionWrapper.action_resamples */
-  HRG_INFO_N_OBJECT_HANDED_OVER = 13 /* human_robot_handover_cartesian_env.py:507-511 */
+  HRG_INFO_N_OBJECT_HANDED_OVER = 13, /* human_robot_handover_cartesian_env.py:507-511 */
+  HRG_INFO_MAX_STACK_HEIGHT = 13      /* CollaborativeStackingCart._get_info (673-679): the same (task-specific) column */
 };
 
 /* COLLISION_TYPE flag values, human_env.py:55-77 */
@@ -106,7 +112,8 @@ enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* H
        HRG_TASK_POINTING = 3 /* PickPlacePointingHumanCart: the target is where the human points (pick_place_pointing_human_cartesian_env.py:336-360) */,
        HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */,
        HRG_TASK_HANDOVER_R2H = 5 /* RobotHumanHandoverCart (robot_human_handover_cartesian_env.py) */,
-       HRG_TASK_LIFTING = 6 /* CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board together */ };
+       HRG_TASK_LIFTING = 6 /* CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board together */,
+       HRG_TASK_STACKING = 7 /* CollaborativeStackingCart (collaborative_stacking_cartesian_env.py): human and robot build a stack of four cubes in turns */ };
 #define HRG_IS_HANDOVER(task) ((task) == HRG_TASK_HANDOVER_H2R || (task) == HRG_TASK_HANDOVER_R2H)
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
@@ -114,6 +121,11 @@ enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HR
 enum { HRG_PHASE_PRESENT = 1, HRG_PHASE_WAIT = 2 };
 /* RobotHumanHandoverPhase, robot_human_handover_cartesian_env.py:49-55 */
 enum { HRG_R2H_APPROACH = 0, HRG_R2H_REACH_OUT = 1, HRG_R2H_RETREAT = 2, HRG_R2H_COMPLETE = 3 };
+/* CollaborativeStackingPhase, collaborative_stacking_cartesian_env.py:52-60 */
+enum { HRG_STK_APPROACH = 0, HRG_STK_PLACE_FIRST = 1, HRG_STK_WAIT_FOR_SECOND = 2, HRG_STK_PLACE_THIRD = 3, HRG_STK_WAIT_FOR_FOURTH = 4, HRG_STK_RETREAT = 5,
+       HRG_STK_COMPLETE = 6 };
+/* cube indices of the stacking task (order of `self.objects`, 1176-1180): the robot's two cubes, then the cubes in the human's hands */
+enum { HRG_CUBE_A = 0, HRG_CUBE_B = 1, HRG_CUBE_L = 2, HRG_CUBE_R = 3 };
 
 enum { HRG_GEOM_ROBOT = 0, HRG_GEOM_HUMAN = 1, HRG_GEOM_ALLOWED = 2, HRG_GEOM_STATIC = 3 };
 
@@ -265,6 +277,9 @@ typedef struct hrg_model_desc {
   double ik_pos_limits[2][3];
   double ik_ee_offset[3];       /* end-effector link origin in the link-6 frame: fixed_gripper_joint of robot_pybullet.urdf (0, 0, 0.17) */
   double ik_target_rot[9];      /* end-effector orientation at init_qpos, held fixed (ik_position_delta_wrapper.py:74-82) */
+  /* ---- CollaborativeStackingCart (collaborative_stacking_cartesian_env.py:316-480): box_half / box_mass / box_inertia describe each of the four cubes ---- */
+  double stack_toppled_reward, second_cube_at_target_reward, fourth_cube_at_target_reward; /* _sparse_reward (700-744) */
+  double stack_weld_relpos[3];  /* relpose of the cube <-> hand mocap welds: mocap body origin in the cube frame, "0 0.045 0" (1263-1281) */
   uint64_t seed;
 } hrg_model_desc;
 
@@ -296,6 +311,10 @@ typedef struct hrg_clip_table {
   int32_t clip_n_loop2[HRG_MAX_CLIPS];
   double clip_loop2_amp[HRG_MAX_CLIPS][HRG_MAX_LOOP];
   double clip_loop2_speed[HRG_MAX_CLIPS][HRG_MAX_LOOP];
+  /* stacking clips (collaborative_stacking_cartesian_env.py:512-520, 825-897): five keyframes -- pass the table / release the first cube / first waiting
+   * loop starts / release the third cube / second waiting loop starts; "first_placing_hand" is stored in clip_holding_hand, the loops of
+   * "wait_for_second" / "wait_for_fourth" in clip_loop_* / clip_loop2_* */
+  int32_t clip_stack_keyframes[HRG_MAX_CLIPS][5];
 } hrg_clip_table;
 
 typedef struct hrg_batch hrg_batch; /* opaque */
@@ -347,6 +366,11 @@ int hrg_batch_set_states(hrg_batch* b, const int32_t* envs_host, int32_t n, cons
 size_t hrg_box_bytes(void);
 int hrg_batch_get_box(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
+/* the four cubes + task bookkeeping of CollaborativeStackingCart (hrg_stack_state, include/hrgym_state.h):
+ * CollaborativeStackingCart.get/set_environment_state, collaborative_stacking_cartesian_env.py:1551-1600 */
+size_t hrg_stack_bytes(void);
+int hrg_batch_get_stack(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
+int hrg_batch_set_stack(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 
 /* HumanEnv.check_collision_action (human_env.py:588-627; called by CollisionPreventionWrapper, wrappers/collision_prevention_wrapper.py:38-51, and
  * utils/training_utils.py:362-366): would the joint-space action drive the robot into the static scene or itself?  The goal configuration the

@@ -99,6 +99,27 @@ typedef struct hrg_box_state {
                                        * picks the object up from its own hand; taken at the palm contact in RobotHumanHandoverCart, 730-748) */
 } hrg_box_state;
 
+/* CollaborativeStackingCart: four cubes with free joints, the two hand mocap bodies their welds pull towards, and the task's bookkeeping
+ * (CollaborativeStackingEnvState, collaborative_stacking_cartesian_env.py:63-97).  Kept in its own HBM array, streamed only by that task's kernel;
+ * get/set through hrg_batch_get_stack / hrg_batch_set_stack. */
+typedef struct hrg_stack_state {
+  double pos[HRG_NCUBE][3], quat[HRG_NCUBE][4]; /* free joint qpos, (w,x,y,z); cube order HRG_CUBE_A, _B, _L, _R */
+  double vel[HRG_NCUBE][6];                     /* linear, angular velocity (world frame) */
+  double acc_warmstart[HRG_NCUBE][6];
+  double obs_pos[HRG_NCUBE][3];                 /* body_xpos of the last forward pass (what observables, targets and the toppled test read) */
+  double mocap_pos[2][3], mocap_quat[2][4];     /* lh_mocap_object, rh_mocap_object (905-936), set once per cycle */
+  double target[3];                             /* next_target_position of the last epilogue (522-548); the eef position while there is none (1347-1355) */
+  int32_t obj_index;                            /* _object_placements_list_index */
+  int32_t gripped;                              /* object_gripped sensor (1467-1481) at the last substep */
+  int32_t task_phase;                           /* HRG_STK_* */
+  int32_t n_delayed[2];                         /* _n_delayed_timesteps */
+  int32_t weld_active[2];                       /* eq_active of lh_weld_eq, rh_weld_eq */
+  int32_t n_stack, stack_ids[HRG_NCUBE];        /* _object_stack_body_ids, bottom to top (cube indices) */
+  int32_t max_stack_height;                     /* _max_stack_height */
+  int32_t has_target;                           /* next_target_position is not None */
+  int32_t pad;
+} hrg_stack_state;
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,9 @@
 #define NV HRG_NV
 #define NARM HRG_NARM
 #define NVT HRG_NVT    /* robot tree + free joint of the manipulation object */
-#define NEFC_MAX 64
+#define NEFC_MAX 160   /* the stacking task: 8 + 16 + 12 + 4 x 23 rows */
+#define NVMAX HRG_NV_STACK /* largest constrained system: robot tree + the four cubes of CollaborativeStackingCart */
+#define NCUBE HRG_NCUBE
 #define BODY_BOX 100   /* body code of the manipulation object in contact_t.b1/b2 */
 #define PI 3.14159265358979323846
 #define SIXTH (1.0 / 6.0) /* cubic term of the constant-jerk profiles */
@@ -119,6 +121,7 @@ typedef struct hrgo_batch {
   int64_t env_id0;
   hrg_env_state* st;
   hrg_box_state* box; /* manipulation object per env (unused by ReachHuman) */
+  hrg_stack_state* stk; /* the four cubes + bookkeeping of CollaborativeStackingCart */
   /* parity taps of the last shield cycle */
   double (*rcaps)[HRG_NSHIELD_RCAP][7];
   double (*hcaps)[HRG_NHCAP_MAX][7];
@@ -378,7 +381,8 @@ static double layered_sines(const hrgo_batch* b, int64_t gid, const hrg_env_stat
   return sum - start * (double)(n - 1);
 }
 
-static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, double* mocap_pos, double* mocap_quat, const double** qh) {
+static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, int clip, int* at_io);
+static void human_control_sk(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, hrg_stack_state* sk, double* mocap_pos, double* mocap_quat, const double** qh) {
   const hrg_model_desc* m = &b->m;
   /* human_env.py:1719-1731 */
   int control_time = (int)floor((double)s->low_level_time / m->anim_step_length);
@@ -432,6 +436,7 @@ static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hr
     if (at >= len - 1) { bx->task_phase = HRG_PHASE_COMPLETE; at = len - 1; }
     if (at < 0) at = 0;
   }
+  if (m->task == HRG_TASK_STACKING) stack_animation_time(b, gid, s, sk, clip, &at);
   s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
     s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
@@ -452,6 +457,10 @@ static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hr
   quatmul(q1, s->human_rot_offset, qbi);
   quatmul(mocap_quat, q1, qa);
   *qh = fr + 7;
+}
+
+static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, double* mocap_pos, double* mocap_quat, const double** qh) {
+  human_control_sk(b, gid, s, bx, NULL, mocap_pos, mocap_quat, qh);
 }
 
 static void human_fk(const hrg_model_desc* m, const double* mocap_pos, const double* mocap_quat, const double* qh, human_kin* h, double site[HRG_NHJ][3]) {
@@ -1022,7 +1031,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
 }
 
 /* the manipulation object is whitelisted: COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717) */
-static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g == GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
+static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); } /* GEOM_BOX + c: cube c of the stacking task (1526-1549) */
 static int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; } /* utils/pairing.py:4-16 */
 
 /* HumanEnv._collision_detection + _on_*_detected, human_env.py:966-1123 */
@@ -1067,7 +1076,7 @@ typedef struct {
   int n;
   int type[NEFC_MAX];
   int nv; /* DoF of the system the rows act on: NV, or NVT with the manipulation object */
-  double J[NEFC_MAX][NVT], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
+  double J[NEFC_MAX][NVMAX], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
 } efc_t;
 
 static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* imp, double* K, double* Bd) {
@@ -1130,7 +1139,7 @@ static int row_zone(const efc_t* E, int r, double x) {
 static void solve(const hrg_model_desc* m, const double* M, const double* a0, const efc_t* E, double* a) {
   const int nv = E->nv; /* M is nv x nv, row-major */
   /* a: in = warm start, out = solution */
-  double Ma0[NVT];
+  double Ma0[NVMAX];
   for (int i = 0; i < nv; i++) { double t = 0; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a0[j]; Ma0[i] = t; }
   if (E->n == 0) { memcpy(a, a0, sizeof(double) * nv); return; }
   /* pick the better of warm start and unconstrained acceleration */
@@ -1149,7 +1158,7 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
   }
   if (!(cost_ws < cost_a0)) memcpy(a, a0, sizeof(double) * nv);
   for (int it = 0; it < m->solver_iters; it++) {
-    double x[NEFC_MAX], g[NVT], H[NVT * NVT];
+    double x[NEFC_MAX], g[NVMAX], H[NVMAX * NVMAX];
     for (int i = 0; i < nv; i++) { double t = -Ma0[i]; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a[j]; g[i] = t; }
     memcpy(H, M, sizeof(double) * nv * nv);
     for (int r = 0; r < E->n; r++) {
@@ -1163,7 +1172,7 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
     double gn = 0, sc = 0;
     for (int i = 0; i < nv; i++) { gn += g[i] * g[i]; sc += Ma0[i] * Ma0[i]; }
     if (sqrt(gn) <= m->solver_tol * (1.0 + sqrt(sc))) break;
-    double d[NVT], Md[NVT], p[NEFC_MAX];
+    double d[NVMAX], Md[NVMAX], p[NEFC_MAX];
     for (int i = 0; i < nv; i++) d[i] = -g[i];
     if (!chol(H, nv)) break;
     chol_solve(H, nv, d);
@@ -1501,6 +1510,9 @@ static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
   v3add(eef, k->p[NARM - 1], t);
 }
 
+static void env_reset_stack(hrgo_batch* B, int e, const robot_kin* k);
+static void compute_obs_stack(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, float* obs);
+static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info);
 static void env_reset(hrgo_batch* B, int e, float* obs) {
   const hrg_model_desc* m = &B->m;
   hrg_env_state* s = &B->st[e];
@@ -1533,6 +1545,11 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   eef_of(m, &k, s->eef_pos);
   shield_reset(m, s, s->qpos); /* FailsafeController.reset, failsafe_controller.py:204-250 */
   for (int j = 0; j < NARM; j++) s->goal_qpos[j] = s->qpos[j];
+  if (m->task == HRG_TASK_STACKING) {
+    env_reset_stack(B, e, &k);
+    if (obs) compute_obs_stack(B, gid, s, &B->stk[e], obs);
+    return;
+  }
   hrg_box_state* bx = m->task != HRG_TASK_REACH ? &B->box[e] : NULL;
   if (bx) { /* PickPlaceHumanCart._reset_internal: first object placement and target, object at rest */
     memset(bx, 0, sizeof *bx);
@@ -1581,6 +1598,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
 
 static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
   const hrg_model_desc* m = &B->m;
+  if (m->task == HRG_TASK_STACKING) { env_step_stack(B, e, action, obs, term_obs, reward, done, info); return; }
   hrg_env_state* s = &B->st[e];
   int64_t gid = s->stream_id; /* in-episode draws follow the state's streams (= the env's own id unless the state was copied in) */
   const double h = m->timestep;
@@ -1990,6 +2008,685 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   else memcpy(obs, term_obs, sizeof(float) * HRG_OBS_DIM);
 }
 
+/* =============================================================================================== CollaborativeStackingCart
+ * collaborative_stacking_cartesian_env.py: four cubes with free joints (manipulation_object_a / _b for the robot, human_l_cube / human_r_cube welded to
+ * mocap bodies at the human's hands), box-box contacts between them, the seven-phase animation state machine, stack bookkeeping, rewards.
+ * Geometry / contact stand-ins as for the single cube; cube-cube contacts by separating-axis test + reference-face clipping (D13). */
+#define GEOM_CUBE(c) (GEOM_BOX + (c))
+#define BODY_CUBE(c) (BODY_BOX + (c))
+
+/* CollaborativeStackingCart._compute_animation_time (825-897), applied to the classic animation time *at_io; wave-uniform bookkeeping in sk */
+static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, int clip, int* at_io) {
+  const int classic = *at_io, len = b->clips.clip_len[clip];
+  const int32_t* kf = b->clips.clip_stack_keyframes[clip];
+  int at = classic;
+  if (sk->task_phase == HRG_STK_APPROACH && at > kf[0]) sk->task_phase = HRG_STK_PLACE_FIRST;
+  else if (sk->task_phase == HRG_STK_WAIT_FOR_SECOND) { /* loop until the robot has placed its cube */
+    if (at >= kf[2]) at = (int)layered_sines(b, gid, s, clip, 0, b->clips.clip_n_loop[clip], (double)classic, (double)kf[2]);
+    sk->n_delayed[0] = classic - at; sk->n_delayed[1] = 0;
+  } else if (sk->task_phase == HRG_STK_PLACE_THIRD) at = classic - sk->n_delayed[0];
+  else if (sk->task_phase == HRG_STK_WAIT_FOR_FOURTH) {
+    at = classic - sk->n_delayed[0];
+    if (at >= kf[4]) at = (int)layered_sines(b, gid, s, clip, HRG_MAX_LOOP, b->clips.clip_n_loop2[clip], (double)at, (double)kf[4]);
+    sk->n_delayed[1] = classic - at;
+  } else if (sk->task_phase == HRG_STK_RETREAT) at = classic - sk->n_delayed[1];
+  if (at >= len - 1) { sk->task_phase = HRG_STK_COMPLETE; at = len - 1; }
+  if (at < 0) at = 0;
+  *at_io = at;
+}
+
+/* Contacts of two boxes with the same half extents h (centres pa / pb, rotations Ra / Rb row-major): separating-axis test over the 15 axes; the axis of
+ * least penetration decides.  A face axis: the face of the other box most anti-parallel to it is clipped against the reference face's rectangle --
+ * candidates = incident vertices inside the rectangle (0..3), rectangle corners under the incident face (4..7), crossings of the incident edges with the
+ * rectangle's sides (8..23); of those that penetrate, the extreme one along each diagonal of the reference face is kept (<= 4 contacts, a resting face keeps
+ * its whole support polygon's span).  An edge-edge axis (only when clearly less penetrating, factor 1.05): one contact between the closest points of the two
+ * edges.  Normal from box a to box b.  Stand-in for mjc_BoxBox [UPSTREAM]. */
+typedef struct { double pos[3], n[3], dist; } bb_contact;
+static int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, bb_contact out[4]) {
+  double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
+  v3sub(t, pb, pa);
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = Ra[3 * k + i]; B[i][k] = Rb[3 * k + i]; }
+  for (int i = 0; i < 3; i++) { ta[i] = v3dot(t, A[i]); tb[i] = v3dot(t, B[i]); for (int j = 0; j < 3; j++) { C[i][j] = v3dot(A[i], B[j]); AC[i][j] = fabs(C[i][j]); } }
+  double sf = -1e300, se = -1e300;
+  int bf = 0, be = -1;
+  for (int i = 0; i < 3; i++) {
+    const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
+    if (s_ > 0) return 0;
+    if (s_ > sf) { sf = s_; bf = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
+    if (s_ > 0) return 0;
+    if (s_ > sf) { sf = s_; bf = 3 + j; }
+  }
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+    const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    const double l2 = 1.0 - C[i][j] * C[i][j];
+    if (l2 < 1e-12) continue; /* parallel edges: the face axes cover it */
+    const double l = sqrt(l2);
+    const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j]; /* t . (A_i x B_j) */
+    const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
+    if (s_ > 0) return 0;
+    if (s_ > se) { se = s_; be = 3 * i + j; }
+  }
+  if (be >= 0 && se * 1.05 > sf) { /* edge - edge */
+    const int i = be / 3, j = be % 3;
+    double n[3], pA[3], pB[3], d[3];
+    v3cross(n, A[i], B[j]);
+    v3scl(n, n, 1.0 / v3norm(n));
+    if (v3dot(n, t) < 0) v3scl(n, n, -1.0);
+    v3cpy(pA, pa); v3cpy(pB, pb);
+    for (int k = 0; k < 3; k++) {
+      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * h[k]);
+      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * h[k]);
+    }
+    v3sub(d, pB, pA);
+    const double uaub = C[i][j], q1 = v3dot(A[i], d), q2 = -v3dot(B[j], d), den = 1.0 - uaub * uaub;
+    const double al = (q1 + uaub * q2) / den, be_ = (uaub * q1 + q2) / den;
+    double xa[3], xb[3];
+    v3madd(xa, pA, A[i], al);
+    v3madd(xb, pB, B[j], be_);
+    for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (xa[k] + xb[k]);
+    v3cpy(out[0].n, n);
+    out[0].dist = se;
+    return 1;
+  }
+  /* face: reference box / incident box */
+  const int refA = bf < 3, r = refA ? bf : bf - 3, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+  const double (*Rf)[3] = refA ? A : B;
+  const double (*In)[3] = refA ? B : A;
+  const double* pr = refA ? pa : pb;
+  const double* pi = refA ? pb : pa;
+  const double sg = refA ? (ta[r] >= 0 ? 1.0 : -1.0) : (tb[r] >= 0 ? -1.0 : 1.0); /* reference normal points at the incident box */
+  double nr[3], cr[3], ci[3];
+  v3scl(nr, Rf[r], sg);
+  v3madd(cr, pr, nr, h[r]);
+  int k = 0;
+  double best = -1;
+  for (int q = 0; q < 3; q++) { const double c_ = fabs(v3dot(In[q], nr)); if (c_ > best) { best = c_; k = q; } }
+  const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  const double si = v3dot(In[k], nr) > 0 ? -1.0 : 1.0; /* incident face normal opposes the reference normal */
+  v3madd(ci, pi, In[k], si * h[k]);
+  const double hu = h[r1], hv = h[r2];
+  static const double S1[4] = {1, -1, -1, 1}, S2[4] = {1, 1, -1, -1};
+  double vu[4], vv[4], vd[4];
+  for (int q = 0; q < 4; q++) {
+    double x[3], d[3];
+    v3madd(x, ci, In[k1], S1[q] * h[k1]);
+    v3madd(x, x, In[k2], S2[q] * h[k2]);
+    v3sub(d, x, cr);
+    vu[q] = v3dot(d, Rf[r1]); vv[q] = v3dot(d, Rf[r2]); vd[q] = v3dot(d, nr);
+  }
+  double cu[24], cv[24], cd[24];
+  int ok[24];
+  for (int q = 0; q < 24; q++) ok[q] = 0;
+  for (int q = 0; q < 4; q++) /* incident vertices over the reference rectangle */
+    if (fabs(vu[q]) <= hu && fabs(vv[q]) <= hv) { ok[q] = 1; cu[q] = vu[q]; cv[q] = vv[q]; cd[q] = vd[q]; }
+  { /* rectangle corners under the incident face: the face projects onto the reference plane as the parallelogram c0 + al e1 + be e2, |al|, |be| <= 1 */
+    double d0[3];
+    v3sub(d0, ci, cr);
+    const double c0u = v3dot(d0, Rf[r1]), c0v = v3dot(d0, Rf[r2]), c0d = v3dot(d0, nr);
+    const double e1u = h[k1] * v3dot(In[k1], Rf[r1]), e1v = h[k1] * v3dot(In[k1], Rf[r2]), e1d = h[k1] * v3dot(In[k1], nr);
+    const double e2u = h[k2] * v3dot(In[k2], Rf[r1]), e2v = h[k2] * v3dot(In[k2], Rf[r2]), e2d = h[k2] * v3dot(In[k2], nr);
+    const double det = e1u * e2v - e1v * e2u;
+    if (fabs(det) > 1e-12 * hu * hv)
+      for (int q = 0; q < 4; q++) {
+        const double pu = S1[q] * hu - c0u, pv = S2[q] * hv - c0v;
+        const double al = (pu * e2v - pv * e2u) / det, be_ = (e1u * pv - e1v * pu) / det;
+        if (fabs(al) <= 1 && fabs(be_) <= 1) { ok[4 + q] = 1; cu[4 + q] = S1[q] * hu; cv[4 + q] = S2[q] * hv; cd[4 + q] = c0d + al * e1d + be_ * e2d; }
+      }
+  }
+  for (int q = 0; q < 4; q++) { /* incident edge q -> q + 1 against the four sides of the rectangle */
+    const int q1 = (q + 1) & 3;
+    const double du = vu[q1] - vu[q], dv = vv[q1] - vv[q], dd = vd[q1] - vd[q];
+    for (int e = 0; e < 4; e++) {
+      const int c_ = 8 + 4 * q + e;
+      const double lim = (e & 1) ? -1.0 : 1.0;
+      if (e < 2) { /* u = +-hu */
+        if (fabs(du) < 1e-14) continue;
+        const double tt = (lim * hu - vu[q]) / du, w = vv[q] + tt * dv;
+        if (tt > 0 && tt < 1 && fabs(w) < hv) { ok[c_] = 1; cu[c_] = lim * hu; cv[c_] = w; cd[c_] = vd[q] + tt * dd; }
+      } else { /* v = +-hv */
+        if (fabs(dv) < 1e-14) continue;
+        const double tt = (lim * hv - vv[q]) / dv, w = vu[q] + tt * du;
+        if (tt > 0 && tt < 1 && fabs(w) < hu) { ok[c_] = 1; cu[c_] = w; cv[c_] = lim * hv; cd[c_] = vd[q] + tt * dd; }
+      }
+    }
+  }
+  int pick[4], np_ = 0;
+  for (int q = 0; q < 4; q++) { /* extreme penetrating candidate along each diagonal; ties -> the lowest candidate index */
+    int arg = -1;
+    double bestv = 0;
+    for (int c_ = 0; c_ < 24; c_++) {
+      if (!ok[c_] || !(cd[c_] < 0)) continue;
+      const double val = S1[q] * cu[c_] / hu + S2[q] * cv[c_] / hv;
+      if (arg < 0 || val > bestv) { arg = c_; bestv = val; }
+    }
+    if (arg < 0) break;
+    int dup = 0;
+    for (int z = 0; z < np_; z++) if (pick[z] == arg) dup = 1;
+    if (!dup) pick[np_++] = arg;
+  }
+  for (int z = 0; z < np_; z++) {
+    const int c_ = pick[z];
+    for (int a = 0; a < 3; a++) {
+      out[z].pos[a] = cr[a] + cu[c_] * Rf[r1][a] + cv[c_] * Rf[r2][a] + 0.5 * cd[c_] * nr[a];
+      out[z].n[a] = refA ? nr[a] : -nr[a];
+    }
+    out[z].dist = cd[c_];
+  }
+  return np_;
+}
+
+/* contact list of the stacking task: the robot's own contacts (collide), then per cube c the robot capsules' first points, table corners, floor corners,
+ * then the cube pairs (a < b), then the second points of capsules lying along a face.  object_gripped (1467-1481): a finger pair holds cube A or B --
+ * the reference's `root_body not in _object_stack_body_ids` compares a name with ids and never excludes a stacked cube; restated as it behaves. */
+static int collide_stack(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, hrg_stack_state* sk, contact_t* con) {
+  int n = collide(m, k, h, NULL, con);
+  double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3], Rb[9], Rx[NCUBE][9];
+  quat2mat(Rb, m->base_quat);
+  for (int c = 0; c < HRG_NRCAP; c++) {
+    int b = m->rcap_body[c];
+    const double* R = b < 0 ? Rb : k->R[b];
+    const double* p = b < 0 ? m->base_pos : k->p[b];
+    double t[3];
+    m3mulv(t, R, m->rcap_p1[c]); v3add(rp1[c], p, t);
+    m3mulv(t, R, m->rcap_p2[c]); v3add(rp2[c], p, t);
+  }
+  for (int c = 0; c < NCUBE; c++) quat2mat(Rx[c], sk->quat[c]);
+  const double* hb = m->box_half;
+#define EMIT(G1, G2, B1, B2, DIST, NRM, POS) \
+  do { if (n < HRG_NCON_MAX) { con[n].g1 = G1; con[n].g2 = G2; con[n].b1 = B1; con[n].b2 = B2; con[n].dist = DIST; v3cpy(con[n].n, NRM); v3cpy(con[n].pos, POS); n++; } } while (0)
+  int n_second = 0, second_i[NCUBE * HRG_NRCAP], second_c[NCUBE * HRG_NRCAP];
+  double second_s[NCUBE * HRG_NRCAP][3], second_b[NCUBE * HRG_NRCAP][3];
+  int f0[NCUBE] = {0}, f1[NCUBE] = {0};
+  for (int c = 0; c < NCUBE; c++)
+    for (int i = 0; i < HRG_NRCAP; i++) {
+      if (m->rcap_body[i] < 0) continue;
+      double t, cs[3], cb[3], nn[3], pos[3], s2[2][3], b2[2][3];
+      double e2 = seg_box(rp1[i], rp2[i], sk->pos[c], Rx[c], hb, &t, cs, cb), dd = sqrt(e2), dist = dd - m->rcap_r[i];
+      if (!(dist < 0)) continue;
+      if (dd > 1e-9 && cap_box_two(rp1[i], rp2[i], sk->pos[c], Rx[c], hb, m->rcap_r[i], cs, cb, s2, b2)) {
+        v3cpy(cs, s2[0]); v3cpy(cb, b2[0]);
+        v3sub(nn, cb, cs); dd = v3norm(nn); dist = dd - m->rcap_r[i];
+        second_i[n_second] = i; second_c[n_second] = c; v3cpy(second_s[n_second], s2[1]); v3cpy(second_b[n_second], b2[1]); n_second++;
+      }
+      if (dd > 1e-9) { v3sub(nn, cb, cs); v3scl(nn, nn, 1.0 / dd); }
+      else { /* capsule axis inside the cube: push out through the nearest face */
+        double loc[3], best = 1e300; int ax = 0;
+        v3sub(pos, cs, sk->pos[c]);
+        for (int a = 0; a < 3; a++) { loc[a] = Rx[c][a] * pos[0] + Rx[c][3 + a] * pos[1] + Rx[c][6 + a] * pos[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
+        double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) nn[a] = sg * Rx[c][3 * a + ax];
+        dist = -best - m->rcap_r[i];
+      }
+      v3madd(pos, cs, nn, m->rcap_r[i] + 0.5 * dist);
+      if (n < HRG_NCON_MAX) { f0[c] |= i == HRG_NRCAP - 2; f1[c] |= i == HRG_NRCAP - 1; } /* contacts beyond the reported list do not count */
+      EMIT(i, GEOM_CUBE(c), m->rcap_body[i], BODY_CUBE(c), dist, nn, pos);
+    }
+  for (int pl = 0; pl < 2; pl++)
+    for (int c = 0; c < NCUBE; c++)
+      for (int cn = 0; cn < 8; cn++) {
+        double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]}, p[3];
+        m3mulv(p, Rx[c], loc);
+        v3add(p, p, sk->pos[c]);
+        double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
+        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (dist < 0) {
+          double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
+          EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_CUBE(c), -1, BODY_CUBE(c), dist, nn, pos);
+        }
+      }
+  for (int a = 0; a < NCUBE; a++)
+    for (int b_ = a + 1; b_ < NCUBE; b_++) {
+      double d[3];
+      v3sub(d, sk->pos[b_], sk->pos[a]);
+      const double reach2 = 4.0 * (hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]);
+      if (v3dot(d, d) > reach2) continue; /* circumspheres apart */
+      bb_contact bc[4];
+      const int nc = box_box(sk->pos[a], Rx[a], sk->pos[b_], Rx[b_], hb, bc);
+      for (int q = 0; q < nc; q++) EMIT(GEOM_CUBE(a), GEOM_CUBE(b_), BODY_CUBE(a), BODY_CUBE(b_), bc[q].dist, bc[q].n, bc[q].pos);
+    }
+  for (int q = 0; q < n_second; q++) {
+    const int i = second_i[q], c = second_c[q];
+    double nn[3], pos[3];
+    v3sub(nn, second_b[q], second_s[q]);
+    const double dd = v3norm(nn), dist = dd - m->rcap_r[i];
+    v3scl(nn, nn, 1.0 / dd);
+    v3madd(pos, second_s[q], nn, m->rcap_r[i] + 0.5 * dist);
+    EMIT(i, GEOM_CUBE(c), m->rcap_body[i], BODY_CUBE(c), dist, nn, pos);
+  }
+#undef EMIT
+  sk->gripped = (f0[HRG_CUBE_A] && f1[HRG_CUBE_A]) || (f0[HRG_CUBE_B] && f1[HRG_CUBE_B]);
+  return n;
+}
+
+/* _update_mocap_body_transforms (905-936): each mocap body sits at its hand site, 3 cm towards the thumb (hand z axis), rotated like the hand body
+ * turned by -90 deg (left) / +90 deg (right) about its y axis */
+static void stack_mocap(const hrg_model_desc* m, const hrg_env_state* s, hrg_stack_state* sk, const human_kin* hk) {
+  for (int hd = 0; hd < 2; hd++) {
+    const int site = hd == 0 ? m->site_lhand : m->site_rhand, body = m->meas_body[site];
+    const double ang = hd == 0 ? -0.5 * PI : 0.5 * PI, c = cos(ang), sn = sin(ang);
+    const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c}, ez[3] = {0, 0, 1};
+    double R[9], t[3];
+    m3mulv(t, hk->R[body], ez);
+    for (int a = 0; a < 3; a++) sk->mocap_pos[hd][a] = s->human_site[site][a] + 0.03 * t[a];
+    m3mul(R, hk->R[body], Ry);
+    mat2quat(sk->mocap_quat[hd], R);
+  }
+}
+/* where the weld of hand hd wants its cube: mocap = cube o relpose  =>  cube = mocap o relpose^-1 (relpose = (stack_weld_relpos, identity)) */
+static void stack_weld_target(const hrg_model_desc* m, const hrg_stack_state* sk, int hd, double* pos) {
+  double Rm[9], t[3];
+  quat2mat(Rm, sk->mocap_quat[hd]);
+  m3mulv(t, Rm, m->stack_weld_relpos);
+  v3sub(pos, sk->mocap_pos[hd], t);
+}
+/* _human_pickup_objects (1053-1056): both welds on.  The reference leaves the cubes where they are and lets the soft welds drag them into the hands;
+ * here they are put there directly, at rest (as for the handover object) */
+static void stack_pickup(const hrg_model_desc* m, hrg_stack_state* sk) {
+  for (int hd = 0; hd < 2; hd++) {
+    const int c = HRG_CUBE_L + hd;
+    stack_weld_target(m, sk, hd, sk->pos[c]);
+    for (int a = 0; a < 4; a++) sk->quat[c][a] = sk->mocap_quat[hd][a];
+    for (int a = 0; a < 6; a++) { sk->vel[c][a] = 0; sk->acc_warmstart[c][a] = 0; }
+    v3cpy(sk->obs_pos[c], sk->pos[c]);
+    sk->weld_active[hd] = 1;
+  }
+}
+/* idx-th placement of robot cube c (A or B): UniformRandomSampler over the bin, rotation (0, 0), no overlap test (1188-1194; human_env.py:1221-1270) */
+static void stack_placement(const hrgo_batch* B, int64_t gid, int episode, int idx, int c, double* p) {
+  const hrg_model_desc* m = &B->m;
+  const double u0 = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_OBJECT, (uint64_t)(4 * idx + 2 * c)), u1 = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_OBJECT, (uint64_t)(4 * idx + 2 * c + 1));
+  p[0] = m->obj_bin[0] + (m->obj_bin[1] - m->obj_bin[0]) * u0;
+  p[1] = m->obj_bin[2] + (m->obj_bin[3] - m->obj_bin[2]) * u1;
+  p[2] = m->obj_z;
+}
+/* _reset_animation (991-998) */
+static void stack_reset_animation(const hrg_model_desc* m, hrg_stack_state* sk) {
+  sk->task_phase = HRG_STK_APPROACH;
+  sk->n_delayed[0] = sk->n_delayed[1] = 0;
+  sk->n_stack = 0;
+  for (int a = 0; a < NCUBE; a++) sk->stack_ids[a] = -1;
+  sk->max_stack_height = 0;
+  stack_pickup(m, sk);
+}
+/* next_target_position (522-548): one cube height above the cube the human placed last; returns 0 when it is not the robot's turn */
+static int stack_next_target(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, const hrg_stack_state* sk, double* tgt) {
+  const hrg_model_desc* m = &B->m;
+  const int left = B->clips.clip_holding_hand[clip_of(B, gid, s, s->anim_index)]; /* first_placing_hand */
+  int c = -1;
+  if (sk->task_phase == HRG_STK_WAIT_FOR_SECOND) c = left ? HRG_CUBE_L : HRG_CUBE_R;
+  else if (sk->task_phase == HRG_STK_WAIT_FOR_FOURTH) c = left ? HRG_CUBE_R : HRG_CUBE_L;
+  if (c < 0) return 0;
+  v3cpy(tgt, sk->obs_pos[c]);
+  tgt[2] += 2.0 * m->box_half[2];
+  return 1;
+}
+/* _id_of_cube_at_target (590-610): a robot cube within goal_dist (maximum norm, 612-618) of the target that is not part of the stack; -1 = none */
+static int stack_cube_at_target(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, const hrg_stack_state* sk) {
+  double tgt[3];
+  if (!stack_next_target(B, gid, s, sk, tgt)) return -1;
+  for (int c = HRG_CUBE_A; c <= HRG_CUBE_B; c++) {
+    double dmax = 0;
+    for (int a = 0; a < 3; a++) { const double d = fabs(tgt[a] - sk->obs_pos[c][a]); if (d > dmax) dmax = d; }
+    int in_stack = 0;
+    for (int q = 0; q < sk->n_stack; q++) if (sk->stack_ids[q] == c) in_stack = 1;
+    if (dmax < B->m.goal_dist && !in_stack) return c;
+  }
+  return -1;
+}
+/* _check_first / _check_second_manipulation_object_in_target_zone (620-654) */
+static int stack_first_in_zone(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, const hrg_stack_state* sk) {
+  if (sk->n_stack < 1) return -1;
+  if (sk->n_stack > 1) return sk->stack_ids[1];
+  return stack_cube_at_target(B, gid, s, sk);
+}
+static int stack_second_in_zone(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, const hrg_stack_state* sk) {
+  if (sk->n_stack < 3) return -1;
+  if (sk->n_stack > 3) return sk->stack_ids[3];
+  return stack_cube_at_target(B, gid, s, sk);
+}
+/* _check_stack_toppled (656-671): the centre of a stacked cube below the top of the bottom one */
+static int stack_toppled(const hrg_model_desc* m, const hrg_stack_state* sk) {
+  if (sk->n_stack < 2) return 0;
+  const double min_h = sk->obs_pos[sk->stack_ids[0]][2] + m->box_half[2];
+  for (int q = 1; q < sk->n_stack; q++) if (sk->obs_pos[sk->stack_ids[q]][2] < min_h) return 1;
+  return 0;
+}
+
+/* _setup_observables (1306-1524) in the columns of the observation superset: vec_eef_to_all_objects (a, b, l, r) takes the 12 joint-space columns the cube
+ * tasks leave empty ([12:18] + [33:39]); object_gripped 39, vec_eef_to_object 40:43 (the cube the robot has to place next: b, then a), vec_eef_to_target
+ * 43:46, gripper_aperture 46, that cube's position 47:50, next_target_pos 50:53 (the eef position while there is no target) */
+static void compute_obs_stack(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, float* obs) {
+  const hrg_model_desc* m = &B->m;
+  double goal[NARM] = {0};
+  compute_obs(m, s, NULL, goal, obs);
+  double tgt[3];
+  sk->has_target = stack_next_target(B, gid, s, sk, tgt);
+  if (!sk->has_target) v3cpy(tgt, s->eef_pos);
+  v3cpy(sk->target, tgt);
+  for (int c = 0; c < NCUBE; c++)
+    for (int a = 0; a < 3; a++) obs[(c < 2 ? 12 : 33) + 3 * (c & 1) + a] = (float)(sk->obs_pos[c][a] - s->eef_pos[a]);
+  const int nxt = sk->n_stack >= 2 ? HRG_CUBE_A : HRG_CUBE_B; /* vec_eef_to_object (1445-1456) */
+  obs[39] = (float)sk->gripped;
+  double ap = 0;
+  for (int f = 0; f < HRG_NFINGER; f++) ap += (s->qpos[NARM + f] - m->finger_qpos_range[0][f]) / (m->finger_qpos_range[1][f] - m->finger_qpos_range[0][f]);
+  obs[46] = (float)(ap / HRG_NFINGER);
+  for (int a = 0; a < 3; a++) {
+    obs[40 + a] = (float)(sk->obs_pos[nxt][a] - s->eef_pos[a]);
+    obs[43 + a] = (float)(tgt[a] - s->eef_pos[a]);
+    obs[47 + a] = (float)sk->obs_pos[nxt][a];
+    obs[50 + a] = (float)tgt[a];
+  }
+}
+
+/* CollaborativeStackingCart._reset_internal (938-959) after the common part of env_reset */
+static void env_reset_stack(hrgo_batch* B, int e, const robot_kin* k) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  hrg_stack_state* sk = &B->stk[e];
+  const int64_t gid = B->env_id0 + e;
+  (void)k;
+  memset(sk, 0, sizeof *sk);
+  for (int c = HRG_CUBE_A; c <= HRG_CUBE_B; c++) {
+    stack_placement(B, gid, s->episode, 0, c, sk->pos[c]);
+    sk->quat[c][0] = 1;
+    v3cpy(sk->obs_pos[c], sk->pos[c]);
+  }
+  human_kin hk;
+  double mp[3], mq[4];
+  const double* qh;
+  human_control_sk(B, gid, s, NULL, sk, mp, mq, &qh); /* _reset_animation + _control_human: phase APPROACH, the human holds both cubes */
+  human_fk(m, mp, mq, qh, &hk, s->human_site);
+  stack_mocap(m, s, sk, &hk);
+  stack_reset_animation(m, sk);
+}
+
+static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  hrg_stack_state* sk = &B->stk[e];
+  int64_t gid = s->stream_id;
+  const double h = m->timestep;
+  if (m->ik_enabled) ik_action(m, s, action);
+  screen_action(B, gid, s, action);
+  s->timestep += 1;
+  int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
+  robot_kin k;
+  human_kin hk;
+  double M[NV * NV], bias[NV];
+  for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
+    robot_fk(m, s->qpos, &k);
+    robot_crba(m, &k, M);
+    robot_bias(m, &k, s->qvel, bias);
+    if (cyc == 0) { /* failsafe_controller.py:252-300 */
+      for (int i = 0; i < NARM; i++) for (int j = 0; j < NARM; j++) s->mass_matrix[i * NARM + j] = M[i * NV + j];
+      double scale = fabs(m->act_out_max - m->act_out_min) / fabs(m->act_in_max - m->act_in_min);
+      double otr = 0.5 * (m->act_out_max + m->act_out_min), itr = 0.5 * (m->act_in_max + m->act_in_min);
+      for (int j = 0; j < NARM; j++) {
+        double a = clampd(action[j], m->act_in_min, m->act_in_max);
+        double g = s->qpos[j] + ((a - itr) * scale + otr);
+        s->goal_qpos[j] = clampd(g, m->qpos_limits[0][j], m->qpos_limits[1][j]);
+        s->new_goal_q[j] = s->goal_qpos[j];
+      }
+      s->new_goal = 1;
+    }
+    shield_step(B, e, s->time);
+    double ctrl[NV];
+    for (int i = 0; i < NARM; i++) {
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += s->mass_matrix[i * NARM + j] * (m->kp * (s->des_q[j] - s->qpos[j]) + m->kd * (s->des_v[j] - s->qvel[j]) + s->des_a[j]);
+      ctrl[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
+    }
+    {
+      double a = action[NARM], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
+      s->grip_action = clampd(s->grip_action - m->gripper_speed * sg, -1.0, 1.0);
+      for (int f = 0; f < HRG_NFINGER; f++) {
+        double lo = m->finger_ctrlrange[f][0], hi = m->finger_ctrlrange[f][1];
+        ctrl[NARM + f] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (f == 0 ? s->grip_action : -s->grip_action);
+      }
+    }
+    if (!failsafe_intervention && !s->is_safe) { failsafe_intervention = 1; s->failsafe_interventions++; }
+    /* _control_human (899-903): super + sim.forward() + the two hand mocap bodies */
+    double mp[3], mq[4];
+    const double* qh;
+    human_control_sk(B, gid, s, NULL, sk, mp, mq, &qh);
+    human_fk(m, mp, mq, qh, &hk, s->human_site);
+    stack_mocap(m, s, sk, &hk);
+    contact_t con[HRG_NCON_MAX];
+    int ncon = collide_stack(m, &k, &hk, sk, con);
+    double rc[HRG_NRCAP][3], Rb[9];
+    quat2mat(Rb, m->base_quat);
+    for (int c = 0; c < HRG_NRCAP; c++) {
+      int b = m->rcap_body[c];
+      double t[3], mid[3];
+      for (int a = 0; a < 3; a++) mid[a] = 0.5 * (m->rcap_p1[c][a] + m->rcap_p2[c][a]);
+      m3mulv(t, b < 0 ? Rb : k.R[b], mid);
+      v3add(rc[c], b < 0 ? m->base_pos : k.p[b], t);
+    }
+    classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
+    s->ncon = ncon;
+    for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
+    /* ---- sim.step(): robot tree + four free cubes (block-diagonal M; cubes: m 1, R diag(I) R' with the mean / deviation split of the single cube) ---- */
+    double LM[NV * NV], a0[NVMAX], qd[NVMAX], frc[NV];
+    static const int NVK = NVMAX;
+    double* Mt = (double*)calloc((size_t)NVK * NVK, sizeof(double));
+    memcpy(LM, M, sizeof LM);
+    if (!chol(LM, NV)) { crash = 1; free(Mt); break; }
+    for (int i = 0; i < NV; i++) {
+      double act = ctrl[i];
+      if (i >= NARM) act = clampd(m->finger_kp * (ctrl[i] - s->qpos[i]), m->finger_forcerange[0], m->finger_forcerange[1]);
+      frc[i] = act - m->jnt_damping[i] * s->qvel[i] - bias[i];
+      a0[i] = frc[i];
+      qd[i] = s->qvel[i];
+    }
+    chol_solve(LM, NV, a0);
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Mt[i * NVK + j] = M[i * NV + j];
+    for (int c = 0; c < NCUBE; c++) {
+      const int o = NV + 6 * c;
+      double Rx[9], Mdev[9], w[3] = {sk->vel[c][3], sk->vel[c][4], sk->vel[c][5]}, Ld[3], Lw[3], tau[3], tl[3];
+      quat2mat(Rx, sk->quat[c]);
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
+        double t = 0;
+        for (int kk = 0; kk < 3; kk++) t += Rx[3 * i + kk] * (m->box_inertia[kk] - m->box_inertia_mean) * Rx[3 * j + kk];
+        Mdev[3 * i + j] = t;
+      }
+      for (int kk = 0; kk < 3; kk++) Ld[kk] = (m->box_inertia[kk] - m->box_inertia_mean) * (Rx[kk] * w[0] + Rx[3 + kk] * w[1] + Rx[6 + kk] * w[2]);
+      m3mulv(Lw, Rx, Ld);
+      v3cross(tau, Lw, w);
+      for (int kk = 0; kk < 3; kk++) tl[kk] = (Rx[kk] * tau[0] + Rx[3 + kk] * tau[1] + Rx[6 + kk] * tau[2]) / m->box_inertia[kk];
+      for (int a = 0; a < 3; a++) {
+        Mt[(o + a) * NVK + o + a] = m->box_mass;
+        for (int b = 0; b < 3; b++) Mt[(o + 3 + a) * NVK + o + 3 + b] = (a == b ? m->box_inertia_mean : 0.0) + Mdev[3 * a + b];
+        a0[o + a] = m->gravity[a];
+        a0[o + 3 + a] = Rx[3 * a] * tl[0] + Rx[3 * a + 1] * tl[1] + Rx[3 * a + 2] * tl[2];
+      }
+      for (int a = 0; a < 6; a++) qd[o + a] = sk->vel[c][a];
+    }
+    efc_t* E = (efc_t*)malloc(sizeof(efc_t));
+    E->n = 0;
+    E->nv = NVK;
+    for (int i = 0; i < NV; i++)
+      if (m->jnt_frictionloss[i] > 0) { double J[NVMAX] = {0}; J[i] = 1; efc_add(m, E, J, qd, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i], m->dof_invweight0[i]); }
+    for (int i = 0; i < NV; i++) {
+      double dlo = s->qpos[i] - m->jnt_range[i][0], dhi = m->jnt_range[i][1] - s->qpos[i];
+      if (dlo < 0) { double J[NVMAX] = {0}; J[i] = 1; efc_add(m, E, J, qd, ROW_UNILATERAL, dlo, 0, 0, m->dof_invweight0[i]); }
+      if (dhi < 0) { double J[NVMAX] = {0}; J[i] = -1; efc_add(m, E, J, qd, ROW_UNILATERAL, dhi, 0, 0, m->dof_invweight0[i]); }
+    }
+    for (int c = 0; c < ncon && c < HRG_NCON_DYN_STACK; c++) {
+      const double* n = con[c].n;
+      double t1[3], t2[3], e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+      v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+      v3scl(t1, t1, 1.0 / v3norm(t1));
+      v3cross(t2, n, t1);
+      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      for (int d = 0; d < 4; d++) {
+        double dir[3], J[NVMAX] = {0};
+        const double* tt = d < 2 ? t1 : t2;
+        double sg = (d & 1) ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m->friction_static * tt[a];
+        if (con[c].b1 >= 0 && con[c].b1 < NV) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
+        if (con[c].b2 >= 0 && con[c].b2 < NV) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
+        double diag = (con[c].b1 >= 0 && con[c].b1 < NV ? m->body_invweight0[con[c].b1] : 0.0) + (con[c].b2 >= 0 && con[c].b2 < NV ? m->body_invweight0[con[c].b2] : 0.0);
+        for (int side = 0; side < 2; side++) { /* free bodies: J = +-dir . (v + w x r), body_invweight0 = 1/m */
+          const int body = side ? con[c].b2 : con[c].b1;
+          if (body < BODY_BOX) continue;
+          const int cb = body - BODY_BOX, o = NV + 6 * cb;
+          const double sgn = side ? 1.0 : -1.0;
+          double r[3], rxd[3];
+          v3sub(r, con[c].pos, sk->pos[cb]);
+          v3cross(rxd, r, dir);
+          for (int a = 0; a < 3; a++) { J[o + a] = sgn * dir[a]; J[o + 3 + a] = sgn * rxd[a]; }
+          diag += 1.0 / m->box_mass;
+        }
+        efc_add(m, E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
+      }
+    }
+    for (int hd = 0; hd < 2; hd++) { /* lh_weld_eq / rh_weld_eq (1255-1284): residual [p_cube - p_target; rotation vector of q_cube q_mocap^-1] on the cube's own DoF */
+      if (!sk->weld_active[hd]) continue;
+      const int cb = HRG_CUBE_L + hd, o = NV + 6 * cb;
+      double tp[3], epos[3], erot[3], qe[4];
+      stack_weld_target(m, sk, hd, tp);
+      v3sub(epos, sk->pos[cb], tp);
+      double qc[4] = {sk->mocap_quat[hd][0], -sk->mocap_quat[hd][1], -sk->mocap_quat[hd][2], -sk->mocap_quat[hd][3]};
+      quatmul(qe, sk->quat[cb], qc);
+      if (qe[0] < 0) for (int a = 0; a < 4; a++) qe[a] = -qe[a];
+      const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+      for (int a = 0; a < 3; a++) erot[a] = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
+      for (int a = 0; a < 3; a++) { double J[NVMAX] = {0}; J[o + a] = 1; efc_add(m, E, J, qd, ROW_EQUALITY, epos[a], 0, 0, 1.0 / m->box_mass); }
+      for (int a = 0; a < 3; a++) { double J[NVMAX] = {0}; J[o + 3 + a] = 1; efc_add(m, E, J, qd, ROW_EQUALITY, erot[a], 0, 0, m->box_invweight_rot); }
+    }
+    double qacc[NVMAX];
+    memcpy(qacc, s->qacc_warmstart, sizeof(double) * NV);
+    for (int c = 0; c < NCUBE; c++) memcpy(qacc + NV + 6 * c, sk->acc_warmstart[c], sizeof(double) * 6);
+    solve(m, Mt, a0, E, qacc);
+    if (g_debug && (ncon > 0 || g_debug > 1)) {
+      double mx = 0; for (int i = 0; i < NVK; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
+      fprintf(stderr, "[oracle stack] env %d cyc %d ncon %d nefc %d max|qacc| %.3e", e, cyc, ncon, E->n, mx);
+      for (int c = 0; c < ncon; c++) fprintf(stderr, " (%d,%d d=%.5f)", con[c].g1, con[c].g2, con[c].dist);
+      fprintf(stderr, "\n");
+    }
+    free(E); free(Mt);
+    for (int i = 0; i < NVK; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
+    if (crash) break;
+    memcpy(s->qacc_warmstart, qacc, sizeof(double) * NV);
+    double Mh[NV * NV], rhs[NV];
+    memcpy(Mh, M, sizeof Mh);
+    for (int i = 0; i < NV; i++) { Mh[i * NV + i] += h * m->jnt_damping[i]; double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * qacc[j]; rhs[i] = t; }
+    if (!chol(Mh, NV)) { crash = 1; break; }
+    chol_solve(Mh, NV, rhs);
+    for (int i = 0; i < NV; i++) { s->qvel[i] += h * rhs[i]; s->qpos[i] += h * s->qvel[i]; }
+    for (int c = 0; c < NCUBE; c++) {
+      memcpy(sk->acc_warmstart[c], qacc + NV + 6 * c, sizeof(double) * 6);
+      v3cpy(sk->obs_pos[c], sk->pos[c]);
+      for (int a = 0; a < 6; a++) sk->vel[c][a] += h * qacc[NV + 6 * c + a];
+      for (int a = 0; a < 3; a++) sk->pos[c][a] += h * sk->vel[c][a];
+      double w[3] = {sk->vel[c][3], sk->vel[c][4], sk->vel[c][5]}, wn = v3norm(w), ang = h * wn;
+      if (wn > 1e-12) {
+        double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w[0] * sh, w[1] * sh, w[2] * sh}, qn[4];
+        quatmul(qn, dq, sk->quat[c]);
+        double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (int a = 0; a < 4; a++) sk->quat[c][a] = qn[a] / nn;
+      }
+    }
+    s->time += h;
+    eef_of(m, &k, s->eef_pos);
+    s->low_level_time += 1;
+  }
+  /* ---- observation, success, info, reward, done ---- */
+  compute_obs_stack(B, gid, s, sk, term_obs);
+  const int goal_reached = !crash && sk->task_phase == HRG_STK_COMPLETE; /* _check_success (746-756) */
+  const int toppled = stack_toppled(m, sk);
+  double r;
+  if (goal_reached) r = m->task_reward; /* _sparse_reward (700-744) */
+  else if (toppled) r = m->stack_toppled_reward;
+  else {
+    if (stack_second_in_zone(B, gid, s, sk) >= 0) r = m->fourth_cube_at_target_reward;
+    else if (stack_first_in_zone(B, gid, s, sk) >= 0) r = m->second_cube_at_target_reward;
+    else r = -1.0;
+    if (sk->gripped) r += m->object_gripped_reward;
+  }
+  if (goal_reached) s->n_goal_reached++;
+  int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0;
+  if (m->reward_shaping) r += 1.0 + 0.0; /* _dense_reward is a TODO returning 0 (681-698) */
+  if (illegal) r += m->collision_reward;
+  r *= m->reward_scale;
+  int d = 0;
+  if (crash) { r += m->sim_crash_reward; d = 1; }
+  else {
+    if (toppled) d = 1; /* _check_done (758-778) */
+    if (m->done_at_collision && illegal) d = 1;
+    if (m->done_at_success && goal_reached) d = 1;
+  }
+  int ncoll = s->n_collisions_static + s->n_collisions_robot + s->n_collisions_human + s->n_collisions_critical;
+  info[HRG_INFO_COLLISION] = has_collision;
+  info[HRG_INFO_COLLISION_TYPE] = collision_type;
+  info[HRG_INFO_N_COLLISIONS] = ncoll;
+  info[HRG_INFO_N_COLLISIONS_STATIC] = s->n_collisions_static;
+  info[HRG_INFO_N_COLLISIONS_ROBOT] = s->n_collisions_robot;
+  info[HRG_INFO_N_COLLISIONS_HUMAN] = s->n_collisions_human;
+  info[HRG_INFO_N_COLLISIONS_CRITICAL] = s->n_collisions_critical;
+  info[HRG_INFO_TIMEOUT] = s->timestep >= m->horizon;
+  info[HRG_INFO_FAILSAFE_INTERVENTIONS] = s->failsafe_interventions;
+  info[HRG_INFO_N_GOAL_REACHED] = s->n_goal_reached;
+  info[HRG_INFO_SIM_CRASH] = crash;
+  info[HRG_INFO_TRUNCATED] = 0;
+  info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
+  info[HRG_INFO_MAX_STACK_HEIGHT] = sk->max_stack_height; /* _get_info (673-679): the value before this step's transitions */
+  /* ---- CollaborativeStackingCart.step tail (550-588) ---- */
+  if (goal_reached && !m->done_at_success && !d) { /* _on_goal_reached (961-977): next placements of the robot's cubes (velocities kept), next animation */
+    sk->obj_index = (sk->obj_index + 1) % m->n_obj_placements;
+    for (int c = HRG_CUBE_A; c <= HRG_CUBE_B; c++) {
+      stack_placement(B, gid, s->episode, sk->obj_index, c, sk->pos[c]);
+      sk->quat[c][0] = 1; sk->quat[c][1] = sk->quat[c][2] = sk->quat[c][3] = 0;
+    }
+    s->anim_index = (s->anim_index + 1) % m->n_anim_ids;
+    s->animation_time = 0;
+    s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+    sk->task_phase = HRG_STK_APPROACH; sk->n_delayed[0] = sk->n_delayed[1] = 0;
+    human_kin hk2;
+    double mp[3], mq[4];
+    const double* qh;
+    human_control_sk(B, gid, s, NULL, sk, mp, mq, &qh);
+    human_fk(m, mp, mq, qh, &hk2, s->human_site);
+    stack_mocap(m, s, sk, &hk2);
+    stack_reset_animation(m, sk);
+  }
+  if (!d) {
+    const int left = B->clips.clip_holding_hand[clip_of(B, gid, s, s->anim_index)]; /* first_placing_hand */
+    const int32_t* kf = B->clips.clip_stack_keyframes[clip_of(B, gid, s, s->anim_index)];
+    int body;
+    if (sk->task_phase == HRG_STK_PLACE_FIRST && s->animation_time > kf[1]) { /* _human_place_first_object (1004-1011) */
+      const int hd = left ? 0 : 1;
+      sk->stack_ids[sk->n_stack++] = HRG_CUBE_L + hd;
+      sk->weld_active[hd] = 0;
+      sk->task_phase = HRG_STK_WAIT_FOR_SECOND;
+    } else if (sk->task_phase == HRG_STK_WAIT_FOR_SECOND && (body = stack_first_in_zone(B, gid, s, sk)) >= 0 && !sk->gripped) {
+      sk->task_phase = HRG_STK_PLACE_THIRD;
+      sk->stack_ids[sk->n_stack++] = body;
+    } else if (sk->task_phase == HRG_STK_PLACE_THIRD && s->animation_time > kf[3]) { /* _human_place_third_object (1013-1043): released directly above the second cube */
+      const int hd = left ? 1 : 0, c = HRG_CUBE_L + hd;
+      sk->weld_active[hd] = 0;
+      v3cpy(sk->pos[c], sk->obs_pos[sk->stack_ids[1]]);
+      sk->pos[c][2] += 2.0 * m->box_half[2];
+      sk->quat[c][0] = 1; sk->quat[c][1] = sk->quat[c][2] = sk->quat[c][3] = 0;
+      for (int a = 0; a < 6; a++) sk->vel[c][a] = 0;
+      sk->stack_ids[sk->n_stack++] = c;
+      sk->task_phase = HRG_STK_WAIT_FOR_FOURTH;
+    } else if (sk->task_phase == HRG_STK_WAIT_FOR_FOURTH && (body = stack_second_in_zone(B, gid, s, sk)) >= 0 && !sk->gripped) {
+      sk->task_phase = HRG_STK_RETREAT;
+      sk->stack_ids[sk->n_stack++] = body;
+    }
+    if (sk->n_stack > sk->max_stack_height) sk->max_stack_height = sk->n_stack;
+  }
+  if (s->timestep >= m->horizon) { info[HRG_INFO_TRUNCATED] = !d; d = 1; }
+  *reward = (float)r;
+  *done = (uint8_t)d;
+  if (d) env_reset(B, e, obs);
+  else memcpy(obs, term_obs, sizeof(float) * HRG_OBS_DIM);
+}
+
 /* =============================================================================================== API */
 int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, hrgo_batch** out) {
   hrgo_batch* B = (hrgo_batch*)calloc(1, sizeof *B);
@@ -2002,6 +2699,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
   B->env_id0 = env_id0;
   B->st = (hrg_env_state*)calloc((size_t)n_envs, sizeof(hrg_env_state));
   B->box = (hrg_box_state*)calloc((size_t)n_envs, sizeof(hrg_box_state));
+  B->stk = (hrg_stack_state*)calloc((size_t)n_envs, sizeof(hrg_stack_state));
   B->rcaps = calloc((size_t)n_envs, sizeof *B->rcaps);
   B->hcaps = calloc((size_t)n_envs, sizeof *B->hcaps);
   B->n_hcaps = calloc((size_t)n_envs, sizeof(int32_t));
@@ -2011,7 +2709,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
 }
 void hrgo_destroy(hrgo_batch* B) {
   if (!B) return;
-  free(B->frames); free(B->st); free(B->box); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
+  free(B->frames); free(B->st); free(B->box); free(B->stk); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
 }
 int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
   for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
@@ -2088,6 +2786,26 @@ int hrgo_set_box(hrgo_batch* B, int e, const void* buf, size_t bytes) {
   if (bytes != sizeof(hrg_box_state)) return -1;
   memcpy(&B->box[e], buf, bytes);
   return 0;
+}
+int hrgo_get_stack(hrgo_batch* B, int e, void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_stack_state)) return -1;
+  memcpy(buf, &B->stk[e], bytes);
+  return 0;
+}
+int hrgo_set_stack(hrgo_batch* B, int e, const void* buf, size_t bytes) {
+  if (bytes != sizeof(hrg_stack_state)) return -1;
+  memcpy(&B->stk[e], buf, bytes);
+  return 0;
+}
+size_t hrgo_stack_bytes(void) { return sizeof(hrg_stack_state); }
+/* known-answer tap: contacts of two equal boxes (tests/test_stacking.py); out = n x [pos 3, normal 3, dist] */
+int hrgo_test_boxbox(const double* pa, const double* qa, const double* pb, const double* qb, const double* half, double* out) {
+  double Ra[9], Rb[9];
+  bb_contact bc[4];
+  quat2mat(Ra, qa); quat2mat(Rb, qb);
+  const int n = box_box(pa, Ra, pb, Rb, half, bc);
+  for (int q = 0; q < n; q++) { for (int a = 0; a < 3; a++) { out[7 * q + a] = bc[q].pos[a]; out[7 * q + 3 + a] = bc[q].n[a]; } out[7 * q + 6] = bc[q].dist; }
+  return n;
 }
 size_t hrgo_state_bytes(void) { return sizeof(hrg_env_state); }
 size_t hrgo_box_bytes(void) { return sizeof(hrg_box_state); }
