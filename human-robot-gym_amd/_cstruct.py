@@ -76,6 +76,7 @@ LTT = _STRUCTS["hrg_ltt"]
 Path = _STRUCTS["hrg_path"]
 EnvState = _STRUCTS["hrg_env_state"]
 BoxState = _STRUCTS["hrg_box_state"]
+StackState = _STRUCTS["hrg_stack_state"]
 
 
 def struct_to_dict(s):

@@ -65,7 +65,23 @@ class ClipSet:
             info = self.infos[i]
             t.clip_pointing_hand[i] = int(info.get("pointing_hand", "right") == "left")   # pick_place_pointing_human_cartesian_env.py:344-347
             t.clip_holding_hand[i] = int(info.get("object_holding_hand", "right") == "left")   # human_robot_handover_cartesian_env.py:459-463
-            if "keyframes" in info:   # animation info of the collaboration tasks (human_object_inspection_cartesian_env.py:447-459, 602-652)
+            if "first_placing_hand" in info:   # stacking clips (collaborative_stacking_cartesian_env.py:512-520): five keyframes, two waiting loops
+                amps, speeds = info.get("loop_amplitudes", {}), info.get("loop_speeds", {})
+                kf = [int(x) for x in info["keyframes"]]
+                if len(kf) < 5 or set(amps) != {"wait_for_second", "wait_for_fourth"}:
+                    raise NotImplementedError("stacking animation info: five keyframes and the loops 'wait_for_second' / 'wait_for_fourth'")
+                t.clip_stack_keyframes[i][:] = kf[:5]
+                t.clip_holding_hand[i] = int(info["first_placing_hand"] == "left")
+                for stage, (na, aa, ss) in (("wait_for_second", (None, t.clip_loop_amp, t.clip_loop_speed)), ("wait_for_fourth", (None, t.clip_loop2_amp, t.clip_loop2_speed))):
+                    a_, s_ = amps[stage], speeds[stage]
+                    if len(a_) > CONST["HRG_MAX_LOOP"] or len(a_) != len(s_):
+                        raise NotImplementedError("animation info: up to 4 layered loop sines per stage")
+                    for k in range(len(a_)):
+                        aa[i][k], ss[i][k] = float(a_[k]), float(s_[k])
+                t.clip_n_loop[i], t.clip_n_loop2[i] = len(amps["wait_for_second"]), len(amps["wait_for_fourth"])
+                t.clip_loop_amp_std[i] = float(info.get("loop_amplitude_std_factor", 1.0))
+                t.clip_loop_speed_std[i] = float(info.get("loop_speed_std_factor", 1.0))
+            elif "keyframes" in info:   # animation info of the collaboration tasks (human_object_inspection_cartesian_env.py:447-459, 602-652)
                 amps, speeds = info.get("loop_amplitudes", []), info.get("loop_speeds", [])
                 if isinstance(amps, dict) and set(amps) == {"present", "wait"}:   # handover clips: two loop stages (440-457)
                     a2, s2 = amps["wait"], speeds["wait"]
@@ -136,7 +152,7 @@ def hand_sites(frames, info):
 
 
 def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None, lift_height=0.7,
-                    choreographed=False):
+                    choreographed=False, stacking=False):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -177,6 +193,10 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         elif handover:  # stand-in for the HumanRobotHandover/* info files: present from 30 %, wait at 60 %, two loop stages
             info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
+                        loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        if stacking:   # stand-in for the CollaborativeStacking/* info files: keyframes at 15 / 25 / 35 / 55 / 65 % of the clip, alternating first hand, two waiting loops
+            info.update(keyframes=[int(f * n) for f in (0.15, 0.25, 0.35, 0.55, 0.65)], first_placing_hand="left" if len(clips) % 2 else "right",
+                        loop_amplitudes=dict(wait_for_second=[15.0, 5.0], wait_for_fourth=[12.0]), loop_speeds=dict(wait_for_second=[1.0, 0.5], wait_for_fourth=[0.8]),
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
         if handover and choreographed:
             # a handover one can act on: the human stands still 1.2 m in front of the robot, facing it, arms down; between the keyframes the

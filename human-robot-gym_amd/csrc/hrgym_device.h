@@ -34,8 +34,15 @@
 #ifndef HRG_HANDOVER
 #define HRG_HANDOVER 0
 #endif
+#ifndef HRG_STACK
+#define HRG_STACK 0   // HRG_STACK=1 (hrgym_stack.hip, HRG_BOX=0): CollaborativeStackingCart -- four free cubes, box-box contacts, two welds; its own collision tail and solver
+#endif
 #define NVT HRG_NVT
-#if HRG_BOX
+#if HRG_STACK
+#define NVS HRG_NV_STACK        // robot tree + four free joints
+#define NCON_DYN HRG_NCON_DYN_STACK
+#define NCUBE HRG_NCUBE
+#elif HRG_BOX
 #define NVS NVT                 // DoF of the constrained system: robot tree + free joint of the cube
 #define NCON_DYN HRG_NCON_DYN_BOX
 #else
@@ -114,7 +121,7 @@
 #define GEOM_HUMAN0 HRG_NRCAP
 #define GEOM_TABLE (HRG_NRCAP + HRG_NHB)
 #define GEOM_FLOOR (GEOM_TABLE + 1)
-#define GEOM_BOX (GEOM_FLOOR + 1)
+#define GEOM_BOX (GEOM_FLOOR + 1)   // stacking: GEOM_BOX + c = cube c, BODY_BOX + c its body code
 
 // ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
 #ifdef HRG_STAMPS
@@ -175,7 +182,12 @@ struct Contact {
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
 #define ROW_WELD0 (ROW_CON0 + 4 * NCON_DYN)   // 6 equality rows of the object <-> hand weld (cube variant: lanes 56..61)
-#if HRG_BOX && (HRG_HANDOVER || HRG_LIFT)
+#if HRG_STACK
+// stacking: two rows per lane -- 0..7 friction loss | 8..23 joint limits | 24..35 the two welds (hand, component) | 36..127 contacts x 4 pyramid edges
+#define SROW_WELD0 24
+#define SROW_CON0 36
+#define NROW HRG_NROW_STACK
+#elif HRG_BOX && (HRG_HANDOVER || HRG_LIFT)
 #define NROW (ROW_WELD0 + 6)   // lifting: the 6 rows of the two connect equalities take the weld's slots (general rows, stored after the contact rows in Jc)
 #else
 #define NROW ROW_WELD0
@@ -201,7 +213,15 @@ struct Lds {
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators
-#if HRG_BOX
+#if HRG_STACK
+  hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)
+  double cR[NCUBE][9];                   // cube rotation matrices at the current substep
+  double rcen[HRG_NRCAP][3];
+  Contact con[NCON_DYN];
+  double hbp[NVS * (NVS + 1) / 2 + NVS]; // Newton Hessian / Cholesky factor of the 32-DoF system, packed lower triangle + reciprocal diagonal
+#define HB(i, j) g_L.hbp[(i) * ((i) + 1) / 2 + (j)]
+#define HBI(k) g_L.hbp[NVS * (NVS + 1) / 2 + (k)]
+#elif HRG_BOX
   union {
     struct {  // collide -> classify / constraint-row set-up
       double rcen[HRG_NRCAP][3];
@@ -231,9 +251,16 @@ struct Lds {
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
       int cur[HRG_NPREV_MAX];
     };
+#if HRG_STACK
+    struct {  // dynamics_step_stack: contact rows of J, compact: [robot 8 | first cube 6 | second cube 6] (+1 pad: odd stride), per-row gradient / curvature
+      double Jc[4 * NCON_DYN][21], rg[NROW], rh[NROW];
+      int con_ca[NCON_DYN], con_cb[NCON_DYN], con_rob[NCON_DYN + 1];   // cube index of geom 1 / geom 2 (-1: none), contact has a robot part
+    };
+#else
     struct {  // dynamics_step: contact rows of J (padded to 9: conflict-free ds_read_b64), per-row gradient / curvature
       double Jc[4 * NCON_DYN + (HRG_LIFT ? 6 : 0)][NVS + 1], rg[NROW], rh[NROW];
     };
+#endif
   };
 };
 
@@ -423,7 +450,7 @@ DI double seg_seg(PA p1, PB q1, PC p2, PD q2, double* c1, double* c2) {
   return v3dot(d, d);
 }
 
-#if HRG_BOX
+#if HRG_BOX || HRG_STACK
 // closest points of a segment and a box (centre c, rotation R row-major, half extents hb[3]): the squared distance along the
 // segment is a convex piecewise quadratic in t; safeguarded Newton on its derivative (exact inside one piece).
 template <class PA, class PB, class PC, class PR>

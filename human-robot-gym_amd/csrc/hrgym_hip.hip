@@ -62,6 +62,448 @@ DI double box_Mrow(double mass, int a, const double* v) {
   return L.bMr[r + (a - 3)] * v[a] + L.bMr[r + (a - 2) % 3] * v[3 + (a - 2) % 3] + L.bMr[r + (a - 1) % 3] * v[3 + (a - 1) % 3];
 }
 #endif
+#if HRG_STACK
+// ================================================================================================ solver (stacking)
+// mj_step for the robot tree + the four free cubes of CollaborativeStackingCart: the same primal Newton method with exact line search as dynamics_step
+// below, on 32 DoF and up to 128 constraint rows -- TWO rows per lane (r = lane, lane + 64):
+//   0..7 friction loss | 8..23 joint limits | 24..35 the two cube <-> hand welds (hand, component) | 36..127 contact c, pyramid edge d.
+// Contact rows of J are stored compact ([robot 8 | cube of geom 1: 6 | cube of geom 2: 6]).  M is block diagonal (8x8 robot, m 1 / I 1 per cube: cubes
+// only, checked at create).  Without a robot-cube contact the Newton system splits: the robot block is factored in registers across the wave as in the
+// ReachHuman kernel, the 24x24 cube block in LDS (packed); a robot-cube contact takes the packed 32x32 factorisation.
+static_assert(NVS == 32, "entry (i, j) of the packed Hessian is decoded as (e >> 5, e & 31)");
+struct SRow { bool active; int type, kind, dof; double sgn, D, floss, flim, aref, y, p; };   // kind: 0 joint row, 1 weld row, 2 contact row
+DI double cube_mdiag(ModelPtr dm, int i) { return ((i - NV) % 6) < 3 ? dm->m.box_mass : dm->m.box_inertia[0]; }
+
+// in-place Cholesky of rows / columns k0..NVS-1 of the packed Hessian (k0 = NV: the cube block alone, valid when the robot-cube coupling block is zero)
+DI bool chol_stack(int lane, int k0) {
+  Lds& L = g_L;
+#pragma unroll 1
+  for (int k = k0; k < NVS; k++) {
+    const double dkk = HB(k, k);
+    if (!(dkk > 0)) return false;
+    const double piv = sqrt(dkk);
+    wave_sync();
+    if (lane == k) { HB(k, k) = piv; HBI(k) = 1.0 / piv; }
+    else if (lane > k && lane < NVS) HB(lane, k) = HB(lane, k) / piv;
+    wave_sync();
+#pragma unroll 1
+    for (int t = (k + 1) >> 1; t < NVS / 2; t++) {   // lanes 0..31 hold row 2t, lanes 32..63 row 2t + 1
+      const int i = 2 * t + (lane >> 5), j = lane & 31;
+      if (j > k && j <= i) HB(i, j) = HB(i, j) - HB(i, k) * HB(j, k);
+    }
+    wave_sync();
+  }
+  return true;
+}
+DI double chol_stack_solve(double b, int lane, int k0) {
+  Lds& L = g_L;
+  double x = b;
+#pragma unroll 1
+  for (int k = k0; k < NVS; k++) {
+    const double xk = __shfl(x, k, 64) * HBI(k);
+    if (lane == k) x = xk;
+    else if (lane > k && lane < NVS) x -= HB(lane, k) * xk;
+  }
+#pragma unroll 1
+  for (int k = NVS - 1; k >= k0; k--) {
+    const double xk = __shfl(x, k, 64) * HBI(k);
+    if (lane == k) x = xk;
+    else if (lane < k && lane >= k0) x -= HB(k, lane) * xk;
+  }
+  return x;
+}
+
+PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  hrg_stack_state& sk = L.sk;
+  const double h = m.timestep;
+  const int mi = lane >> 3, mj = lane & 7;
+  const int nc = ncon < NCON_DYN ? ncon : NCON_DYN;
+  bool ok;
+  const double Mij = L.M[lane];
+  double l_damp;
+  {
+    double lm;
+    chol_lanes2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &lm, &l_damp);
+    if (!ok) return 1;
+    chol_store(lm, lane, L.H, L.Hinv);
+  }
+  if (lane < NV) {
+    double act = L.ctrl[lane];
+    if (lane >= NARM) act = clampd(m.finger_kp * (act - s.qpos[lane]), m.finger_forcerange[0], m.finger_forcerange[1]);
+    L.Ma0[lane] = act - m.jnt_damping[lane] * s.qvel[lane] - L.bias[lane];
+    L.qacc[lane] = s.qacc_warmstart[lane];
+  } else if (lane < NVS) {   // free cubes: gravity; a cube's rotational inertia is isotropic, so there is no gyroscopic torque
+    const int a = lane - NV, c = a / 6, k = a - 6 * c;
+    const double a0v = k < 3 ? m.gravity[k] : 0.0;
+    L.a0[lane] = a0v;
+    L.Ma0[lane] = k < 3 ? m.box_mass * a0v : 0.0;
+    L.qacc[lane] = sk.acc_warmstart[c][k];
+  }
+  wave_sync();
+  {
+    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
+    if (lane < NV) L.a0[lane] = x;
+  }
+  // ---- per-contact bookkeeping: which cubes / whether the robot take part ----
+  if (lane < NCON_DYN) {
+    int ca = -1, cb = -1, rob = 0;
+    if (lane < nc) {
+      const Contact& cc = L.con[lane];
+      ca = cc.b1 >= BODY_BOX ? cc.b1 - BODY_BOX : -1;
+      cb = cc.b2 >= BODY_BOX ? cc.b2 - BODY_BOX : -1;
+      rob = (cc.b1 >= 0 && cc.b1 < NV) || (cc.b2 >= 0 && cc.b2 < NV);
+    }
+    L.con_ca[lane] = ca; L.con_cb[lane] = cb; L.con_rob[lane] = rob;
+  }
+  wave_sync();
+  // ---- this lane's two constraint rows ----
+  SRow R[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int r = lane + 64 * k;
+    SRow& w = R[k];
+    w.active = false; w.type = 1; w.kind = 0; w.dof = 0; w.sgn = 0; w.D = 0; w.floss = 0; w.flim = 0; w.aref = 0; w.y = 0; w.p = 0;
+    bool cand = false;
+    double pos = 0, margin = 0, diag = 0, vel = 0;
+    if (r < NV) {
+      if (m.jnt_frictionloss[r] > 0) { cand = true; w.type = 0; w.floss = m.jnt_frictionloss[r]; diag = m.dof_invweight0[r]; w.dof = r; w.sgn = 1.0; vel = s.qvel[r]; }
+    } else if (r < SROW_WELD0) {
+      const int q = r - NV, dof = q >> 1, side = q & 1;
+      const double dist = side ? m.jnt_range[dof][1] - s.qpos[dof] : s.qpos[dof] - m.jnt_range[dof][0];
+      if (dist < 0) { cand = true; pos = dist; diag = m.dof_invweight0[dof]; w.dof = dof; w.sgn = side ? -1.0 : 1.0; vel = w.sgn * s.qvel[dof]; }
+    } else if (r < SROW_CON0) {   // lh_weld_eq / rh_weld_eq (collaborative_stacking_cartesian_env.py:1255-1284): [p_cube - p_target; rotation vector of q_cube q_mocap^-1]
+      const int q = r - SROW_WELD0, hd = q / 6, a = q - 6 * hd, cb = HRG_CUBE_L + hd;
+      if (sk.weld_active[hd]) {
+        const double qm[4] = {sk.mocap_quat[hd][0], sk.mocap_quat[hd][1], sk.mocap_quat[hd][2], sk.mocap_quat[hd][3]};
+        if (a < 3) {   // where the weld wants the cube: mocap = cube o relpose  =>  p_cube = p_mocap - R_mocap relpos
+          double Rm[9], tp[3];
+          quat2mat(Rm, qm);
+          m3mulv(tp, Rm, m.stack_weld_relpos);
+          pos = sk.pos[cb][a] - (sk.mocap_pos[hd][a] - tp[a]);
+        } else {
+          const double qo[4] = {sk.quat[cb][0], sk.quat[cb][1], sk.quat[cb][2], sk.quat[cb][3]}, qc[4] = {qm[0], -qm[1], -qm[2], -qm[3]};
+          double qe[4];
+          quatmul(qe, qo, qc);
+          if (qe[0] < 0) for (int z = 0; z < 4; z++) qe[z] = -qe[z];
+          const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+          pos = sn > 1e-12 ? qe[1 + (a - 3)] / sn * ang : 0.0;
+        }
+        cand = true; w.type = 2; w.kind = 1;
+        diag = a < 3 ? 1.0 / m.box_mass : m.box_invweight_rot;
+        w.dof = NV + 6 * cb + a; w.sgn = 1.0; vel = sk.vel[cb][a];
+      }
+    } else {
+      const int q = r - SROW_CON0, c = q >> 2, d = q & 3;
+      w.kind = 2; w.dof = q;
+      if (c < nc) {
+        const Contact& cc = L.con[c];
+        const double n[3] = {cc.n[0], cc.n[1], cc.n[2]}, cp[3] = {cc.pos[0], cc.pos[1], cc.pos[2]};
+        double t1[3], t2[3], dir[3];
+        const double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+        v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+        v3scl(t1, t1, 1.0 / v3norm(t1));
+        v3cross(t2, n, t1);
+        const double sg = (d & 1) ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
+        pos = cc.dist;
+        margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+        const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
+        diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
+        const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
+        double nz = 0;
+        double* Jr = L.Jc[q];
+        if (!(rb1 || rb2)) { for (int i = 0; i < NV; i++) Jr[i] = 0.0; }
+        else {
+#pragma unroll 1
+          for (int i = 0; i < NV; i++) {
+            double t[3], v[3];
+            v3cross(t, L.Sw[i], cp);
+            v3add(v, L.Sv[i], t);
+            const double jv = v3dot(dir, v);
+            double acc = 0;
+            if ((am1 >> i) & 1) acc += -1.0 * jv;
+            if ((am2 >> i) & 1) acc += jv;
+            Jr[i] = acc;
+            vel += acc * s.qvel[i];
+            nz += fabs(acc);
+          }
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {   // free bodies: J = -+dir . (v + w x r); body_invweight0 of a free body = 1/m
+          const int body = side ? cc.b2 : cc.b1;
+          double* Jb = Jr + 8 + 6 * side;
+          if (body >= BODY_BOX) {
+            const int cb = body - BODY_BOX;
+            const double sgn = side ? 1.0 : -1.0;
+            double rr[3], rxd[3];
+            for (int a = 0; a < 3; a++) rr[a] = cp[a] - sk.pos[cb][a];
+            v3cross(rxd, rr, dir);
+            for (int a = 0; a < 3; a++) { Jb[a] = sgn * dir[a]; Jb[3 + a] = sgn * rxd[a]; vel += sgn * (dir[a] * sk.vel[cb][a] + rxd[a] * sk.vel[cb][3 + a]); nz += fabs(dir[a]) + fabs(rxd[a]); }
+            diag += 1.0 / m.box_mass;
+          } else for (int a = 0; a < 6; a++) Jb[a] = 0.0;
+        }
+        diag *= 1.0 + m.friction_static * m.friction_static;
+        cand = nz > 0;
+      }
+    }
+    w.active = cand && diag > 0;
+    if (w.active) {
+      double imp;
+      const double K = dm->sol_K, Bd = dm->sol_Bd;
+      impedance(m, pos - margin, &imp);
+      w.aref = -Bd * vel - K * imp * (pos - margin);
+      w.D = 1.0 / ((1 - imp) / imp * diag);
+      if (w.type == 0) w.flim = w.floss / w.D;
+    }
+  }
+  const bool any_row = __any(R[0].active || R[1].active);
+  // a robot-cube contact couples the robot block of the Newton system to the cube block
+  bool cpl = false;
+  if (lane < nc) cpl = L.con_rob[lane] && (L.con_ca[lane] >= 0 || L.con_cb[lane] >= 0);
+  const bool coupled = __any(cpl);
+  wave_sync();
+  auto rowdot = [&](const SRow& w, const double* x) -> double {
+    if (!w.active) return 0.0;
+    if (w.kind != 2) return w.sgn * x[w.dof];
+    const int q = w.dof, c = q >> 2;
+    const double* Jr = L.Jc[q];
+    const int ca = L.con_ca[c], cb = L.con_cb[c];
+    double t = 0;
+    if (L.con_rob[c]) {
+#pragma unroll
+      for (int i = 0; i < NV; i++) t += Jr[i] * x[i];
+    }
+    if (ca >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) t += Jr[8 + a] * x[NV + 6 * ca + a];
+    }
+    if (cb >= 0) {
+#pragma unroll
+      for (int a = 0; a < 6; a++) t += Jr[14 + a] * x[NV + 6 * cb + a];
+    }
+    return t;
+  };
+  // M x for the DoF of this lane (robot rows dense, cube DoF diagonal)
+  auto Mrow = [&](const double* x) -> double {
+    double t = 0;
+    if (lane < NV) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * x[j];
+    } else if (lane < NVS) t = cube_mdiag(dm, lane) * x[lane];
+    return t;
+  };
+  if (!any_row) {
+    if (lane < NVS) L.qacc[lane] = L.a0[lane];
+    wave_sync();
+  } else {
+    { // warm start vs unconstrained acceleration: keep the cheaper point
+      double c0 = 0, c1 = 0, g_, h_;
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (R[k].active) {
+          double t0, t1;
+          row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, rowdot(R[k], L.qacc) - R[k].aref, &t0, &g_, &h_);
+          row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, rowdot(R[k], L.a0) - R[k].aref, &t1, &g_, &h_);
+          c0 += t0; c1 += t1;
+        }
+      const double ei = L.qacc[mi] - L.a0[mi], ej = L.qacc[mj] - L.a0[mj];
+      double quad = 0.5 * Mij * ei * ej;
+      if (lane >= NV && lane < NVS) { const double eb = L.qacc[lane] - L.a0[lane]; quad += 0.5 * cube_mdiag(dm, lane) * eb * eb; }
+      const double cost_ws = wave_sum(quad + c0), cost_a0 = wave_sum(c1);
+      wave_sync();
+      if (!(cost_ws < cost_a0)) { if (lane < NVS) L.qacc[lane] = L.a0[lane]; }
+      wave_sync();
+    }
+#pragma unroll 1
+    for (int it = 0; it < m.solver_iters; it++) {
+      double gg[2], hh[2];
+#pragma unroll
+      for (int k = 0; k < 2; k++) {
+        double cc_ = 0;
+        gg[k] = 0; hh[k] = 0;
+        R[k].y = rowdot(R[k], L.qacc) - R[k].aref;
+        if (R[k].active) row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, R[k].y, &cc_, &gg[k], &hh[k]);
+        L.rg[lane + 64 * k] = gg[k]; L.rh[lane + 64 * k] = hh[k];
+      }
+      wave_sync();
+      double gm = 0;
+      if (lane < NVS) {   // gradient of the DoF of this lane
+        double t = Mrow(L.qacc) - L.Ma0[lane];
+        gm = t;
+        if (lane < NV) {
+          t += L.rg[lane];
+          t += L.rg[NV + 2 * lane];
+          t -= L.rg[NV + 2 * lane + 1];
+#pragma unroll 1
+          for (int c = 0; c < nc; c++)
+            if (L.con_rob[c])
+              for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][lane] * L.rg[SROW_CON0 + 4 * c + d];
+        } else {
+          const int a = lane - NV, cu = a / 6, k = a - 6 * cu;
+          if (cu >= HRG_CUBE_L) t += L.rg[SROW_WELD0 + 6 * (cu - HRG_CUBE_L) + k];
+#pragma unroll 1
+          for (int c = 0; c < nc; c++) {
+            if (L.con_ca[c] == cu) for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][8 + k] * L.rg[SROW_CON0 + 4 * c + d];
+            if (L.con_cb[c] == cu) for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][14 + k] * L.rg[SROW_CON0 + 4 * c + d];
+          }
+        }
+        L.g[lane] = t;
+      }
+      wave_sync();
+      {
+        const double gl = lane < NVS ? L.g[lane] : 0.0, ml = lane < NVS ? L.Ma0[lane] : 0.0;
+        const double gn = wave_sum(gl * gl), sc = wave_sum(ml * ml);
+        if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      }
+      // ---- Newton Hessian: M + sum_r h_r J_r' J_r ----
+      if (!coupled) {   // robot block in registers (lanes = (mi, mj)), as in the ReachHuman solver
+        double hval = Mij;
+        if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
+#pragma unroll 1
+        for (int c = 0; c < nc; c++)
+          if (L.con_rob[c])
+            for (int d = 0; d < 4; d++) { const double hq = L.rh[SROW_CON0 + 4 * c + d]; if (hq != 0) hval += hq * L.Jc[4 * c + d][mi] * L.Jc[4 * c + d][mj]; }
+        const double hl = chol_lanes(hval, lane, &ok);
+        if (!ok) break;
+        chol_store(hl, lane, L.H, L.Hinv);
+      }
+#pragma unroll 1
+      for (int t = coupled ? 0 : NV / 2; t < NVS / 2; t++) {   // block-diagonal part of the packed Hessian
+        const int i = 2 * t + (lane >> 5), j = lane & 31;
+        if (j <= i) {
+          double hv = 0;
+          if (i < NV) { hv = L.M[i * NV + j]; if (i == j) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; } }
+          else if (i == j) { hv = cube_mdiag(dm, i); const int cu = (i - NV) / 6; if (cu >= HRG_CUBE_L) hv += L.rh[SROW_WELD0 + (i - NV) - 6 * HRG_CUBE_L]; }
+          HB(i, j) = hv;
+        }
+      }
+      wave_sync();
+#pragma unroll 1
+      for (int c = 0; c < nc; c++) {   // contact c adds h J' J on its 20 local columns [robot 8 | cube of geom 1 | cube of geom 2]
+        const int ca = L.con_ca[c], cb = L.con_cb[c], rob = L.con_rob[c] && coupled;
+        if (ca < 0 && cb < 0) continue;   // robot-only contact: in the robot block above (uncoupled) ...
+        const double h0 = L.rh[SROW_CON0 + 4 * c], h1 = L.rh[SROW_CON0 + 4 * c + 1], h2 = L.rh[SROW_CON0 + 4 * c + 2], h3 = L.rh[SROW_CON0 + 4 * c + 3];
+        if (h0 == 0 && h1 == 0 && h2 == 0 && h3 == 0) continue;
+#pragma unroll 1
+        for (int e = lane; e < 400; e += 64) {
+          const int li = e / 20, lj = e - 20 * li;
+          if (lj > li) continue;
+          if ((li < 8 && !rob) || (lj < 8 && !rob)) continue;
+          if ((li >= 8 && li < 14 && ca < 0) || (lj >= 8 && lj < 14 && ca < 0) || (li >= 14 && cb < 0) || (lj >= 14 && cb < 0)) continue;
+          const int gi = li < 8 ? li : (li < 14 ? NV + 6 * ca + li - 8 : NV + 6 * cb + li - 14), gj = lj < 8 ? lj : (lj < 14 ? NV + 6 * ca + lj - 8 : NV + 6 * cb + lj - 14);
+          const double v = h0 * L.Jc[4 * c][li] * L.Jc[4 * c][lj] + h1 * L.Jc[4 * c + 1][li] * L.Jc[4 * c + 1][lj] + h2 * L.Jc[4 * c + 2][li] * L.Jc[4 * c + 2][lj] +
+                           h3 * L.Jc[4 * c + 3][li] * L.Jc[4 * c + 3][lj];
+          HB(gi, gj) = HB(gi, gj) + v;
+        }
+        wave_sync();
+      }
+      if (coupled) {   // ... or here, when the robot block is part of the packed system
+#pragma unroll 1
+        for (int c = 0; c < nc; c++) {
+          if (!(L.con_rob[c] && L.con_ca[c] < 0 && L.con_cb[c] < 0)) continue;
+          for (int d = 0; d < 4; d++) { const double hq = L.rh[SROW_CON0 + 4 * c + d]; if (hq != 0 && mj <= mi) HB(mi, mj) = HB(mi, mj) + hq * L.Jc[4 * c + d][mi] * L.Jc[4 * c + d][mj]; }
+        }
+        wave_sync();
+      }
+      if (!chol_stack(lane, coupled ? 0 : NV)) break;
+      {
+        double x;
+        if (coupled) x = chol_stack_solve(lane < NVS ? -L.g[lane] : 0.0, lane, 0);
+        else {
+          const double x1 = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
+          const double x2 = chol_stack_solve(lane >= NV && lane < NVS ? -L.g[lane] : 0.0, lane, NV);
+          x = lane < NV ? x1 : x2;
+        }
+        if (lane < NVS) L.d[lane] = x;
+      }
+      wave_sync();
+#pragma unroll
+      for (int k = 0; k < 2; k++) R[k].p = rowdot(R[k], L.d);
+      double dd = 0, Mdi = 0;
+      if (lane < NVS) { dd = L.d[lane]; Mdi = Mrow(L.d); }
+      const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
+      double al = 1.0, lo = 0, hi = -1;
+      const double d1_0 = gd0 + wave_sum(gg[0] * R[0].p + gg[1] * R[1].p);
+#pragma unroll 1
+      for (int ls = 0; ls < 40; ls++) {
+        double sg_ = 0, sh_ = 0;
+#pragma unroll
+        for (int k = 0; k < 2; k++)
+          if (R[k].active) {
+            double c2, g2, h2;
+            row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, R[k].y + al * R[k].p, &c2, &g2, &h2);
+            sg_ += g2 * R[k].p; sh_ += h2 * R[k].p * R[k].p;
+          }
+        const double d1 = gd0 + al * dMd + wave_sum(sg_);
+        const double d2 = dMd + wave_sum(sh_);
+        if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+        if (d1 < 0) lo = al; else hi = al;
+        double nx = al - d1 / d2;
+        if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
+        else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+        al = nx;
+      }
+      if (lane < NVS) L.qacc[lane] += al * dd;
+      wave_sync();
+      bool moved = false;
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (R[k].active) moved = moved || row_zone(R[k].type, R[k].flim, R[k].y) != row_zone(R[k].type, R[k].flim, R[k].y + R[k].p);
+      if (al == 1.0 && !__any(moved)) break;
+    }
+  }
+  const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
+  if (__any(badacc)) return 1;
+  // mj_Euler with implicit joint damping for the robot tree
+  chol_store(l_damp, lane, L.H, L.Hinv);
+  if (lane < NV) {
+    s.qacc_warmstart[lane] = L.qacc[lane];
+    double t = 0;
+#pragma unroll
+    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
+    L.d[lane] = t;
+  }
+  wave_sync();
+  {
+    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.d[lane] : 0.0, lane);
+    if (lane < NV) {
+      const double v = s.qvel[lane] + h * x;
+      s.qvel[lane] = v;
+      s.qpos[lane] = s.qpos[lane] + h * v;
+    }
+  }
+  { // the cubes' free joints: lanes 8..31 = (cube, component); quaternions by lanes 0..3 of each cube's group
+    double vnew = 0;
+    const int a = lane - NV, cu = lane >= NV && lane < NVS ? a / 6 : 0, k = lane >= NV && lane < NVS ? a - 6 * cu : 0;
+    if (lane >= NV && lane < NVS) {
+      const double acc = L.qacc[lane];
+      sk.acc_warmstart[cu][k] = acc;
+      vnew = sk.vel[cu][k] + h * acc;
+      sk.vel[cu][k] = vnew;
+      if (k < 3) { const double p0 = sk.pos[cu][k]; sk.obs_pos[cu][k] = p0; sk.pos[cu][k] = p0 + h * vnew; }
+    }
+    wave_sync();
+    if (lane < NCUBE) {
+      const double w0 = sk.vel[lane][3], w1 = sk.vel[lane][4], w2 = sk.vel[lane][5];
+      const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+      if (wn > 1e-12) {
+        const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
+        const double qo[4] = {sk.quat[lane][0], sk.quat[lane][1], sk.quat[lane][2], sk.quat[lane][3]};
+        double qn[4];
+        quatmul(qn, dq, qo);
+        const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (int z = 0; z < 4; z++) sk.quat[lane][z] = qn[z] / nn;
+      }
+    }
+  }
+  wave_sync();
+  return 0;
+}
+#else
 PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -520,6 +962,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   wave_sync();
   return 0;
 }
+#endif   // HRG_STACK
 
 // ================================================================================================ env
 // HumanEnv._check_action_safety (human_env.py:931-946) for the configuration in L.cq: static collision objects (table
@@ -763,6 +1206,24 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
     else if (lane >= 53 && lane < 55) v = s.qpos[NARM + lane - 53];  // robot0_gripper_qpos
     else if (lane >= 55) v = s.qvel[NARM + lane - 55];               // robot0_gripper_qvel
     else v = 0.0;                                   // PickPlaceHumanCart columns
+#if HRG_STACK
+    // CollaborativeStackingCart._setup_observables (collaborative_stacking_cartesian_env.py:1306-1524): vec_eef_to_all_objects (a, b, l, r) in the 12 joint-space
+    // columns the cube tasks leave empty, object_gripped 39, vec_eef_to_object 40:43 (the cube the robot places next: b, then a), vec_eef_to_target 43:46,
+    // gripper_aperture 46, that cube's position 47:50, next_target_pos 50:53 (sk.target: the eef position while there is no target)
+    const hrg_stack_state& sk = L.sk;
+    const int nxt = sk.n_stack >= 2 ? HRG_CUBE_A : HRG_CUBE_B;
+    if (lane >= 12 && lane < 18) v = sk.obs_pos[(lane - 12) / 3][(lane - 12) % 3] - s.eef_pos[(lane - 12) % 3];
+    else if (lane >= 33 && lane < 39) v = sk.obs_pos[2 + (lane - 33) / 3][(lane - 33) % 3] - s.eef_pos[(lane - 33) % 3];
+    else if (lane == 39) v = (double)sk.gripped;
+    else if (lane >= 40 && lane < 43) v = sk.obs_pos[nxt][lane - 40] - s.eef_pos[lane - 40];
+    else if (lane >= 43 && lane < 46) v = sk.target[lane - 43] - s.eef_pos[lane - 43];
+    else if (lane == 46) {
+      double ap = 0;
+      for (int f = 0; f < HRG_NFINGER; f++) ap += (s.qpos[NARM + f] - m.finger_qpos_range[0][f]) / (m.finger_qpos_range[1][f] - m.finger_qpos_range[0][f]);
+      v = ap / HRG_NFINGER;
+    } else if (lane >= 47 && lane < 50) v = sk.obs_pos[nxt][lane - 47];
+    else if (lane >= 50 && lane < 53) v = sk.target[lane - 50];
+#endif
 #if HRG_BOX
     // PickPlaceHumanCart._setup_observables (pick_place_human_cartesian_env.py:726-841), gripper_aperture (human_env.py:1508-1524)
     const hrg_box_state& bx = L.bx;
@@ -827,6 +1288,76 @@ DI void placement_of(ModelPtr dm, int64_t gid, int episode, int idx, int target,
   const double u0 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx)), u1 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, st, (uint64_t)(2 * idx + 1));
   if (target) { p[0] = m.tgt_bin[0] + (m.tgt_bin[1] - m.tgt_bin[0]) * u0; p[1] = m.tgt_bin[2] + (m.tgt_bin[3] - m.tgt_bin[2]) * u1; p[2] = m.tgt_z; }
   else { p[0] = m.obj_bin[0] + (m.obj_bin[1] - m.obj_bin[0]) * u0; p[1] = m.obj_bin[2] + (m.obj_bin[3] - m.obj_bin[2]) * u1; p[2] = m.obj_z; }
+}
+#endif
+
+#if HRG_STACK
+// next_target_position (collaborative_stacking_cartesian_env.py:522-548) -> sk.target / sk.has_target; the eef position while it is not the robot's turn (1347-1355).
+// Wave-uniform; called before an observation is written.
+DI void stack_update_target(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_stack_state& sk = L.sk;
+  const int left = dm->clips.clip_holding_hand[clip_of(dm, gid, L.st.episode, L.st.anim_index)];   // first_placing_hand
+  int c = -1;
+  if (sk.task_phase == HRG_STK_WAIT_FOR_SECOND) c = left ? HRG_CUBE_L : HRG_CUBE_R;
+  else if (sk.task_phase == HRG_STK_WAIT_FOR_FOURTH) c = left ? HRG_CUBE_R : HRG_CUBE_L;
+  double tv = 0;
+  if (lane < 3) tv = c >= 0 ? sk.obs_pos[c][lane] + (lane == 2 ? 2.0 * m.box_half[2] : 0.0) : L.st.eef_pos[lane];
+  wave_sync();
+  if (lane < 3) sk.target[lane] = tv;
+  sk.has_target = c >= 0;
+  wave_sync();
+}
+// _id_of_cube_at_target (590-610): a robot cube within goal_dist (maximum norm) of the target that is not part of the stack; -1 = none.  Needs sk.target.
+DI int stack_cube_at_target(ModelPtr dm) {
+  const hrg_stack_state& sk = g_L.sk;
+  if (!sk.has_target) return -1;
+  for (int c = HRG_CUBE_A; c <= HRG_CUBE_B; c++) {
+    double dmax = 0;
+    for (int a = 0; a < 3; a++) { const double d = fabs(sk.target[a] - sk.obs_pos[c][a]); if (d > dmax) dmax = d; }
+    bool in_stack = false;
+    for (int q = 0; q < NCUBE; q++) if (q < sk.n_stack && sk.stack_ids[q] == c) in_stack = true;
+    if (dmax < dm->m.goal_dist && !in_stack) return c;
+  }
+  return -1;
+}
+// _human_pickup_objects (1053-1056) as restated in the oracle (stack_pickup): both cubes put into the hands at rest, both welds on.  Needs sk.mocap_*.
+DI void stack_pickup(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_stack_state& sk = L.sk;
+  wave_sync();
+  if (lane < 2) {
+    const int hd = lane, c = HRG_CUBE_L + hd;
+    double Rm[9], t[3];
+    const double qm[4] = {sk.mocap_quat[hd][0], sk.mocap_quat[hd][1], sk.mocap_quat[hd][2], sk.mocap_quat[hd][3]};
+    quat2mat(Rm, qm);
+    m3mulv(t, Rm, m.stack_weld_relpos);
+    for (int a = 0; a < 3; a++) { const double pv = sk.mocap_pos[hd][a] - t[a]; sk.pos[c][a] = pv; sk.obs_pos[c][a] = pv; }
+    for (int a = 0; a < 4; a++) sk.quat[c][a] = qm[a];
+    for (int a = 0; a < 6; a++) { sk.vel[c][a] = 0.0; sk.acc_warmstart[c][a] = 0.0; }
+    sk.weld_active[hd] = 1;
+  }
+  wave_sync();
+}
+// idx-th placement of robot cube c (oracle stack_placement); wave-uniform
+DI void stack_placement(ModelPtr dm, int64_t gid, int episode, int idx, int c, double* p) {
+  const auto& m = dm->m;
+  const double u0 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_OBJECT, (uint64_t)(4 * idx + 2 * c)), u1 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_OBJECT, (uint64_t)(4 * idx + 2 * c + 1));
+  p[0] = m.obj_bin[0] + (m.obj_bin[1] - m.obj_bin[0]) * u0;
+  p[1] = m.obj_bin[2] + (m.obj_bin[3] - m.obj_bin[2]) * u1;
+  p[2] = m.obj_z;
+}
+// _reset_animation (991-998) after the human has been posed
+DI void stack_reset_animation(const DevModel* __restrict__ dm_, int lane) {
+  hrg_stack_state& sk = g_L.sk;
+  wave_sync();
+  sk.task_phase = HRG_STK_APPROACH; sk.n_delayed[0] = 0; sk.n_delayed[1] = 0; sk.n_stack = 0; sk.max_stack_height = 0;
+  if (lane < NCUBE) sk.stack_ids[lane] = -1;
+  stack_pickup(dm_, lane);
 }
 #endif
 
@@ -938,6 +1469,21 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
       wave_sync();
     }
 #endif
+  }
+#elif HRG_STACK
+  { // CollaborativeStackingCart._reset_internal (938-959): the robot's cubes in their bin, the human's cubes in the hands, phase APPROACH
+    hrg_stack_state& sk = L.sk;
+    for (int k = lane; k < (int)(sizeof(hrg_stack_state) / sizeof(double)); k += 64) ((double*)&sk)[k] = 0.0;
+    wave_sync();
+    double pa[3], pb[3];
+    stack_placement(dm, gid, episode, 0, HRG_CUBE_A, pa);
+    stack_placement(dm, gid, episode, 0, HRG_CUBE_B, pb);
+    if (lane < 3) { sk.pos[HRG_CUBE_A][lane] = pa[lane]; sk.obs_pos[HRG_CUBE_A][lane] = pa[lane]; sk.pos[HRG_CUBE_B][lane] = pb[lane]; sk.obs_pos[HRG_CUBE_B][lane] = pb[lane]; }
+    if (lane < 2) sk.quat[lane][0] = 1.0;
+    wave_sync();
+    human_control(dm_, lane, gid);
+    stack_reset_animation(dm_, lane);
+    stack_update_target(dm_, lane, gid);
   }
 #else
   goal_sample(dm_, lane, gid, 0);
@@ -1128,8 +1674,32 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
     wave_sync();
   }
 #endif
+#if HRG_STACK
+  stack_update_target(dm_, lane, gid);
+#endif
   write_obs(dm_, lane, goal, term_obs);
-#if HRG_BOX
+#if HRG_STACK
+  // CollaborativeStackingCart: success = the animation ran to its end (_check_success, 746-756); _sparse_reward (700-744); _check_stack_toppled (656-671)
+  hrg_stack_state& sk = L.sk;
+  const int goal_reached = !crash && sk.task_phase == HRG_STK_COMPLETE;
+  int toppled = 0;
+  if (sk.n_stack >= 2) {
+    const double min_h = sk.obs_pos[sk.stack_ids[0]][2] + m.box_half[2];
+    for (int q = 1; q < NCUBE; q++) if (q < sk.n_stack && sk.obs_pos[sk.stack_ids[q]][2] < min_h) toppled = 1;
+  }
+  const int at_target = stack_cube_at_target(dm);
+  // _check_first / _check_second_manipulation_object_in_target_zone (620-654)
+  const int first_zone = sk.n_stack < 1 ? -1 : (sk.n_stack > 1 ? sk.stack_ids[1] : at_target);
+  const int second_zone = sk.n_stack < 3 ? -1 : (sk.n_stack > 3 ? sk.stack_ids[3] : at_target);
+  double r;
+  if (goal_reached) r = m.task_reward;
+  else if (toppled) r = m.stack_toppled_reward;
+  else {
+    r = second_zone >= 0 ? m.fourth_cube_at_target_reward : (first_zone >= 0 ? m.second_cube_at_target_reward : -1.0);
+    if (sk.gripped) r += m.object_gripped_reward;
+  }
+  const double dense = 0.0;   // _dense_reward is a TODO returning 0 (681-698)
+#elif HRG_BOX
   // PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611);
   // _check_object_in_target_zone (550-572), _sparse_reward (471-500), _dense_reward (502-526)
   hrg_box_state& bx = L.bx;
@@ -1175,6 +1745,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   else {
     if (m.done_at_collision && illegal) d = 1;
     if (m.done_at_success && goal_reached) d = 1;
+#if HRG_STACK
+    if (toppled) d = 1;   // _check_done (758-778)
+#endif
 #if HRG_LIFT
     if (m.task == HRG_TASK_LIFTING) { // _check_done (509-561): unbalanced, or the board out of the gripper for more than 5 steps in a row
       const int nd = L.bx.gripped ? 0 : L.bx.n_delayed + 1;
@@ -1206,6 +1779,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
       case HRG_INFO_ACTION_RESAMPLES: v = s.action_resamples; break;
 #if HRG_BOX
       case HRG_INFO_N_OBJECT_HANDED_OVER: v = L.bx.n_handed_over; break;
+#endif
+#if HRG_STACK
+      case HRG_INFO_MAX_STACK_HEIGHT: v = L.sk.max_stack_height; break;   // _get_info (673-679): the value before this step's transitions
 #endif
     }
     info[lane] = v;
@@ -1333,6 +1909,58 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
     if (lane < 4) bx.quat[lane] = lane == 0 ? 1.0 : 0.0;
     wave_sync();
   }
+#elif HRG_STACK
+  if (!d) write_obs(dm_, lane, goal, obs);   // the step's observation predates the transitions below (CollaborativeStackingCart.step, 550-588)
+  wave_sync();
+  if (goal_reached && !m.done_at_success && !d) { // _on_goal_reached (961-977): next placements of the robot's cubes (velocities kept), next animation, both cubes back in the hands
+    const int oi = (sk.obj_index + 1) % m.n_obj_placements;
+    double pa[3], pb[3];
+    stack_placement(dm, gid, s.episode, oi, HRG_CUBE_A, pa);
+    stack_placement(dm, gid, s.episode, oi, HRG_CUBE_B, pb);
+    const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+    wave_sync();
+    sk.obj_index = oi;
+    if (lane < 3) { sk.pos[HRG_CUBE_A][lane] = pa[lane]; sk.pos[HRG_CUBE_B][lane] = pb[lane]; }
+    if (lane < 4) { sk.quat[HRG_CUBE_A][lane] = lane == 0 ? 1.0 : 0.0; sk.quat[HRG_CUBE_B][lane] = lane == 0 ? 1.0 : 0.0; }
+    s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+    sk.task_phase = HRG_STK_APPROACH; sk.n_delayed[0] = 0; sk.n_delayed[1] = 0;
+    wave_sync();
+    human_control(dm_, lane, gid);
+    stack_reset_animation(dm_, lane);
+  }
+  if (!d) { // the phase machine of CollaborativeStackingCart.step (563-586); wave-uniform
+    const int clip = clip_of(dm, gid, s.episode, s.anim_index);
+    const int left = dm->clips.clip_holding_hand[clip], k1 = dm->clips.clip_stack_keyframes[clip][1], k3 = dm->clips.clip_stack_keyframes[clip][3];
+    const int ph = sk.task_phase, ns = sk.n_stack, at = s.animation_time, gr = sk.gripped;
+    const int fz = ns < 1 ? -1 : (ns > 1 ? sk.stack_ids[1] : stack_cube_at_target(dm)), sz = ns < 3 ? -1 : (ns > 3 ? sk.stack_ids[3] : stack_cube_at_target(dm));
+    double top[3] = {0, 0, 0};
+    if (ns >= 2) for (int a = 0; a < 3; a++) top[a] = sk.obs_pos[sk.stack_ids[1]][a];
+    wave_sync();
+    int nns = ns;
+    if (ph == HRG_STK_PLACE_FIRST && at > k1) { // _human_place_first_object (1004-1011)
+      const int hd = left ? 0 : 1;
+      sk.stack_ids[ns] = HRG_CUBE_L + hd; nns = ns + 1;
+      sk.weld_active[hd] = 0;
+      sk.task_phase = HRG_STK_WAIT_FOR_SECOND;
+    } else if (ph == HRG_STK_WAIT_FOR_SECOND && fz >= 0 && !gr) {
+      sk.task_phase = HRG_STK_PLACE_THIRD;
+      sk.stack_ids[ns] = fz; nns = ns + 1;
+    } else if (ph == HRG_STK_PLACE_THIRD && at > k3) { // _human_place_third_object (1013-1043): released directly above the second cube, at rest
+      const int hd = left ? 1 : 0, c = HRG_CUBE_L + hd;
+      sk.weld_active[hd] = 0;
+      if (lane < 3) sk.pos[c][lane] = top[lane] + (lane == 2 ? 2.0 * m.box_half[2] : 0.0);
+      if (lane < 4) sk.quat[c][lane] = lane == 0 ? 1.0 : 0.0;
+      if (lane < 6) sk.vel[c][lane] = 0.0;
+      sk.stack_ids[ns] = c; nns = ns + 1;
+      sk.task_phase = HRG_STK_WAIT_FOR_FOURTH;
+    } else if (ph == HRG_STK_WAIT_FOR_FOURTH && sz >= 0 && !gr) {
+      sk.task_phase = HRG_STK_RETREAT;
+      sk.stack_ids[ns] = sz; nns = ns + 1;
+    }
+    sk.n_stack = nns;
+    if (nns > sk.max_stack_height) sk.max_stack_height = nns;
+    wave_sync();
+  }
 #else
   if (goal_reached && !d) { // reach_human_env.py:399-407 (a finished episode resamples its goals at reset anyway)
     s.goal_index = (s.goal_index + 1) % m.n_goals;
@@ -1341,7 +1969,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #endif
   STAMP(8);
   if (d) env_reset(dm_, lane, own_gid, obs);
-#if !HRG_BOX
+#if !HRG_BOX && !HRG_STACK
   else write_obs(dm_, lane, goal, obs);
 #endif
   STAMP(9);
@@ -1349,6 +1977,13 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 }
 
 // ================================================================================================ kernels
+#if HRG_STACK
+#define hrg_step_kernel hrg_step_kernel_stack
+#define hrg_reset_kernel hrg_reset_kernel_stack
+typedef hrg_stack_state ObjState;   // the per-env object block this variant streams next to hrg_env_state
+#else
+typedef hrg_box_state ObjState;
+#endif
 #if HRG_BOX && HRG_HANDOVER
 #define hrg_step_kernel hrg_step_kernel_ho
 #define hrg_reset_kernel hrg_reset_kernel_ho
@@ -1381,13 +2016,27 @@ DI void box_store(hrg_box_state* __restrict__ boxes, int e, int lane) {
   const double* src = (const double*)&g_L.bx;
   if (lane < NB) out[lane] = src[lane];
 }
+#elif HRG_STACK
+#define HRG_KERNEL_WAVES 1   // 35 KB of LDS per env (92 compact contact rows, the packed 32x32 Hessian): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
+DI void box_load(const hrg_stack_state* __restrict__ stacks, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_stack_state) / sizeof(double));
+  const double* src = (const double*)(stacks + e);
+  double* dst = (double*)&g_L.sk;
+  for (int k = lane; k < NB; k += 64) dst[k] = src[k];
+}
+DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_stack_state) / sizeof(double));
+  double* out = (double*)(stacks + e);
+  const double* src = (const double*)&g_L.sk;
+  for (int k = lane; k < NB; k += 64) out[k] = src[k];
+}
 #else
 #define HRG_KERNEL_WAVES HRG_MIN_WAVES
 #endif
 __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs,
-                                                     hrg_box_state* __restrict__ boxes) {
+                                                     ObjState* __restrict__ boxes) {
   Lds& L = g_L;
   (void)boxes;  // the cube's state array: only the HRG_BOX variant streams it
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -1395,7 +2044,7 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const De
   double* dst = (double*)&L.st;
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
   for (int k = lane; k < NW; k += 64) dst[k] = src[k];
-#if HRG_BOX
+#if HRG_BOX || HRG_STACK
   box_load(boxes, e, lane);
 #endif
   wave_sync();
@@ -1405,13 +2054,13 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const De
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
-#if HRG_BOX
+#if HRG_BOX || HRG_STACK
   box_store(boxes, e, lane);
 #endif
 }
 
 __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ obs, int64_t env_id0, hrg_box_state* __restrict__ boxes) {
+                                                      float* __restrict__ obs, int64_t env_id0, ObjState* __restrict__ boxes) {
   Lds& L = g_L;
   (void)boxes;
   const int e = blockIdx.x, lane = threadIdx.x;
@@ -1425,12 +2074,12 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const D
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
-#if HRG_BOX
+#if HRG_BOX || HRG_STACK
   box_store(boxes, e, lane);
 #endif
 }
 
-#if !HRG_BOX
+#if !HRG_BOX && !HRG_STACK
 // HumanEnv.check_collision_action for every env: goal configuration of the action at the env's current joint angles -> pre-check capsule model.
 // The check reads the robot part of the state only, so one kernel serves every task.
 __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
@@ -1456,7 +2105,15 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_
                                                                            float* scratch_obs, hrg_box_state* boxes);
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                             int64_t env_id0, hrg_box_state* boxes);
-#if !HRG_BOX
+#if !HRG_BOX && !HRG_STACK
+// ... of the stacking variant (hrgym_stack.hip)
+extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                             float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                             float* scratch_obs, hrg_stack_state* stacks);
+extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                              int64_t env_id0, hrg_stack_state* stacks);
+#endif
+#if !HRG_BOX && !HRG_STACK
 // the same shims of the handover variant (hrgym_handover.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                           float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -1470,6 +2127,15 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_step(int n
 extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                              int64_t env_id0, hrg_box_state* boxes);
 #endif
+#if HRG_STACK
+extern "C" void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
+                                      int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_stack_state* stacks) {
+  hipLaunchKernelGGL(hrg_step_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, stacks);
+}
+extern "C" void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_stack_state* stacks) {
+  hipLaunchKernelGGL(hrg_reset_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, mask, obs, env_id0, stacks);
+}
+#endif
 #if HRG_BOX
 extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
                                     int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes) {
@@ -1481,7 +2147,9 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #endif
 
 #ifdef HRG_STAMPS
-#if HRG_HANDOVER
+#if HRG_STACK
+#define hrg_debug_stamps hrg_debug_stamps_stack
+#elif HRG_HANDOVER
 #define hrg_debug_stamps hrg_debug_stamps_ho
 #elif HRG_LIFT
 #define hrg_debug_stamps hrg_debug_stamps_lift
@@ -1495,12 +2163,12 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
   if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
   return 0;
 }
-#if !HRG_BOX
+#if !HRG_BOX && !HRG_STACK
 extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envcyc), sizeof(unsigned long long) * 3 * n) == hipSuccess ? 0 : -1; }
 #endif
 #endif
 
-#if !HRG_BOX
+#if !HRG_BOX && !HRG_STACK
 
 // ================================================================================================ host side
 static thread_local std::string g_err;
@@ -1523,6 +2191,7 @@ struct hrg_batch {
   int32_t* d_nh = nullptr;
   float* d_scratch_obs = nullptr;
   hrg_box_state* d_boxes = nullptr;   // the manipulation object of each env (PickPlaceHumanCart)
+  hrg_stack_state* d_stacks = nullptr; // the four cubes of each env (CollaborativeStackingCart)
   int32_t task = HRG_TASK_REACH;
   bool timing = false;
   bool taps = false;
@@ -1543,6 +2212,7 @@ const char* hrg_last_error(void) { return g_err.c_str(); }
 const char* hrg_version(void) { return "hrgym-hip 0.1.0 (gfx950)"; }
 size_t hrg_state_bytes(void) { return sizeof(hrg_env_state); }
 size_t hrg_box_bytes(void) { return sizeof(hrg_box_state); }
+size_t hrg_stack_bytes(void) { return sizeof(hrg_stack_state); }
 
 int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
   if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
@@ -1558,7 +2228,17 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_LIFTING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_STACKING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task == HRG_TASK_STACKING) {
+    if (!(desc->box_inertia[0] == desc->box_inertia[1] && desc->box_inertia[1] == desc->box_inertia[2]))
+      return fail(HRG_ERR_UNSUPPORTED, "CollaborativeStackingCart: the HIP stepper stacks cubes (object_full_size with three equal edges)");
+    for (int c = 0; c < clips->n_clips; c++) {
+      const int32_t* kf = clips->clip_stack_keyframes[c];
+      if (!(kf[0] >= 0 && kf[0] <= kf[1] && kf[1] <= kf[2] && kf[2] <= kf[3] && kf[3] <= kf[4] && clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP &&
+            clips->clip_n_loop2[c] >= 0 && clips->clip_n_loop2[c] <= HRG_MAX_LOOP))
+        return fail(HRG_ERR_INVALID, "CollaborativeStackingCart: every clip needs five ascending keyframes and at most 4 loop sines per waiting phase in its info");
+    }
+  }
   if (desc->task == HRG_TASK_LIFTING && !(desc->min_balance > -1 && desc->min_balance < 1)) return fail(HRG_ERR_INVALID, "CollaborativeLiftingCart: min_balance must lie in (-1, 1)");
   if (HRG_IS_HANDOVER(desc->task))
     for (int c = 0; c < clips->n_clips; c++)
@@ -1682,6 +2362,10 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   HIPCHK_C(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
   HIPCHK_C(hipMalloc(&b->d_boxes, sizeof(hrg_box_state) * (size_t)n_envs));
   HIPCHK_C(hipMemset(b->d_boxes, 0, sizeof(hrg_box_state) * (size_t)n_envs));
+  if (desc->task == HRG_TASK_STACKING) {
+    HIPCHK_C(hipMalloc(&b->d_stacks, sizeof(hrg_stack_state) * (size_t)n_envs));
+    HIPCHK_C(hipMemset(b->d_stacks, 0, sizeof(hrg_stack_state) * (size_t)n_envs));
+  }
 #undef HIPCHK_C
   *out = b;
   return HRG_OK;
@@ -1693,14 +2377,15 @@ void hrg_batch_destroy(hrg_batch* b) {
   hipDeviceSynchronize();
   for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes);
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks);
   delete b;
 }
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  if (b->task == HRG_TASK_STACKING) hrg_stack_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_stacks);
+  else if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
@@ -1726,7 +2411,10 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  if (b->task == HRG_TASK_LIFTING)
+  if (b->task == HRG_TASK_STACKING)
+    hrg_stack_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                          b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_stacks);
+  else if (b->task == HRG_TASK_LIFTING)
     hrg_lift_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                          b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task))
@@ -1798,6 +2486,24 @@ int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t by
   return HRG_OK;
 }
 
+int hrg_batch_get_stack(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_stack_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  if (!b->d_stacks) return fail(HRG_ERR_INVALID, "not a CollaborativeStackingCart batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(buf_host, b->d_stacks + env, bytes, hipMemcpyDeviceToHost));
+  return HRG_OK;
+}
+
+int hrg_batch_set_stack(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_stack_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  if (!b->d_stacks) return fail(HRG_ERR_INVALID, "not a CollaborativeStackingCart batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_stacks + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
 int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void* states_host, void* boxes_host) {
   if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
@@ -1853,4 +2559,4 @@ int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
 }
 
 } // extern "C"
-#endif // !HRG_BOX
+#endif // !HRG_BOX && !HRG_STACK

@@ -261,6 +261,27 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     for (int a = 0; a < 3; a++) L.hand_off[a] = to[a];
   }
 #endif
+#if HRG_STACK
+  { // _update_mocap_body_transforms (collaborative_stacking_cartesian_env.py:905-936): each hand's mocap body = the hand site moved 3 cm towards the thumb
+    // (hand z axis), the hand rotation turned -90 deg (left) / +90 deg (right) about its y axis; computed by the lanes of the two hand bodies
+    const int bl = m.meas_body[m.site_lhand], br = m.meas_body[m.site_rhand];
+    if (lane == bl || lane == br) {
+      const int hd = lane == bl ? 0 : 1;
+      const double sn = hd == 0 ? -1.0 : 1.0;                  // cos(-+pi/2) = 0, sin = -+1: R Ry = [-sn c2 | c1 | sn c0] by columns
+      double Rm[9], q[4], site[3], t[3];
+      for (int a = 0; a < 3; a++) { Rm[3 * a] = -sn * R[3 * a + 2]; Rm[3 * a + 1] = R[3 * a + 1]; Rm[3 * a + 2] = sn * R[3 * a]; }
+      const double tr = Rm[0] + Rm[4] + Rm[8];
+      if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+      else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+      else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+      m3mulv(t, R, m.hb_anchor[b]);
+      v3add(site, p, t);
+      for (int a = 0; a < 4; a++) L.sk.mocap_quat[hd][a] = q[a];
+      for (int a = 0; a < 3; a++) L.sk.mocap_pos[hd][a] = site[a] + 0.03 * R[3 * a + 2];
+    }
+  }
+#endif
   // sites of the measured joints: site k sits at the anchor of body meas_body[k]
   {
     const int k = lane < HRG_NHJ ? lane : 0;
@@ -299,7 +320,7 @@ DI void human_pose_fk(const DevModel* __restrict__ dm_, int lane, int clip, int 
   human_fk_lanes(dm_, lane, mp, mq, fr + 7, hold_body, hold_left);
 }
 
-#if HRG_BOX
+#if HRG_BOX || HRG_STACK
 // amplitude (speed = 0) or speed modifier (1) of layered sine k of the idle loop of animation slot ai in this episode
 // (sample_animation_loop_properties, utils/animation_utils.py:122-176), drawn counter-based on demand
 DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int k, int speed) {
@@ -398,6 +419,28 @@ PH_HUMAN void human_control(const DevModel* __restrict__ dm_, int lane, int64_t 
     hold_body = m.meas_body[hold_left ? m.site_lhand : m.site_rhand];
   }
 #endif
+#endif
+#if HRG_STACK
+  { // CollaborativeStackingCart._compute_animation_time (collaborative_stacking_cartesian_env.py:825-897); wave-uniform
+    hrg_stack_state& sk = L.sk;
+    const int classic = at, len = dm->clips.clip_len[clip];
+    const int k0 = dm->clips.clip_stack_keyframes[clip][0], k2 = dm->clips.clip_stack_keyframes[clip][2], k4 = dm->clips.clip_stack_keyframes[clip][4];
+    int phase = sk.task_phase, nd0 = sk.n_delayed[0], nd1 = sk.n_delayed[1];
+    if (phase == HRG_STK_APPROACH && at > k0) phase = HRG_STK_PLACE_FIRST;
+    else if (phase == HRG_STK_WAIT_FOR_SECOND) {
+      if (at >= k2) at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, 0, dm->clips.clip_n_loop[clip], (double)classic, (double)k2);
+      nd0 = classic - at; nd1 = 0;
+    } else if (phase == HRG_STK_PLACE_THIRD) at = classic - nd0;
+    else if (phase == HRG_STK_WAIT_FOR_FOURTH) {
+      at = classic - nd0;
+      if (at >= k4) at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, HRG_MAX_LOOP, dm->clips.clip_n_loop2[clip], (double)at, (double)k4);
+      nd1 = classic - at;
+    } else if (phase == HRG_STK_RETREAT) at = classic - nd1;
+    if (at >= len - 1) { phase = HRG_STK_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+    wave_sync();
+    sk.task_phase = phase; sk.n_delayed[0] = nd0; sk.n_delayed[1] = nd1;
+  }
 #endif
 #if HRG_LIFT
   if (m.task == HRG_TASK_LIFTING) { // CollaborativeLiftingCart._compute_animation_time (collaborative_lifting_cartesian_env.py:563-581): frozen at the last frame
@@ -624,6 +667,286 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 }
 
 // ================================================================================================ contacts
+#if HRG_STACK
+// Contacts of two boxes with the same half extents (centres pa / pb, rotations Ra / Rb row-major in LDS): separating-axis test over the 15 axes, then
+// the reference face's rectangle clipped against the incident face (candidates: incident vertices, rectangle corners under the incident face, edge
+// crossings; at most four penetrating candidates that span the patch are kept) or one edge-edge contact.  Restated as in
+// oracle/hrg_oracle.c box_box; one lane runs one pair.  Normal from box a to box b.  Returns the number of contacts (<= 4).
+struct BBContact { double pos[3], n[3], dist; };
+DI int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, BBContact* out, double* T) {
+  double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
+  v3sub(t, pb, pa);
+  for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = Ra[3 * k + i]; B[i][k] = Rb[3 * k + i]; }
+  for (int i = 0; i < 3; i++) { ta[i] = v3dot(t, A[i]); tb[i] = v3dot(t, B[i]); for (int j = 0; j < 3; j++) { C[i][j] = v3dot(A[i], B[j]); AC[i][j] = fabs(C[i][j]); } }
+  double sf = -1e300, se = -1e300;
+  int bf = 0, be = -1;
+  for (int i = 0; i < 3; i++) {
+    const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
+    if (s_ > 0) return 0;
+    if (s_ > sf) { sf = s_; bf = i; }
+  }
+  for (int j = 0; j < 3; j++) {
+    const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
+    if (s_ > 0) return 0;
+    if (s_ > sf) { sf = s_; bf = 3 + j; }
+  }
+#pragma unroll 1
+  for (int ij = 0; ij < 9; ij++) {
+    const int i = ij / 3, j = ij - 3 * i, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    const double l2 = 1.0 - C[i][j] * C[i][j];
+    if (l2 < 1e-12) continue;
+    const double l = sqrt(l2);
+    const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
+    const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
+    if (s_ > 0) return 0;
+    if (s_ > se) { se = s_; be = ij; }
+  }
+  if (be >= 0 && se * 1.05 > sf) {
+    const int i = be / 3, j = be - 3 * i;
+    double n[3], pA[3], pB[3], d[3];
+    v3cross(n, A[i], B[j]);
+    v3scl(n, n, 1.0 / v3norm(n));
+    if (v3dot(n, t) < 0) v3scl(n, n, -1.0);
+    v3cpy(pA, pa); v3cpy(pB, pb);
+    for (int k = 0; k < 3; k++) {
+      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * h[k]);
+      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * h[k]);
+    }
+    v3sub(d, pB, pA);
+    const double uaub = C[i][j], q1 = v3dot(A[i], d), q2 = -v3dot(B[j], d), den = 1.0 - uaub * uaub;
+    const double al = (q1 + uaub * q2) / den, be_ = (uaub * q1 + q2) / den;
+    double xa[3], xb[3];
+    v3madd(xa, pA, A[i], al);
+    v3madd(xb, pB, B[j], be_);
+    for (int k = 0; k < 3; k++) out[0].pos[k] = 0.5 * (xa[k] + xb[k]);
+    v3cpy(out[0].n, n);
+    out[0].dist = se;
+    return 1;
+  }
+  const bool refA = bf < 3;
+  const int r = refA ? bf : bf - 3, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
+  double Rf[3][3], In[3][3], pr[3], pi_[3];
+  for (int a = 0; a < 3; a++) for (int k = 0; k < 3; k++) { Rf[a][k] = refA ? A[a][k] : B[a][k]; In[a][k] = refA ? B[a][k] : A[a][k]; }
+  for (int k = 0; k < 3; k++) { pr[k] = refA ? pa[k] : pb[k]; pi_[k] = refA ? pb[k] : pa[k]; }
+  const double sg = refA ? (ta[r] >= 0 ? 1.0 : -1.0) : (tb[r] >= 0 ? -1.0 : 1.0);
+  double nr[3], cr[3], ci[3];
+  v3scl(nr, Rf[r], sg);
+  v3madd(cr, pr, nr, h[r]);
+  int k = 0;
+  double best = -1;
+  for (int q = 0; q < 3; q++) { const double c_ = fabs(v3dot(In[q], nr)); if (c_ > best) { best = c_; k = q; } }
+  const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
+  const double si = v3dot(In[k], nr) > 0 ? -1.0 : 1.0;
+  v3madd(ci, pi_, In[k], si * h[k]);
+  const double hu = h[r1], hv = h[r2];
+  const double S1[4] = {1, -1, -1, 1}, S2[4] = {1, 1, -1, -1};
+  double vu[4], vv[4], vd[4];
+  for (int q = 0; q < 4; q++) {
+    double x[3], d[3];
+    v3madd(x, ci, In[k1], S1[q] * h[k1]);
+    v3madd(x, x, In[k2], S2[q] * h[k2]);
+    v3sub(d, x, cr);
+    vu[q] = v3dot(d, Rf[r1]); vv[q] = v3dot(d, Rf[r2]); vd[q] = v3dot(d, nr);
+  }
+  // candidate table (u, v, depth; depth >= 0 marks "not a penetrating candidate") in the caller's LDS scratch: T[0..23] u, T[24..47] v, T[48..71] depth
+  for (int q = 0; q < 24; q++) T[48 + q] = 1.0;
+  auto offer = [&](int idx, double u, double v, double dpt) { if (dpt < 0) { T[idx] = u; T[24 + idx] = v; T[48 + idx] = dpt; } };
+  for (int q = 0; q < 4; q++)
+    if (fabs(vu[q]) <= hu && fabs(vv[q]) <= hv) offer(q, vu[q], vv[q], vd[q]);
+  {
+    double d0[3];
+    v3sub(d0, ci, cr);
+    const double c0u = v3dot(d0, Rf[r1]), c0v = v3dot(d0, Rf[r2]), c0d = v3dot(d0, nr);
+    const double e1u = h[k1] * v3dot(In[k1], Rf[r1]), e1v = h[k1] * v3dot(In[k1], Rf[r2]), e1d = h[k1] * v3dot(In[k1], nr);
+    const double e2u = h[k2] * v3dot(In[k2], Rf[r1]), e2v = h[k2] * v3dot(In[k2], Rf[r2]), e2d = h[k2] * v3dot(In[k2], nr);
+    const double det = e1u * e2v - e1v * e2u;
+    if (fabs(det) > 1e-12 * hu * hv)
+      for (int q = 0; q < 4; q++) {
+        const double pu = S1[q] * hu - c0u, pv = S2[q] * hv - c0v;
+        const double al = (pu * e2v - pv * e2u) / det, be_ = (e1u * pv - e1v * pu) / det;
+        if (fabs(al) <= 1 && fabs(be_) <= 1) offer(4 + q, S1[q] * hu, S2[q] * hv, c0d + al * e1d + be_ * e2d);
+      }
+  }
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const int q1 = (q + 1) & 3;
+    const double du = vu[q1] - vu[q], dv = vv[q1] - vv[q], dd = vd[q1] - vd[q];
+#pragma unroll 1
+    for (int e = 0; e < 4; e++) {
+      const double lim = (e & 1) ? -1.0 : 1.0;
+      if (e < 2) {
+        if (fabs(du) < 1e-14) continue;
+        const double tt = (lim * hu - vu[q]) / du, w = vv[q] + tt * dv;
+        if (tt > 0 && tt < 1 && fabs(w) < hv) offer(8 + 4 * q + e, lim * hu, w, vd[q] + tt * dd);
+      } else {
+        if (fabs(dv) < 1e-14) continue;
+        const double tt = (lim * hv - vv[q]) / dv, w = vu[q] + tt * du;
+        if (tt > 0 && tt < 1 && fabs(w) < hu) offer(8 + 4 * q + e, w, lim * hv, vd[q] + tt * dd);
+      }
+    }
+  }
+  // keep at most four that span the patch: the deepest, the one farthest from it, the farthest from their line on either side (ties -> lowest index)
+  int pick[4], np_ = 0;
+  const double eps2 = 1e-12 * (hu * hu + hv * hv);
+  {
+    int arg = -1;
+    double bd = 0;
+#pragma unroll 1
+    for (int q = 0; q < 24; q++) { const double dq = T[48 + q]; if (dq < 0 && (arg < 0 || dq < bd)) { arg = q; bd = dq; } }
+    if (arg >= 0) pick[np_++] = arg;
+  }
+  if (np_ == 1) {
+    int arg = -1;
+    double bestv = eps2;
+    const double u0 = T[pick[0]], v0 = T[24 + pick[0]];
+#pragma unroll 1
+    for (int q = 0; q < 24; q++) {
+      if (!(T[48 + q] < 0)) continue;
+      const double du = T[q] - u0, dv = T[24 + q] - v0, val = du * du + dv * dv;
+      if (val > bestv) { arg = q; bestv = val; }
+    }
+    if (arg >= 0) pick[np_++] = arg;
+  }
+  if (np_ == 2) {
+    const double u0 = T[pick[0]], v0 = T[24 + pick[0]], lu = T[pick[1]] - u0, lv = T[24 + pick[1]] - v0, epsc = sqrt(eps2 * (lu * lu + lv * lv));
+    int argp = -1, argn = -1;
+    double bp = epsc, bn = epsc;
+#pragma unroll 1
+    for (int q = 0; q < 24; q++) {
+      if (!(T[48 + q] < 0)) continue;
+      const double cr_ = lu * (T[24 + q] - v0) - lv * (T[q] - u0);
+      if (cr_ > bp) { argp = q; bp = cr_; }
+      if (-cr_ > bn) { argn = q; bn = -cr_; }
+    }
+    if (argp >= 0) pick[np_++] = argp;
+    if (argn >= 0) pick[np_++] = argn;
+  }
+  for (int z = 0; z < np_; z++) {
+    const double u = T[pick[z]], v = T[24 + pick[z]], dpt = T[48 + pick[z]];
+    for (int a = 0; a < 3; a++) {
+      out[z].pos[a] = cr[a] + u * Rf[r1][a] + v * Rf[r2][a] + 0.5 * dpt * nr[a];
+      out[z].n[a] = refA ? nr[a] : -nr[a];
+    }
+    out[z].dist = dpt;
+  }
+  return np_;
+}
+
+// The cubes' part of the stacking task's contact list (after the robot's own rounds): robot capsule x cube first points (cube-major), table corners,
+// floor corners, cube pairs (a < b; one lane per pair), second points of capsules lying along a face; and the object_gripped sensor.
+DI void collide_cubes(const DevModel* __restrict__ dm_, int lane, int* base_io) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_stack_state& sk = L.sk;
+  int base = *base_io;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  if (lane < NCUBE) { double Rm[9]; quat2mat(Rm, sk.quat[lane]); for (int a = 0; a < 9; a++) L.cR[lane][a] = Rm[a]; }
+  wave_sync();
+  const double hb[3] = {m.box_half[0], m.box_half[1], m.box_half[2]};
+  const double circ2 = hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2];
+  bool f0a = false, f1a = false, f0b = false, f1b = false;
+#pragma unroll 1
+  for (int round = 0; round < 4; round++) {
+    Contact c;
+    c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
+    bool hit = false;
+    if (round == 0 || round == 3) {   // capsule i x cube cb: first point / second point (a capsule lying along a face)
+      const bool second = round == 3;
+      const int cb = lane / HRG_NRCAP, i = lane - cb * HRG_NRCAP;
+      bool near = false;
+      if (lane < NCUBE * HRG_NRCAP && m.rcap_body[i] >= 0) {
+        double dc[3];
+        for (int a = 0; a < 3; a++) dc[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]) - sk.pos[cb][a];
+        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + sqrt(circ2) + 1e-9;
+        near = v3dot(dc, dc) <= reach * reach;
+      }
+      if (__any(near) && near) {
+        double cs[3], cbp[3];
+        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], sk.pos[cb], L.cR[cb], hb, cs, cbp);
+        double dd = sqrt(e2), dist = dd - m.rcap_r[i];
+        if (dist < 0) {
+          double s2[3], b2[3];
+          const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], sk.pos[cb], L.cR[cb], hb, m.rcap_r[i], cs, cbp, second ? 1 : 0, s2, b2);
+          if (two) { v3cpy(cs, s2); v3cpy(cbp, b2); double dv[3]; v3sub(dv, cbp, cs); dd = v3norm(dv); dist = dd - m.rcap_r[i]; }
+          hit = two || !second;
+          if (dd > 1e-9) { v3sub(c.n, cbp, cs); v3scl(c.n, c.n, 1.0 / dd); }
+          else {
+            double loc[3], rel[3], best = 1e300;
+            int ax = 0;
+            v3sub(rel, cs, sk.pos[cb]);
+            for (int a = 0; a < 3; a++) { loc[a] = L.cR[cb][a] * rel[0] + L.cR[cb][3 + a] * rel[1] + L.cR[cb][6 + a] * rel[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
+            const double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+            for (int a = 0; a < 3; a++) c.n[a] = sg * L.cR[cb][3 * a + ax];
+            dist = -best - m.rcap_r[i];
+          }
+          v3madd(c.pos, cs, c.n, m.rcap_r[i] + 0.5 * dist);
+          c.g1 = i; c.g2 = GEOM_BOX + cb; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX + cb; c.dist = dist;
+        }
+      }
+      const uint64_t mask = __ballot(hit);
+      const int slot = base + __popcll(mask & lt);
+      if (hit) {
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      if (!second) {   // object_gripped (1467-1481): both fingers on cube A, or both on cube B (contacts beyond the reported list do not count)
+        const bool rep = hit && slot < HRG_NCON_MAX;
+        f0a = __any(rep && lane == HRG_CUBE_A * HRG_NRCAP + HRG_NRCAP - 2); f1a = __any(rep && lane == HRG_CUBE_A * HRG_NRCAP + HRG_NRCAP - 1);
+        f0b = __any(rep && lane == HRG_CUBE_B * HRG_NRCAP + HRG_NRCAP - 2); f1b = __any(rep && lane == HRG_CUBE_B * HRG_NRCAP + HRG_NRCAP - 1);
+      }
+      base += __popcll(mask);
+    } else if (round == 1) {   // lanes 0..31: table x corner cn of cube cb, lanes 32..63: floor
+      const int pl = lane >> 5, cb = (lane >> 3) & 3, cn = lane & 7;
+      const double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]};
+      double p[3];
+      m3mulv(p, L.cR[cb], loc);
+      v3add(p, p, sk.pos[cb]);
+      const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
+      bool ok = true;
+      if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+      if (ok && dist < 0) {
+        hit = true;
+        v3set(c.n, 0, 0, 1);
+        v3set(c.pos, p[0], p[1], z0 + 0.5 * dist);
+        c.g1 = pl ? GEOM_FLOOR : GEOM_TABLE; c.g2 = GEOM_BOX + cb; c.b1 = -1; c.b2 = BODY_BOX + cb; c.dist = dist;
+      }
+      const uint64_t mask = __ballot(hit);
+      if (hit) {
+        const int slot = base + __popcll(mask & lt);
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      base += __popcll(mask);
+    } else {   // cube pairs: lane p < 6 runs pair (a, b)
+      int nc = 0;
+      BBContact bc[4];
+      int pa_ = 0, pb_ = 1;
+      if (lane < 6) {
+        const int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {1, 2, 3, 2, 3, 3};
+        pa_ = PA[lane]; pb_ = PB[lane];
+        double d[3];
+        v3sub(d, sk.pos[pb_], sk.pos[pa_]);
+        // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
+        if (!(v3dot(d, d) > 4.0 * circ2)) nc = box_box(sk.pos[pa_], L.cR[pa_], sk.pos[pb_], L.cR[pb_], hb, bc, &L.Jc[40][0] + 72 * lane);
+      }
+      // exclusive prefix of the contact counts over lanes 0..5
+      int pre = 0, tot = 0;
+      for (int q = 0; q < 6; q++) { const int nq = __shfl(nc, q, 64); if (q < lane) pre += nq; tot += nq; }
+      for (int q = 0; q < nc; q++) {
+        const int slot = base + pre + q;
+        c.g1 = GEOM_BOX + pa_; c.g2 = GEOM_BOX + pb_; c.b1 = BODY_BOX + pa_; c.b2 = BODY_BOX + pb_; c.dist = bc[q].dist;
+        v3cpy(c.n, bc[q].n); v3cpy(c.pos, bc[q].pos);
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      base += tot;
+    }
+  }
+  sk.gripped = (f0a && f1a) || (f0b && f1b);
+  *base_io = base;
+}
+#endif
 // Stand-in for mj_collision (bounding capsules, table top face, floor plane), pair order = contact order.
 PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_out) {
   const ModelPtr dm = uniform_model(dm_);
@@ -816,6 +1139,9 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
     base += __popcll(mask);
   }
 #endif
+#if HRG_STACK
+  collide_cubes(dm_, lane, &base);
+#endif
   const int ncon = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
   if (lane < HRG_NCON_MAX && lane >= ncon) { L.st.con_pairs[lane][0] = -1; L.st.con_pairs[lane][1] = -1; }
   L.st.ncon = ncon;
@@ -824,7 +1150,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
 }
 
 // the manipulation object is whitelisted -> COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717)
-DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g == GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
+DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }   // GEOM_BOX + c: cube c of the stacking task
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0

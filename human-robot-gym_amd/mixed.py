@@ -18,13 +18,14 @@ ICRA_TASKS = (
     ("CollaborativeLiftingCart", dict(horizon=5000, shield_type="SSM")),
     ("RobotHumanHandoverCart", dict(horizon=1000, shield_type="PFL")),
     ("HumanRobotHandoverCart", dict(horizon=1000, shield_type="PFL")),
+    ("CollaborativeStackingCart", dict(horizon=3000, shield_type="SSM")),
 )
 
 
 def task_clips(env_id, n_clips=13, seed=0, **kw):
     """Synthetic clip set carrying the animation info `env_id` reads."""
     extra = {"HumanObjectInspectionCart": dict(inspection=True), "HumanRobotHandoverCart": dict(handover=True),
-             "RobotHumanHandoverCart": dict(handover="r2h")}.get(env_id, {})
+             "RobotHumanHandoverCart": dict(handover="r2h"), "CollaborativeStackingCart": dict(stacking=True)}.get(env_id, {})
     if env_id == "CollaborativeLiftingCart":
         from .animation import lifting_hands_nominal
         extra = dict(lifting=lifting_hands_nominal(build_model_desc(None, env_id=env_id)), fps=20.0)

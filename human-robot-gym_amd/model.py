@@ -133,13 +133,33 @@ LIFTING_ENV_KWARGS = dict(
     safe_vel=0.001,
     lift_anchors=[[-0.45, 0.25, 0.0], [-0.45, -0.25, 0.0]],   # l_anchor / r_anchor of _postprocess_model, 786-795
 )
-ENV_DEFAULTS = {"CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
+# CollaborativeStackingCart constructor defaults (collaborative_stacking_cartesian_env.py:316-386) overlaid with
+# config/environment/(default/)collaborative_stacking_cart.yaml
+STACKING_ENV_KWARGS = dict(
+    PICK_PLACE_ENV_KWARGS,
+    horizon=3000,
+    table_full_size=[1.2, 2.0, 0.05],
+    object_full_size=[0.045, 0.045, 0.045],
+    goal_dist=0.025,
+    n_object_placements_sampled_per_100_steps=2,
+    n_animations_sampled_per_100_steps=5,
+    collision_reward=0.0,
+    stack_toppled_reward=-10.0,
+    task_reward=2.0,
+    second_cube_at_target_reward=0.0,
+    fourth_cube_at_target_reward=1.0,
+    object_gripped_reward=0.75,
+    human_rand=[0.02, 0.1, 0.1],
+    done_at_success=True,
+    stack_weld_relpos=[0.0, 0.045, 0.0],   # relpose of lh_weld_eq / rh_weld_eq (1263-1281)
+)
+ENV_DEFAULTS = {"CollaborativeStackingCart": STACKING_ENV_KWARGS, "CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
                 "RobotHumanHandoverCart": HANDOVER_R2H_ENV_KWARGS,
                 "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
                 "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
-BOX_TASKS = ("CollaborativeLiftingCart", "PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart",
+BOX_TASKS = ("CollaborativeStackingCart", "CollaborativeLiftingCart", "PickPlaceHumanCart", "PickPlaceCloseHumanCart", "PickPlacePointingHumanCart", "HumanObjectInspectionCart", "HumanRobotHandoverCart",
              "RobotHumanHandoverCart")
-_TASK_OF = {"CollaborativeLiftingCart": "HRG_TASK_LIFTING", "PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
+_TASK_OF = {"CollaborativeStackingCart": "HRG_TASK_STACKING", "CollaborativeLiftingCart": "HRG_TASK_LIFTING", "PickPlaceHumanCart": "HRG_TASK_PICK_PLACE", "PickPlaceCloseHumanCart": "HRG_TASK_PICK_PLACE",
             "PickPlacePointingHumanCart": "HRG_TASK_POINTING", "HumanObjectInspectionCart": "HRG_TASK_INSPECTION",
             "HumanRobotHandoverCart": "HRG_TASK_HANDOVER_H2R", "RobotHumanHandoverCart": "HRG_TASK_HANDOVER_R2H"}
 # RethinkValidGripper.qpos_range (models/grippers/rethink_valid_gripper.py:29-42)
@@ -584,6 +604,12 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
             d.object_in_human_hand_reward = float(kw["object_in_human_hand_reward"])
         if env_id == "HumanRobotHandoverCart":      # human_robot_handover_cartesian_env.py:713-730
             d.tgt_bin[:] = [bx * 0.45, bx * 0.85, -by * 0.15, by * 0.15]
+        if env_id == "CollaborativeStackingCart":   # _get_default_object_bin_boundaries (1058-1073); the four cubes share box_half / box_mass / box_inertia
+            d.obj_bin[:] = [bx * 0.5, bx * 0.8, -by * 0.15, by * 0.15]
+            d.stack_toppled_reward = float(kw["stack_toppled_reward"])
+            d.second_cube_at_target_reward = float(kw["second_cube_at_target_reward"])
+            d.fourth_cube_at_target_reward = float(kw["fourth_cube_at_target_reward"])
+            d.stack_weld_relpos[:] = [float(x) for x in kw["stack_weld_relpos"]]
         if env_id in ("HumanObjectInspectionCart", "HumanRobotHandoverCart"):
             d.object_at_target_reward = float(kw["object_at_target_reward"])
             d.goal_exit_tolerance = float(kw["goal_exit_tolerance"])

@@ -71,14 +71,17 @@ INFO_KEYS = [  # column order of the kernel's info block (include/hrgym.h)
     "n_collisions_critical", "timeout", "failsafe_interventions", "n_goal_reached", "TimeLimit.truncated", "sim_crash",
     "action_resamples", "n_object_handed_over",
 ]
+INFO_KEY_ALIASES = {"CollaborativeStackingCart": {"n_object_handed_over": "max_stack_height"}}   # the task-specific info column (include/hrgym.h HRG_INFO_MAX_STACK_HEIGHT)
 _BOOL_KEYS = {"collision", "timeout", "TimeLimit.truncated", "sim_crash"}
 _BOOL_ITEMS = [(j, k) for j, k in enumerate(INFO_KEYS) if k in _BOOL_KEYS]
 OBS_KEYS = ["object-state", "goal_difference"]  # default: training/config/human_reach_ppo_parallel.yaml:14-16
 # training/config/run/obs_keys of the pick-place experiments (e.g. PP-SAC): the observables the policy sees
 PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target", "gripper_aperture", "dist_eef_to_human_head",
                        "dist_eef_to_human_lh", "dist_eef_to_human_rh"]
+STACKING_OBS_KEYS = ["object_gripped", "vec_eef_to_all_objects", "gripper_aperture", "dist_eef_to_human_head", "dist_eef_to_human_lh", "dist_eef_to_human_rh"]   # CS-SAC.yaml run.obs_keys
 LIFTING_OBS_KEYS = ["board_quat", "dist_eef_to_human_head", "vec_eef_to_human_lh", "vec_eef_to_human_rh"]   # CL-SAC.yaml run.obs_keys
-DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else (LIFTING_OBS_KEYS if k == "CollaborativeLiftingCart" else PICK_PLACE_OBS_KEYS)) for k in ENV_DEFAULTS}
+DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else (LIFTING_OBS_KEYS if k == "CollaborativeLiftingCart" else (STACKING_OBS_KEYS if k == "CollaborativeStackingCart" else PICK_PLACE_OBS_KEYS)))
+                    for k in ENV_DEFAULTS}
 # columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
 OBS_COLUMNS = {
     "object-state": range(0, 12), "goal_difference": range(12, 18), "robot0_joint_pos": range(18, 24),
@@ -94,6 +97,10 @@ OBS_COLUMNS = {
     # first target column
     "board_pos": range(47, 50), "vec_eef_to_board": range(40, 43), "board_gripped": range(39, 40), "board_balance": range(50, 51),
     "board_quat": [43, 44, 45, 51],
+    # CollaborativeStackingCart (collaborative_stacking_cartesian_env.py:1306-1524): the vectors to the four cubes (a, b, l, r) take the 12 joint-space columns the cube
+    # tasks leave empty; vec_eef_to_object / object_pos follow the cube the robot has to place next; next_target_pos sits in the target columns
+    "vec_eef_to_all_objects": list(range(12, 18)) + list(range(33, 39)), "vec_eef_to_object_a": range(12, 15), "vec_eef_to_object_b": range(15, 18),
+    "vec_eef_to_object_l": range(33, 36), "vec_eef_to_object_r": range(36, 39), "next_target_pos": range(50, 53),
 }
 
 
@@ -150,13 +157,14 @@ class LazyInfo(dict):
 class _InfoSource:
     """What the infos of one step are filled from: a copy of the info block, the executed actions, the expert views."""
 
-    def __init__(self, rows, acts, expert, prev_full, term_obs):
+    def __init__(self, rows, acts, expert, prev_full, term_obs, keys=None):
         self.rows, self.acts, self.expert, self.prev_full, self.term_obs = rows, acts, expert, prev_full, term_obs
+        self.keys = keys or INFO_KEYS
 
     def fill(self, d, i):
         row = self.rows[i].tolist()
         set_ = dict.__setitem__
-        for k, v in zip(INFO_KEYS, row):
+        for k, v in zip(self.keys, row):
             if k != "TimeLimit.truncated":
                 set_(d, k, v)
         for j, k in _BOOL_ITEMS:
@@ -222,6 +230,7 @@ class HipVecEnv(_VecEnvBase):
     _norm = None      # (mean, std, squash_factor) of DatasetObsNormWrapper, when configured
     _monitor = None   # open Monitor csv, when monitor_dir is given
     _monitor_keys = ()
+    _info_keys = INFO_KEYS   # names of the info columns (a task may rename its task-specific column: INFO_KEY_ALIASES)
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
@@ -229,12 +238,13 @@ class HipVecEnv(_VecEnvBase):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
+        self._info_keys = [INFO_KEY_ALIASES.get(env_id, {}).get(k, k) for k in INFO_KEYS]
         # GoalEnvironmentGymWrapper (wrappers/goal_env_wrapper.py): dict observations {observation, achieved_goal, desired_goal} and an
         # externalised reward for hindsight relabelling.  Goals per task: ReachHuman joint angles (reach_human_env.py:477-507),
         # the cube tasks [eef_pos, object_pos, object_gripped] vs target_pos (pick_place_human_cartesian_env.py:574-611)
         self.goal_env = bool(goal_env)
         if self.goal_env:
-            if env_id in ("HumanObjectInspectionCart", "CollaborativeLiftingCart"):
+            if env_id in ("HumanObjectInspectionCart", "CollaborativeLiftingCart", "CollaborativeStackingCart"):
                 raise NotImplementedError("goal_env: this task's success is a task phase, not a function of the goals")
             if obs_keys is None:  # goal_env_wrapper.py:62-71
                 obs_keys = ["object-state", "robot0_proprio-state", "desired_goal"]
@@ -357,7 +367,8 @@ class HipVecEnv(_VecEnvBase):
     def _make_infos(self, info, dones, term_obs):
         # the per-env dicts are filled from a copy of the info block on first use (LazyInfo)
         info = np.array(info, copy=True)
-        src = _InfoSource(info, self._actions, self.expert_obs_keys, self._expert_cur, np.array(term_obs, copy=True) if self.expert_obs_keys is not None else None)
+        src = _InfoSource(info, self._actions, self.expert_obs_keys, self._expert_cur, np.array(term_obs, copy=True) if self.expert_obs_keys is not None else None,
+                          keys=self._info_keys)
         n = self.num_envs
         new = LazyInfo.__new__
         infos = [new(LazyInfo) for _ in range(n)]
@@ -419,6 +430,8 @@ class HipVecEnv(_VecEnvBase):
             raise NotImplementedError("get_environment_state needs the HIP batch backend")
         idx = self._indices(indices)
         states, boxes = batch.get_states(np.asarray(idx, np.int32))
+        if self.env_id == "CollaborativeStackingCart":   # CollaborativeStackingEnvState (collaborative_stacking_cartesian_env.py:63-97): the four cubes + stack bookkeeping
+            return [(st, batch.get_stack(i)) for st, i in zip(states, idx)]
         has_box = self.env_id != "ReachHuman"
         return [(st, boxes[k] if has_box else None) for k, st in enumerate(states)]
 
@@ -431,6 +444,11 @@ class HipVecEnv(_VecEnvBase):
             raise ValueError(f"{len(states)} states for {len(idx)} envs")
         from ._cstruct import BoxState, EnvState
         st_arr = (EnvState * len(idx))(*[st for st, _ in states])
+        if self.env_id == "CollaborativeStackingCart":
+            batch.set_states(np.asarray(idx, np.int32), st_arr, None)
+            for i, (_, sk) in zip(idx, states):
+                batch.set_stack(i, sk)
+            return
         boxes = [b for _, b in states]
         bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and self.env_id != "ReachHuman" else None
         batch.set_states(np.asarray(idx, np.int32), st_arr, bx_arr)

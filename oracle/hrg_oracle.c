@@ -2038,8 +2038,8 @@ static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env
 /* Contacts of two boxes with the same half extents h (centres pa / pb, rotations Ra / Rb row-major): separating-axis test over the 15 axes; the axis of
  * least penetration decides.  A face axis: the face of the other box most anti-parallel to it is clipped against the reference face's rectangle --
  * candidates = incident vertices inside the rectangle (0..3), rectangle corners under the incident face (4..7), crossings of the incident edges with the
- * rectangle's sides (8..23); of those that penetrate, the extreme one along each diagonal of the reference face is kept (<= 4 contacts, a resting face keeps
- * its whole support polygon's span).  An edge-edge axis (only when clearly less penetrating, factor 1.05): one contact between the closest points of the two
+ * rectangle's sides (8..23); of those that penetrate, at most four are kept: the deepest, the one farthest from it, and the farthest from their line on
+ * either side (a resting face keeps a quadrilateral that spans its support polygon).  An edge-edge axis (only when clearly less penetrating, factor 1.05): one contact between the closest points of the two
  * edges.  Normal from box a to box b.  Stand-in for mjc_BoxBox [UPSTREAM]. */
 typedef struct { double pos[3], n[3], dist; } bb_contact;
 static int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, bb_contact out[4]) {
@@ -2153,19 +2153,38 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
       }
     }
   }
+  /* of the penetrating candidates keep at most four that span the contact patch: the deepest, the one farthest from it, then the one farthest from
+   * their line on either side (ties -> the lowest candidate index; a candidate closer than 1e-6 of an edge to what is already kept adds nothing) */
   int pick[4], np_ = 0;
-  for (int q = 0; q < 4; q++) { /* extreme penetrating candidate along each diagonal; ties -> the lowest candidate index */
+  const double eps2 = 1e-12 * (hu * hu + hv * hv);
+  for (int c_ = 0; c_ < 24; c_++) if (ok[c_] && !(cd[c_] < 0)) ok[c_] = 0;
+  {
     int arg = -1;
-    double bestv = 0;
+    for (int c_ = 0; c_ < 24; c_++) if (ok[c_] && (arg < 0 || cd[c_] < cd[arg])) arg = c_;
+    if (arg >= 0) pick[np_++] = arg;
+  }
+  if (np_ == 1) {
+    int arg = -1;
+    double bestv = eps2;
     for (int c_ = 0; c_ < 24; c_++) {
-      if (!ok[c_] || !(cd[c_] < 0)) continue;
-      const double val = S1[q] * cu[c_] / hu + S2[q] * cv[c_] / hv;
-      if (arg < 0 || val > bestv) { arg = c_; bestv = val; }
+      if (!ok[c_]) continue;
+      const double du = cu[c_] - cu[pick[0]], dv = cv[c_] - cv[pick[0]], val = du * du + dv * dv;
+      if (val > bestv) { arg = c_; bestv = val; }
     }
-    if (arg < 0) break;
-    int dup = 0;
-    for (int z = 0; z < np_; z++) if (pick[z] == arg) dup = 1;
-    if (!dup) pick[np_++] = arg;
+    if (arg >= 0) pick[np_++] = arg;
+  }
+  if (np_ == 2) {
+    const double lu = cu[pick[1]] - cu[pick[0]], lv = cv[pick[1]] - cv[pick[0]], epsc = sqrt(eps2 * (lu * lu + lv * lv));
+    int argp = -1, argn = -1;
+    double bp = epsc, bn = epsc;
+    for (int c_ = 0; c_ < 24; c_++) {
+      if (!ok[c_]) continue;
+      const double cr_ = lu * (cv[c_] - cv[pick[0]]) - lv * (cu[c_] - cu[pick[0]]);
+      if (cr_ > bp) { argp = c_; bp = cr_; }
+      if (-cr_ > bn) { argn = c_; bn = -cr_; }
+    }
+    if (argp >= 0) pick[np_++] = argp;
+    if (argn >= 0) pick[np_++] = argn;
   }
   for (int z = 0; z < np_; z++) {
     const int c_ = pick[z];

@@ -101,6 +101,15 @@ class OracleBatch:
     def set_box(self, e, s):
         assert self.lib.hrgo_set_box(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
 
+    def get_stack(self, e):
+        from human_robot_gym_amd._cstruct import StackState
+        s = StackState()
+        assert self.lib.hrgo_get_stack(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+        return s
+
+    def set_stack(self, e, s):
+        assert self.lib.hrgo_set_stack(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+
     def check_actions(self, actions):
         a = np.ascontiguousarray(actions, np.float64)
         out = np.zeros(self.n, np.uint8)

@@ -8,11 +8,11 @@ from human_robot_gym_amd.model import ENV_DEFAULTS
 
 
 def test_even_split_and_task_table():
-    assert mixed.split_evenly(4096, 4) == [1024] * 4 and len(mixed.ICRA_TASKS) == 5
+    assert mixed.split_evenly(4096, 4) == [1024] * 4 and len(mixed.ICRA_TASKS) == 6     # the six tasks of icra_2024_run_experiments.sh:4-9
     assert mixed.split_evenly(10, 4) == [3, 3, 2, 2] and sum(mixed.split_evenly(4097, 6)) == 4097
     for env_id, kw in mixed.ICRA_TASKS:
         assert env_id in ENV_DEFAULTS
-        assert kw["horizon"] == {"ReachHuman": 100, "CollaborativeLiftingCart": 5000}.get(env_id, 1000)          # icra_2024_run_experiments.sh:4-9
+        assert kw["horizon"] == {"ReachHuman": 100, "CollaborativeLiftingCart": 5000, "CollaborativeStackingCart": 3000}.get(env_id, 1000)   # icra_2024_run_experiments.sh:4-9
         assert kw["shield_type"] == ("PFL" if "Handover" in env_id else "SSM")
         clips = mixed.task_clips(env_id, 2, min_frames=60, max_frames=80)
         assert clips.n_clips == 2
@@ -32,7 +32,7 @@ def test_mixed_batch_equals_the_per_task_batches(concurrent):
     """Each task's rows of a mixed batch are bit-identical to that task stepped alone (same global env ids, same actions)."""
     import torch
     from human_robot_gym_amd._lib import HipBatch
-    n = 40
+    n = 42
     M = mixed.make_mixed_batch(n, n_clips=3, seed=5, concurrent=concurrent)
     assert M.env_ids == [t[0] for t in mixed.ICRA_TASKS] and M.n == n
     singles = []
@@ -83,3 +83,38 @@ def test_mixed_vec_env_surface():
     assert env2.reset().shape == (8, 4)
     env.close()
     env2.close()
+
+
+@pytest.mark.gpu
+def test_six_task_mixed_batch_at_4096_envs():
+    """BASELINE configs[4] on one GPU: the six ICRA tasks, 4096 envs split evenly, each task's kernel on its own stream.  Size-independent properties over
+    40 steps, and every task's rows bit-identical to the task stepped alone at the same global env ids."""
+    import torch
+    from human_robot_gym_amd._lib import HipBatch
+    n = 4096
+    M = mixed.make_mixed_batch(n, seed=11)
+    assert len(M.env_ids) == 6 and M.n == n and [sl.stop - sl.start for sl in M.slices] == [683, 683, 683, 683, 682, 682]
+    singles = []
+    for (env_id, kw), sl in zip(mixed.ICRA_TASKS, M.slices):
+        clips = mixed.task_clips(env_id, 13)
+        singles.append(HipBatch(hrg.build_model_desc(dict(kw, seed=11), n_clips=clips.n_clips, env_id=env_id), clips, sl.stop - sl.start, env_id0=sl.start))
+    obs = M.reset()
+    for S, sl in zip(singles, M.slices):
+        assert torch.equal(obs[sl], S.reset())
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    crashes = 0
+    for k in range(40):
+        a = torch.rand((n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        o, r, d, i = M.step(a)
+        torch.cuda.synchronize()
+        assert torch.isfinite(o).all() and torch.isfinite(r).all()
+        crashes += int(i[:, 11].sum())
+        for S, sl in zip(singles, M.slices):
+            so, sr, sd, si = S.step(a[sl].contiguous())
+            assert torch.equal(o[sl], so) and torch.equal(r[sl], sr) and torch.equal(d[sl], sd) and torch.equal(i[sl], si), f"step {k} {S}"
+    st = M.slices[M.env_ids.index("CollaborativeStackingCart")]
+    assert int(M.info[st, 13].max()) >= 1                 # max_stack_height: the human has put its first cube down somewhere
+    assert crashes < 0.01 * n * 40
+    for S in singles:
+        S.close()
+    M.close()

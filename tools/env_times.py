@@ -7,7 +7,7 @@ from human_robot_gym_amd import _lib
 from human_robot_gym_amd._lib import HipBatch, load_library
 _lib.use_variant_library("human-robot-gym_amd/variant_stamps.so")   # the -DHRG_STAMPS diagnostic build
 lib = load_library()
-n = 4096
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 clips = hrg.synthetic_clips(13, seed=0)
 kw = dict(shield_type="SSM", control_freq=10, horizon=100, done_at_success=True, reward_shaping=True, seed=1234)
 G = HipBatch(hrg.build_model_desc(kw, n_clips=13), clips, n); G.reset()
