@@ -672,6 +672,8 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 // the reference face's rectangle clipped against the incident face (candidates: incident vertices, rectangle corners under the incident face, edge
 // crossings; at most four penetrating candidates that span the patch are kept) or one edge-edge contact.  Restated as in
 // oracle/hrg_oracle.c box_box; one lane runs one pair.  Normal from box a to box b.  Returns the number of contacts (<= 4).
+// near-ties between separating axes / candidate depths go to the earlier one unless the later wins by this margin (1 nm)
+#define BB_TIE 1e-9
 struct BBContact { double pos[3], n[3], dist; };
 DI int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, BBContact* out, double* T) {
   double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
@@ -683,12 +685,12 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
   for (int i = 0; i < 3; i++) {
     const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
     if (s_ > 0) return 0;
-    if (s_ > sf) { sf = s_; bf = i; }
+    if (s_ > sf + BB_TIE) { sf = s_; bf = i; }
   }
   for (int j = 0; j < 3; j++) {
     const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
     if (s_ > 0) return 0;
-    if (s_ > sf) { sf = s_; bf = 3 + j; }
+    if (s_ > sf + BB_TIE) { sf = s_; bf = 3 + j; }
   }
 #pragma unroll 1
   for (int ij = 0; ij < 9; ij++) {
@@ -699,7 +701,7 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
     const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
     if (s_ > 0) return 0;
-    if (s_ > se) { se = s_; be = ij; }
+    if (s_ > se + BB_TIE) { se = s_; be = ij; }
   }
   if (be >= 0 && se * 1.05 > sf) {
     const int i = be / 3, j = be - 3 * i;
@@ -792,7 +794,7 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     int arg = -1;
     double bd = 0;
 #pragma unroll 1
-    for (int q = 0; q < 24; q++) { const double dq = T[48 + q]; if (dq < 0 && (arg < 0 || dq < bd)) { arg = q; bd = dq; } }
+    for (int q = 0; q < 24; q++) { const double dq = T[48 + q]; if (dq < 0 && (arg < 0 || dq < bd - BB_TIE)) { arg = q; bd = dq; } }
     if (arg >= 0) pick[np_++] = arg;
   }
   if (np_ == 1) {
@@ -803,7 +805,7 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     for (int q = 0; q < 24; q++) {
       if (!(T[48 + q] < 0)) continue;
       const double du = T[q] - u0, dv = T[24 + q] - v0, val = du * du + dv * dv;
-      if (val > bestv) { arg = q; bestv = val; }
+      if (val > bestv * (1 + 1e-9)) { arg = q; bestv = val; }
     }
     if (arg >= 0) pick[np_++] = arg;
   }
@@ -815,8 +817,8 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     for (int q = 0; q < 24; q++) {
       if (!(T[48 + q] < 0)) continue;
       const double cr_ = lu * (T[24 + q] - v0) - lv * (T[q] - u0);
-      if (cr_ > bp) { argp = q; bp = cr_; }
-      if (-cr_ > bn) { argn = q; bn = -cr_; }
+      if (cr_ > bp * (1 + 1e-9)) { argp = q; bp = cr_; }
+      if (-cr_ > bn * (1 + 1e-9)) { argn = q; bn = -cr_; }
     }
     if (argp >= 0) pick[np_++] = argp;
     if (argn >= 0) pick[np_++] = argn;

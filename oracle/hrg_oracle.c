@@ -2041,6 +2041,9 @@ static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env
  * rectangle's sides (8..23); of those that penetrate, at most four are kept: the deepest, the one farthest from it, and the farthest from their line on
  * either side (a resting face keeps a quadrilateral that spans its support polygon).  An edge-edge axis (only when clearly less penetrating, factor 1.05): one contact between the closest points of the two
  * edges.  Normal from box a to box b.  Stand-in for mjc_BoxBox [UPSTREAM]. */
+/* near-ties between separating axes / candidate depths are broken towards the earlier one unless the later wins by this margin (1 nm): two nearly
+ * parallel cubes keep their reference face while rounding-level differences come and go */
+#define BB_TIE 1e-9
 typedef struct { double pos[3], n[3], dist; } bb_contact;
 static int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, bb_contact out[4]) {
   double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
@@ -2052,12 +2055,12 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
   for (int i = 0; i < 3; i++) {
     const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
     if (s_ > 0) return 0;
-    if (s_ > sf) { sf = s_; bf = i; }
+    if (s_ > sf + BB_TIE) { sf = s_; bf = i; }
   }
   for (int j = 0; j < 3; j++) {
     const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
     if (s_ > 0) return 0;
-    if (s_ > sf) { sf = s_; bf = 3 + j; }
+    if (s_ > sf + BB_TIE) { sf = s_; bf = 3 + j; }
   }
   for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) {
     const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
@@ -2067,7 +2070,7 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j]; /* t . (A_i x B_j) */
     const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
     if (s_ > 0) return 0;
-    if (s_ > se) { se = s_; be = 3 * i + j; }
+    if (s_ > se + BB_TIE) { se = s_; be = 3 * i + j; }
   }
   if (be >= 0 && se * 1.05 > sf) { /* edge - edge */
     const int i = be / 3, j = be % 3;
@@ -2160,7 +2163,7 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
   for (int c_ = 0; c_ < 24; c_++) if (ok[c_] && !(cd[c_] < 0)) ok[c_] = 0;
   {
     int arg = -1;
-    for (int c_ = 0; c_ < 24; c_++) if (ok[c_] && (arg < 0 || cd[c_] < cd[arg])) arg = c_;
+    for (int c_ = 0; c_ < 24; c_++) if (ok[c_] && (arg < 0 || cd[c_] < cd[arg] - BB_TIE)) arg = c_;
     if (arg >= 0) pick[np_++] = arg;
   }
   if (np_ == 1) {
@@ -2169,7 +2172,7 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     for (int c_ = 0; c_ < 24; c_++) {
       if (!ok[c_]) continue;
       const double du = cu[c_] - cu[pick[0]], dv = cv[c_] - cv[pick[0]], val = du * du + dv * dv;
-      if (val > bestv) { arg = c_; bestv = val; }
+      if (val > bestv * (1 + 1e-9)) { arg = c_; bestv = val; }
     }
     if (arg >= 0) pick[np_++] = arg;
   }
@@ -2180,8 +2183,8 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     for (int c_ = 0; c_ < 24; c_++) {
       if (!ok[c_]) continue;
       const double cr_ = lu * (cv[c_] - cv[pick[0]]) - lv * (cu[c_] - cu[pick[0]]);
-      if (cr_ > bp) { argp = c_; bp = cr_; }
-      if (-cr_ > bn) { argn = c_; bn = -cr_; }
+      if (cr_ > bp * (1 + 1e-9)) { argp = c_; bp = cr_; }
+      if (-cr_ > bn * (1 + 1e-9)) { argn = c_; bn = -cr_; }
     }
     if (argp >= 0) pick[np_++] = argp;
     if (argn >= 0) pick[np_++] = argn;
@@ -2859,6 +2862,7 @@ void hrgo_test_robot(const hrg_model_desc* m, const double* q, const double* qd,
 double hrgo_test_segseg(const double* p1, const double* q1, const double* p2, const double* q2, double* c1, double* c2) { return seg_seg(p1, q1, p2, q2, c1, c2); }
 void hrgo_test_ltt(const hrg_model_desc* m, const double* q0, const double* v0, const double* a0, const double* goal, hrg_ltt* L) { ltt_plan(m, L, q0, v0, a0, goal); }
 void hrgo_test_ltt_eval(const hrg_ltt* L, int j, double s, double* out3) { ltt_eval(L, j, s, out3, out3 + 1, out3 + 2); }
+void hrgo_test_path_eval(const hrg_path* P, double t, double ve, double* out3) { path_eval(P, t, ve, out3, out3 + 1, out3 + 2); }
 void hrgo_test_path(double s0, double v0, double a0, double ve, double amax, double jmax, double t, double* out4) {
   hrg_path P;
   path_plan(&P, s0, v0, a0, ve, amax, jmax);

@@ -28,6 +28,7 @@ def load():
     lib.hrgo_test_u01.argtypes = [ctypes.c_uint64] * 5
     lib.hrgo_test_path.argtypes = [ctypes.c_double] * 7 + [ctypes.c_void_p]
     lib.hrgo_test_ltt_eval.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_double, ctypes.c_void_p]
+    lib.hrgo_test_path_eval.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_double, ctypes.c_void_p]
     return lib
 
 

@@ -63,35 +63,59 @@ def flat_state(s, names=None):
     return np.array(fl), np.array(it)
 
 
-def _ltt_samples(ltt):
-    """A long-term trajectory as what it commands: (q, q', q'') of every joint at fractions of its duration.  The segment
-    table itself has knife edges (a start-acceleration ramp exists only for |a0| > 1e-9, zero-length segments move
-    between slots), so two tables that command the same motion need not be equal entry by entry."""
+def _ltt_samples(ltt, T):
+    """A long-term trajectory as what it commands: (q, q', q'') of every joint at fixed times (fractions of the ORACLE's duration T, the same absolute times
+    for both sides).  The segment table itself has knife edges (a start-acceleration ramp exists only for |a0| > 1e-9, zero-length segments move between
+    slots), so two tables that command the same motion need not be equal entry by entry."""
     from oracle.oracle import load
     lib = load()
     out = (ctypes.c_double * 3)()
     res = []
     for j in range(CONST["HRG_NARM"]):
         for f in (0.0, 0.15, 0.3, 0.5, 0.7, 0.85, 1.0, 1.2):
-            lib.hrgo_test_ltt_eval(ctypes.byref(ltt), ctypes.c_int(j), ctypes.c_double(f * ltt.T), out)
+            lib.hrgo_test_ltt_eval(ctypes.byref(ltt), ctypes.c_int(j), ctypes.c_double(f * T), out)
             res += list(out)
+    return np.array(res).reshape(-1, 3)
+
+
+def _path_samples(path, T):
+    """A fail-safe / recovery profile of the path parameter as what it commands: (s, s', s'') at fixed times within the ORACLE's duration T.  Its three
+    (duration, jerk) phases are not unique either: a single ramp can sit in the first or in the last slot with an empty phase of the opposite sign beside it."""
+    from oracle.oracle import load
+    lib = load()
+    out = (ctypes.c_double * 3)()
+    res = []
+    for f in (0.0, 0.2, 0.4, 0.6, 0.8, 1.0):
+        lib.hrgo_test_path_eval(ctypes.byref(path), ctypes.c_double(f * T), ctypes.c_double(0.0), out)
+        res.append(list(out))
     return np.array(res)
 
 
 def assert_state_close(so, sg, what=""):
+    """Integers bit-exact; floats within the north-star tolerance (1e-5 relative, ATOL absolute).  Exceptions, each a knife edge of a REPRESENTATION, not of
+    the motion it stands for (the motion itself is compared at 1e-5):
+      * ltt.dur / ltt.jerk / safe_path.dur / safe_path.jerk are compared through the trajectory they define, sampled at fixed times (see above);
+      * the sampled second derivatives sit on ramps of slope j_max (15 rad/s^3 for the joints, path_jmax for s): a segment boundary that moves by dt moves
+        them by j dt.  Boundaries are square roots of velocity differences, so rounding-level state differences (1e-16) at |dv| ~ 1e-10 move a boundary by
+        ~1e-8 s: atol 1e-6 on q'' (5e-6 on s'', whose jerk is ~20 x larger);
+      * ltt.T (the sum of the durations) changes by the length of a ramp that exists on one side only (|a0| just above / below 1e-9: 2 sqrt(1e-9 / j) ~ 1.6e-5 s)."""
     names = ([], [])
     fo, io = flat_state(so, names)
     fg, ig = flat_state(sg)
     if hasattr(so, "ltt"):
-        keep = np.array([not (nm.startswith("st.ltt.dur") or nm.startswith("st.ltt.jerk")) for nm in names[0]])
+        rep = (".ltt.dur", ".ltt.jerk", ".safe_path.dur", ".safe_path.jerk")
+        keep = np.array([not any(r in nm for r in rep) for nm in names[0]])
         fo, fg, names = fo[keep], fg[keep], ([nm for nm, k in zip(names[0], keep) if k], names[1])
-        # sampled q'' values sit on piecewise-linear ramps of slope j_max = 15 rad/s^3: a 1e-6 s shift of a segment boundary moves them by 1.5e-5
-        np.testing.assert_allclose(_ltt_samples(sg.ltt), _ltt_samples(so.ltt), rtol=1e-4, atol=2e-5, err_msg=f"long-term trajectory differs {what}")
+        lo, lg = _ltt_samples(so.ltt, so.ltt.T), _ltt_samples(sg.ltt, so.ltt.T)
+        np.testing.assert_allclose(lg[:, :2], lo[:, :2], rtol=RTOL, atol=ATOL, err_msg=f"long-term trajectory (q, q') differs {what}")
+        np.testing.assert_allclose(lg[:, 2], lo[:, 2], rtol=RTOL, atol=1e-6, err_msg=f"long-term trajectory (q'') differs {what}")
+        Tp = sum(so.safe_path.dur)
+        po, pg = _path_samples(so.safe_path, Tp), _path_samples(sg.safe_path, Tp)
+        np.testing.assert_allclose(pg[:, :2], po[:, :2], rtol=RTOL, atol=ATOL, err_msg=f"fail-safe path (s, s') differs {what}")
+        np.testing.assert_allclose(pg[:, 2], po[:, 2], rtol=RTOL, atol=5e-6, err_msg=f"fail-safe path (s'') differs {what}")
     bad_i = [f"{names[1][k]}: oracle {io[k]} hip {ig[k]}" for k in np.nonzero(io != ig)[0][:12]]
     assert not bad_i, f"integer state differs {what}: {bad_i}"
-    # segment durations of a planned profile are square roots of velocity differences: a ramp of ~1e-10 rad/s has a
-    # duration of microseconds that moves by its own size under rounding-level state differences (and carries no motion)
-    atol = np.array([2e-5 if (".dur[" in nm or nm == "st.ltt.T") else ATOL for nm in names[0]])
+    atol = np.array([2e-5 if nm == "st.ltt.T" else ATOL for nm in names[0]])
     bad = np.nonzero(~(np.abs(fg - fo) <= atol + RTOL * np.abs(fo)))[0]
     bad_f = [f"{names[0][k]}: oracle {fo[k]!r} hip {fg[k]!r}" for k in bad[:12]]
     assert not bad_f, f"float state differs {what}: {bad_f}"

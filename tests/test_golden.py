@@ -13,7 +13,7 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 from tools_cases import CASES, GPU_CASES  # noqa: E402
 
 
-from make_golden import clips_for as _clips  # noqa: E402
+from make_golden import clips_for as _clips, object_rows  # noqa: E402
 
 
 def _desc(name, clips):
@@ -30,9 +30,6 @@ def _deliver(B, n, env_id, k):  # the scripted delivery of the pick-place case (
             B.set_box(e, bx)
 
 
-def _box(B, n):
-    bxs = [B.get_box(e) for e in range(n)]
-    return np.array([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs])
 
 
 @pytest.mark.parametrize("name", sorted(CASES))
@@ -47,7 +44,8 @@ def test_oracle_reproduces_golden(name):
     for k in range(g["actions"].shape[0]):
         _deliver(B, n, env_id, k)
         o, r, d, i = B.step(g["actions"][k])
-        np.testing.assert_allclose(_box(B, n), g["box"][k], rtol=1e-6, atol=1e-9)
+        fl, it = object_rows(B, env_id, n)
+        np.testing.assert_allclose(fl, g["box"][k], rtol=1e-6, atol=1e-9)
         np.testing.assert_array_equal(i, g["info"][k], err_msg=f"step {k}")
         np.testing.assert_array_equal(d, g["done"][k])
         np.testing.assert_allclose(o, g["obs"][k], rtol=1e-6, atol=1e-7)
@@ -56,8 +54,7 @@ def test_oracle_reproduces_golden(name):
         np.testing.assert_array_equal(nc, g["ncon"][k])
         np.testing.assert_array_equal(p, g["pairs"][k].astype(np.int32))
         if "phase" in g:
-            bxs = [B.get_box(e) for e in range(n)]
-            np.testing.assert_array_equal(np.array([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs]), g["phase"][k])
+            np.testing.assert_array_equal(it, g["phase"][k])
 
 
 @pytest.mark.gpu
@@ -83,13 +80,13 @@ def test_hip_reproduces_golden(name):
         np.testing.assert_allclose(r.cpu().numpy()[live], g["reward"][k][live], rtol=1e-5, atol=1e-6)
         q = np.array([list(B.get_state(e).qpos) for e in range(n)])
         np.testing.assert_allclose(q[live], g["qpos"][k][live], rtol=1e-5, atol=1e-7)               # north_star: qpos within 1e-5 rel
-        np.testing.assert_allclose(_box(B, n)[live], g["box"][k][live], rtol=1e-5, atol=1e-7)
+        fl, it = object_rows(B, env_id, n)
+        np.testing.assert_allclose(fl[live], g["box"][k][live], rtol=1e-5, atol=1e-7)
         p, nc = B.contacts()
         np.testing.assert_array_equal(nc[live], g["ncon"][k][live])                                   # contact-pair indices bit-exact
         np.testing.assert_array_equal(p[live], g["pairs"][k].astype(np.int32)[live])
         if "phase" in g:
-            bxs = [B.get_box(e) for e in range(n)]
-            np.testing.assert_array_equal(np.array([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs])[live], g["phase"][k][live])
+            np.testing.assert_array_equal(it[live], g["phase"][k][live])
     from helpers import record_live
     record_live(f"test_golden::{name}", live, 0.9)
     B.close()

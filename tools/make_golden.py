@@ -27,10 +27,23 @@ CASES = {
     "handover_h2r_pfl": dict(env_id="HumanRobotHandoverCart", shield_type="PFL", horizon=60),
     "handover_r2h_pfl": dict(env_id="RobotHumanHandoverCart", shield_type="PFL", horizon=60),
     "lifting_ssm": dict(env_id="CollaborativeLiftingCart", shield_type="SSM", horizon=60),
+    # four free cubes: two resting on the table, two welded to the hands; the human drops its first cube at its keyframe (it falls to the table / floor)
+    "stacking_ssm": dict(env_id="CollaborativeStackingCart", shield_type="SSM", horizon=60),
 }
-# cases whose free-running GPU rollout is compared against the fixture (tests/test_golden.py); the lifting task's finger / board contacts chatter,
-# its oracle <-> HIP parity is checked with re-synchronisation in tests/test_lifting.py
-GPU_CASES = [k for k in CASES if k != "lifting_ssm"]
+# cases whose free-running GPU rollout is compared against the fixture (tests/test_golden.py): all of them
+GPU_CASES = list(CASES)
+
+
+def object_rows(B, env_id, n):
+    """(float rows, integer rows) of the manipulation object(s) of every env: what the fixtures store as `box` / `phase`."""
+    if env_id == "CollaborativeStackingCart":
+        sks = [B.get_stack(e) for e in range(n)]
+        fl = [[x for c in range(4) for x in list(s.pos[c]) + list(s.quat[c]) + list(s.vel[c])] + list(s.target) for s in sks]
+        it = [[s.task_phase, s.weld_active[0], s.weld_active[1], s.gripped, s.n_stack, s.max_stack_height, s.has_target] + list(s.stack_ids) for s in sks]
+        return np.array(fl), np.array(it, np.int32)
+    bxs = [B.get_box(e) for e in range(n)]
+    return (np.array([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs]),
+            np.array([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs], np.int32))
 
 
 def clips_for(name):
@@ -70,9 +83,8 @@ def run(name, kw, n_envs=8, n_steps=40, seed=11):
         qpos.append([list(s.qpos) for s in st]); qvel.append([list(s.qvel) for s in st])
         p, n = B.contacts()
         ncon.append(n); pairs.append(p)
-        bxs = [B.get_box(e) for e in range(n_envs)]
-        box.append([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs])
-        phase.append([[b.task_phase, b.weld_active, b.gripped, b.n_handed_over] for b in bxs])
+        fl, it = object_rows(B, env_id, n_envs)
+        box.append(fl); phase.append(it)
     out.update(phase=np.array(phase, np.int32))
     out.update(actions=np.array(acts), obs=np.array(obs), reward=np.array(rew), done=np.array(done), info=np.array(info),
                qpos=np.array(qpos), qvel=np.array(qvel), ncon=np.array(ncon), pairs=np.array(pairs).astype(np.int8), box=np.array(box))
