@@ -110,6 +110,7 @@ OTHER_TASKS = {  # --env values beyond the two benchmark configurations: (env kw
     "HumanRobotHandoverCart": (dict(horizon=1000, shield_type="PFL"), "hrg_step_kernel_ho"),
     "RobotHumanHandoverCart": (dict(horizon=1000, shield_type="PFL"), "hrg_step_kernel_ho"),
     "CollaborativeLiftingCart": (dict(horizon=5000), "hrg_step_kernel_lift"),
+    "CollaborativeStackingCart": (dict(horizon=3000), "hrg_step_kernel_stack"),
 }
 
 
@@ -306,11 +307,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank == 0:
-        state_bytes = load_library().hrg_state_bytes() + (load_library().hrg_box_bytes() if pick_place else 0)
+        lib = load_library()
+        obj_bytes = lib.hrg_stack_bytes() if args.env == "CollaborativeStackingCart" else (lib.hrg_box_bytes() if pick_place else 0)   # the task's object block, streamed next to the env block
+        state_bytes = lib.hrg_state_bytes() + obj_bytes
         per_env = algorithmic_bytes_per_env_step(C, state_bytes, desc.n_cycles)
-        if mixed_tasks:  # ReachHuman's share moves no object block; the kernels overlap, so the launch duration is the step's wall time
-            n_reach = G.slices[G.env_ids.index("ReachHuman")].stop - G.slices[G.env_ids.index("ReachHuman")].start if "ReachHuman" in G.env_ids else 0
-            per_env = (per_env * n - n_reach * 2 * load_library().hrg_box_bytes()) / n
+        if mixed_tasks:  # each task streams its own object block; the kernels overlap, so the launch duration is the step's wall time
+            tot = 0
+            for env_id, sl in zip(G.env_ids, G.slices):
+                ob = 0 if env_id == "ReachHuman" else (lib.hrg_stack_bytes() if env_id == "CollaborativeStackingCart" else lib.hrg_box_bytes())
+                tot += (sl.stop - sl.start) * algorithmic_bytes_per_env_step(C, lib.hrg_state_bytes() + ob, desc.n_cycles)
+            per_env = tot / n
             kernel_ms = 1e3 * elapsed / args.steps
         achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         kernel_name = "all step kernels, concurrent (wall time per step)" if mixed_tasks else (

@@ -85,7 +85,7 @@ def _path_samples(path, T):
     lib = load()
     out = (ctypes.c_double * 3)()
     res = []
-    for f in (0.0, 0.2, 0.4, 0.6, 0.8, 1.0):
+    for f in (0.0, 0.2, 0.4, 0.6, 0.8, 0.98):   # (beyond T the profile continues at the model's fail-safe speed, which the state block does not carry)
         lib.hrgo_test_path_eval(ctypes.byref(path), ctypes.c_double(f * T), ctypes.c_double(0.0), out)
         res.append(list(out))
     return np.array(res)
