@@ -126,6 +126,8 @@
 // ---- diagnostic build only (-DHRG_STAMPS): where do the cycles go?  s_memtime deltas per phase, summed over waves.
 #ifdef HRG_STAMPS
 static __device__ unsigned long long g_stamps[32];
+static __device__ unsigned long long g_stamps_slow[34];     // the same sums over the waves that lived longer than g_slow_thresh cycles ([32] = their number, [33] = their total lifetime)
+static __device__ unsigned long long g_slow_thresh = ~0ull;
 static __device__ unsigned long long g_envcyc[16384][3];   // per env: start, end timestamp of its last step
 __shared__ unsigned long long g_tbeg;
 __shared__ unsigned long long g_acc[32];   // per-wave accumulators (diagnostic build only: costs one workgroup of occupancy)
@@ -136,7 +138,7 @@ __shared__ unsigned long long g_t0;
 #define STAMP(k) do { unsigned long long _t; STAMP_NOW(_t); if (threadIdx.x == 0) { g_acc[k] += _t - g_t0; g_t0 = _t; } } while (0)
 #define STAMP_FLUSH(lane)
 #define COUNT(k, n) do { if (threadIdx.x == 0) g_acc[k] += (n); } while (0)
-#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); if ((lane) == 0 && blockIdx.x < 16384) { unsigned long long _t; STAMP_NOW(_t); g_envcyc[blockIdx.x][0] = g_tbeg; g_envcyc[blockIdx.x][1] = _t; unsigned _hw, _xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); g_envcyc[blockIdx.x][2] = ((unsigned long long)_xcc << 32) | _hw; } } while (0)
+#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); { unsigned long long _te; STAMP_NOW(_te); if (_te - g_tbeg > g_slow_thresh) { if ((lane) < 32) atomicAdd(&g_stamps_slow[lane], g_acc[lane]); if ((lane) == 32) atomicAdd(&g_stamps_slow[32], 1ull); if ((lane) == 33) atomicAdd(&g_stamps_slow[33], _te - g_tbeg); } } if ((lane) == 0 && blockIdx.x < 16384) { unsigned long long _t; STAMP_NOW(_t); g_envcyc[blockIdx.x][0] = g_tbeg; g_envcyc[blockIdx.x][1] = _t; unsigned _hw, _xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); g_envcyc[blockIdx.x][2] = ((unsigned long long)_xcc << 32) | _hw; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_INIT(lane)
@@ -266,7 +268,22 @@ struct Lds {
 
 // The per-env LDS image is a file-scope __shared__ object: every device function addresses it directly (ds_* instructions),
 // nothing is passed around as a generic pointer.
+// HRG_WG_WAVES envs (one wave each) may share a workgroup: with W = 4 the dispatcher has to place the four waves of a workgroup at once, one per
+// SIMD, so every SIMD of a full CU runs exactly LDS-capacity / W envs from the first cycle of a launch.  Single-wave workgroups are bound to a SIMD
+// one by one, 3 to 5 per SIMD at a 4096-env launch (profiles/r02a_env_times.log): the fifth waits a whole env-step for a slot.  The waves of a
+// workgroup share nothing; each addresses its own image, and wave_sync() is a wave-level fence, never an s_barrier.
+#ifndef HRG_WG_WAVES
+#define HRG_WG_WAVES 1
+#endif
+#if HRG_WG_WAVES > 1
+__shared__ Lds g_Lw[HRG_WG_WAVES];
+#define g_L (g_Lw[__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))])
+#else
 __shared__ Lds g_L;
+#endif
+DI int hrg_lane() { return (int)(threadIdx.x & 63u); }
+DI int hrg_env() { return (int)blockIdx.x * HRG_WG_WAVES + (int)(threadIdx.x >> 6); }
+#define HRG_LAUNCH_DIMS(n) dim3(((n) + HRG_WG_WAVES - 1) / HRG_WG_WAVES), dim3(64 * HRG_WG_WAVES)
 
 // Model constants are read through the CONSTANT address space from a wave-uniform base held in SGPRs, so that every
 // uniform-index access becomes a scalar load (s_load_*, scalar cache, SGPR destination) instead of a per-lane flat load.
@@ -398,7 +415,14 @@ DI double row16_max(double v) {
   t = dpp_f64<0x140, 0xf>(v); v = t > v ? t : v;   // row_mirror
   return v;
 }
-DI void wave_sync() { __syncthreads(); }  // workgroup == one wave: orders LDS traffic between lane roles
+// orders LDS traffic between the lane roles of ONE wave.  A wave's LDS instructions execute in issue order, so no hardware wait is needed between a
+// write by one lane and a read by another; what has to be stopped is the compiler moving one across the other.  (With one wave per workgroup
+// __syncthreads() lowers to the same thing plus a drain of every outstanding memory operation.)
+#if HRG_WG_WAVES > 1
+DI void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+#else
+DI void wave_sync() { __syncthreads(); }
+#endif
 
 // ------------------------------------------------------------------------------------------------ RNG
 DI uint64_t mix64(uint64_t x) {
@@ -770,6 +794,37 @@ DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* 
   *ok = good;
   *la = a; *lb = b;
 }
+// Inverses of two symmetric positive definite 8x8 matrices (M and M + h D of a substep) in one pass: in-place Gauss-Jordan sweeps, lane (i,j) owns entry
+// (i,j) of each matrix, three shuffles and one reciprocal per pivot and matrix -- the cost of the factorisation above, but what comes out turns every later
+// solve with these matrices (unconstrained acceleration, the Newton direction while no row has curvature, the implicit-damping step) into one product per
+// lane and a three-step row reduction, instead of a 16-step dependent substitution chain on 8 lanes.  Pivots are the same Schur complements as the
+// Cholesky pivots: positive definiteness is checked on them.
+DI void spd_inverse2(double a, double b, int lane, bool* ok, double* ia, double* ib) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const double akk = __shfl(a, k * 9, 64), bkk = __shfl(b, k * 9, 64);
+    if (!(akk > 0) || !(bkk > 0)) good = false;
+    const double pa = 1.0 / akk, pb = 1.0 / bkk;
+    const double aik = __shfl(a, i * 8 + k, 64), bik = __shfl(b, i * 8 + k, 64);
+    const double akj = __shfl(a, k * 8 + j, 64), bkj = __shfl(b, k * 8 + j, 64);
+    if (i == k) { a = j == k ? pa : akj * pa; b = j == k ? pb : bkj * pb; }
+    else if (j == k) { a = -aik * pa; b = -bik * pb; }
+    else { a -= aik * akj * pa; b -= bik * bkj * pb; }
+  }
+  *ok = good;
+  *ia = a; *ib = b;
+}
+// sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it
+DI double row8_sum(double v) {
+  v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
+  v += dpp_f64<0x4E, 0xf>(v);    // quad_perm [2,3,0,1]
+  v += dpp_f64<0x141, 0xf>(v);   // row_half_mirror: lane k <-> 7 - k within each half row
+  return v;
+}
+// y = A x for lanes = (i, j): A_ij in a register, x in LDS; returns y_i in every lane of row i
+DI double matvec_lanes(double aij, const double* x, int lane) { return row8_sum(aij * x[lane & 7]); }
 // publish the factor for the wave-uniform solves: lower triangle + reciprocal diagonal
 DI void chol_store(double l, int lane, double* Lm, double* invd) {
   Lm[lane] = l;

@@ -148,6 +148,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
     if (lane < NV) L.a0[lane] = x;
   }
+  STAMP(20);
   // ---- per-contact bookkeeping: which cubes / whether the robot take part ----
   if (lane < NCON_DYN) {
     int ca = -1, cb = -1, rob = 0;
@@ -260,6 +261,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       if (w.type == 0) w.flim = w.floss / w.D;
     }
   }
+  STAMP(21);
+  COUNT(19, __popcll(__ballot(R[0].active)) + __popcll(__ballot(R[1].active)));
   const bool any_row = __any(R[0].active || R[1].active);
   // a robot-cube contact couples the robot block of the Newton system to the cube block
   bool cpl = false;
@@ -318,8 +321,10 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       if (!(cost_ws < cost_a0)) { if (lane < NVS) L.qacc[lane] = L.a0[lane]; }
       wave_sync();
     }
+    STAMP(22);
 #pragma unroll 1
     for (int it = 0; it < m.solver_iters; it++) {
+      COUNT(16, 1);
       double gg[2], hh[2];
 #pragma unroll
       for (int k = 0; k < 2; k++) {
@@ -359,6 +364,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         const double gn = wave_sum(gl * gl), sc = wave_sum(ml * ml);
         if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
       }
+      STAMP(27);
       // ---- Newton Hessian: M + sum_r h_r J_r' J_r ----
       if (!coupled) {   // robot block in registers (lanes = (mi, mj)), as in the ReachHuman solver
         double hval = Mij;
@@ -409,7 +415,10 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         }
         wave_sync();
       }
+      STAMP(23);
+      COUNT(18, 1);
       if (!chol_stack(lane, coupled ? 0 : NV)) break;
+      STAMP(24);
       {
         double x;
         if (coupled) x = chol_stack_solve(lane < NVS ? -L.g[lane] : 0.0, lane, 0);
@@ -425,11 +434,13 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       for (int k = 0; k < 2; k++) R[k].p = rowdot(R[k], L.d);
       double dd = 0, Mdi = 0;
       if (lane < NVS) { dd = L.d[lane]; Mdi = Mrow(L.d); }
+      STAMP(25);
       const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
       double al = 1.0, lo = 0, hi = -1;
       const double d1_0 = gd0 + wave_sum(gg[0] * R[0].p + gg[1] * R[1].p);
 #pragma unroll 1
       for (int ls = 0; ls < 40; ls++) {
+        COUNT(17, 1);
         double sg_ = 0, sh_ = 0;
 #pragma unroll
         for (int k = 0; k < 2; k++)
@@ -447,6 +458,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
         al = nx;
       }
+      STAMP(26);
       if (lane < NVS) L.qacc[lane] += al * dd;
       wave_sync();
       bool moved = false;
@@ -514,13 +526,9 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   // ---- factor M across the wave; unconstrained acceleration a0 = M^-1 (actuation + passive - bias) ----
   bool ok;
   const double Mij = L.M[lane];
-  double l_damp;  // factor of M + h D (mj_Euler's implicit damping), used at the end of the substep
-  {
-    double lm;
-    chol_lanes2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &lm, &l_damp);
-    if (!ok) return 1;
-    chol_store(lm, lane, L.H, L.Hinv);
-  }
+  double Minv, MDinv;  // entries (mi, mj) of M^-1 and (M + h D)^-1 (mj_Euler's implicit damping, used at the end of the substep)
+  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  if (!ok) return 1;
   if (lane < NV) {
     double act = L.ctrl[lane];
     if (lane >= NARM) act = clampd(m.finger_kp * (act - s.qpos[lane]), m.finger_forcerange[0], m.finger_forcerange[1]);
@@ -560,8 +568,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
 #endif
   wave_sync();
   {
-    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
-    if (lane < NV) L.a0[lane] = x;
+    const double x = matvec_lanes(Minv, L.Ma0, lane);   // a0 = M^-1 (M a0): lanes (i, 0) publish row i
+    if (mj == 0) L.a0[mi] = x;
   }
   STAMP(20);
   // ---- this lane's constraint row (fixed slot) ----
@@ -801,7 +809,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
             if (hq != 0) sval += hq * L.Jc[q][NV + mi] * L.Jc[q][NV + mj];
           }
         STAMP(23);
-        if (__any(hh != 0 && rpart) || !h_is_m) {  // no robot row with curvature: the robot block is M and its factor is still in LDS
+        if (__any(hh != 0 && rpart) || !h_is_m) {  // no robot row with curvature: the robot block is M, whose inverse is held in registers
           const double hl = chol_lanes(hval, lane, &ok);
           if (!ok) break;
           chol_store(hl, lane, L.H, L.Hinv);
@@ -816,9 +824,9 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
           wave_sync();
         }
         STAMP(24);
-        const double x1 = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
+        const double x1 = h_is_m ? -matvec_lanes(Minv, L.g, lane) : chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
         const double x2 = chol_solve_lanes(Hs, Hs + 64, lane < HRG_NBOXV ? -L.g[NV + lane] : 0.0, lane);
-        if (lane < NV) L.d[lane] = x1;
+        if (h_is_m) { if (mj == 0) L.d[mi] = x1; } else if (lane < NV) L.d[lane] = x1;
         if (lane < HRG_NBOXV) L.d[NV + lane] = x2;
       } else {
       // Hessian of the coupled 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
@@ -869,14 +877,17 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
       if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
       COUNT(18, (__any(hh != 0) || !h_is_m) ? 1 : 0);  // Hessian factorizations
-      if (__any(hh != 0) || !h_is_m) {  // no row with curvature: H == M and its factor is still in LDS
+      if (__any(hh != 0) || !h_is_m) {  // no row with curvature: H == M, whose inverse is held in registers
         const double hl = chol_lanes(hval, lane, &ok);
         if (!ok) break;
         chol_store(hl, lane, L.H, L.Hinv);
         h_is_m = false;
         wave_sync();
       }
-      {
+      if (h_is_m) {   // no row with curvature so far: H == M, the direction is -M^-1 g
+        const double x = -matvec_lanes(Minv, L.g, lane);
+        if (mj == 0) L.d[mi] = x;
+      } else {
         const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
         if (lane < NV) L.d[lane] = x;
       }
@@ -920,21 +931,17 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
-  chol_store(l_damp, lane, L.H, L.Hinv);
-  if (lane < NV) {
-    s.qacc_warmstart[lane] = L.qacc[lane];
-    double t = 0;
-#pragma unroll
-    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
-    L.d[lane] = t;
-  }
-  wave_sync();
   {
-    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.d[lane] : 0.0, lane);
-    if (lane < NV) {
-      const double v = s.qvel[lane] + h * x;
-      s.qvel[lane] = v;
-      s.qpos[lane] = s.qpos[lane] + h * v;
+    const double t = matvec_lanes(Mij, L.qacc, lane);
+    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
+    wave_sync();
+    if (mj == 0) L.d[mi] = t;
+    wave_sync();
+    const double x = matvec_lanes(MDinv, L.d, lane);
+    if (mj == 0) {
+      const double v = s.qvel[mi] + h * x;
+      s.qvel[mi] = v;
+      s.qpos[mi] = s.qpos[mi] + h * v;
     }
   }
 #if HRG_BOX
@@ -2033,13 +2040,14 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
 #else
 #define HRG_KERNEL_WAVES HRG_MIN_WAVES
 #endif
-__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
+__global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs,
-                                                     ObjState* __restrict__ boxes) {
+                                                     ObjState* __restrict__ boxes, int n_envs) {
+  const int e = hrg_env(), lane = hrg_lane();
+  if (e >= n_envs) return;   // a partly filled last workgroup (HRG_WG_WAVES > 1); the waves of a workgroup never wait for each other
   Lds& L = g_L;
   (void)boxes;  // the cube's state array: only the HRG_BOX variant streams it
-  const int e = blockIdx.x, lane = threadIdx.x;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
@@ -2059,11 +2067,12 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_step_kernel(const De
 #endif
 }
 
-__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
-                                                      float* __restrict__ obs, int64_t env_id0, ObjState* __restrict__ boxes) {
+__global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_reset_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, const uint8_t* __restrict__ mask,
+                                                      float* __restrict__ obs, int64_t env_id0, ObjState* __restrict__ boxes, int n_envs) {
+  const int e = hrg_env(), lane = hrg_lane();
+  if (e >= n_envs) return;
   Lds& L = g_L;
   (void)boxes;
-  const int e = blockIdx.x, lane = threadIdx.x;
   if (mask && !mask[e]) return;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
@@ -2082,10 +2091,11 @@ __global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_reset_kernel(const D
 #if !HRG_BOX && !HRG_STACK
 // HumanEnv.check_collision_action for every env: goal configuration of the action at the env's current joint angles -> pre-check capsule model.
 // The check reads the robot part of the state only, so one kernel serves every task.
-__global__ __launch_bounds__(64, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
-                                                                          uint8_t* __restrict__ collides) {
+__global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
+                                                                          uint8_t* __restrict__ collides, int n_envs) {
+  const int e = hrg_env(), lane = hrg_lane();
+  if (e >= n_envs) return;
   Lds& L = g_L;
-  const int e = blockIdx.x, lane = threadIdx.x;
   const double* src = (const double*)(states + e);
   double* dst = (double*)&L.st;
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
@@ -2130,19 +2140,19 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int 
 #if HRG_STACK
 extern "C" void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
                                       int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_stack_state* stacks) {
-  hipLaunchKernelGGL(hrg_step_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, stacks);
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, stacks, n_envs);
 }
 extern "C" void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_stack_state* stacks) {
-  hipLaunchKernelGGL(hrg_reset_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, mask, obs, env_id0, stacks);
+  hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, stacks, n_envs);
 }
 #endif
 #if HRG_BOX
 extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
                                     int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes) {
-  hipLaunchKernelGGL(hrg_step_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, boxes);
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, boxes, n_envs);
 }
 extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_box_state* boxes) {
-  hipLaunchKernelGGL(hrg_reset_kernel, dim3(n_envs), dim3(64), 0, st, dm, states, mask, obs, env_id0, boxes);
+  hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, boxes, n_envs);
 }
 #endif
 
@@ -2155,6 +2165,17 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #define hrg_debug_stamps hrg_debug_stamps_lift
 #elif HRG_BOX
 #define hrg_debug_stamps hrg_debug_stamps_box
+#endif
+#if !HRG_BOX && !HRG_STACK
+// waves that live longer than `thresh` shader cycles are also summed into a second set of accumulators: out[0..31] phase sums, out[32] their number, out[33] lifetime sum
+extern "C" int hrg_debug_stamps_slow(double* out, unsigned long long thresh, int reset) {
+  unsigned long long h[34];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_stamps_slow), sizeof h) != hipSuccess) return -1;
+  for (int i = 0; i < 34; i++) out[i] = (double)h[i];
+  if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps_slow), h, sizeof h); }
+  hipMemcpyToSymbol(HIP_SYMBOL(g_slow_thresh), &thresh, sizeof thresh);
+  return 0;
+}
 #endif
 extern "C" int hrg_debug_stamps(double* out, int reset) {
   unsigned long long h[32];
@@ -2388,7 +2409,7 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
   else if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
-  else hipLaunchKernelGGL(hrg_reset_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  else hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes, b->n_envs);
   HIPCHK(hipGetLastError());
   return HRG_OK;
 }
@@ -2396,7 +2417,7 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
 int hrg_batch_check_actions(hrg_batch* b, const double* actions_dev, uint8_t* collides_dev, void* stream) {
   if (!b || !actions_dev || !collides_dev) return fail(HRG_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
-  hipLaunchKernelGGL(hrg_check_kernel, dim3(b->n_envs), dim3(64), 0, (hipStream_t)stream, b->d_model, b->d_states, actions_dev, collides_dev);
+  hipLaunchKernelGGL(hrg_check_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, (hipStream_t)stream, b->d_model, b->d_states, actions_dev, collides_dev, b->n_envs);
   HIPCHK(hipGetLastError());
   return HRG_OK;
 }
@@ -2424,8 +2445,8 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
   else
-    hipLaunchKernelGGL(hrg_step_kernel, dim3(b->n_envs), dim3(64), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+    hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, b->n_envs);
   HIPCHK(hipGetLastError());
   if (b->timing) { HIPCHK(hipEventRecord(ev.second, st)); b->events.push_back(ev); }
   return HRG_OK;

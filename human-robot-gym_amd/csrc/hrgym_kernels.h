@@ -334,7 +334,7 @@ DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int
 // (wave-uniform call; the 2n draws run on lanes 0..2n-1 and are handed round by shuffles, the sum runs in the reference's order)
 DI double layered_sines(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int kfirst, int n, double t, double start) {
   static_assert(2 * HRG_MAX_LOOP <= 64, "one lane per loop property");
-  const int lane = (int)threadIdx.x, kk = lane % HRG_MAX_LOOP, sp = (lane / HRG_MAX_LOOP) & 1;
+  const int lane = hrg_lane(), kk = lane % HRG_MAX_LOOP, sp = (lane / HRG_MAX_LOOP) & 1;
   const double mine = loop_prop(dm, gid, episode, ai, clip, kfirst + (kk < n ? kk : 0), sp);
   double sum = 0;
   for (int k = 0; k < n; k++) {

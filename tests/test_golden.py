@@ -74,11 +74,13 @@ def test_hip_reproduces_golden(name):
         o, r, d, i = B.step(torch.from_numpy(g["actions"][k]).cuda())
         torch.cuda.synchronize()
         live &= (np.abs(g["qvel"][k]).max(1) <= 5.0) & (g["info"][k][:, 11] == 0)
-        if env_id == "CollaborativeStackingCart":   # a cube the human let go of over the floor arrives at > 4 m/s: the bounce is chaotic, like a violent arm
+        if env_id == "CollaborativeStackingCart":
+            # chaotic, like a violent arm: a cube that touches something while it moves at > 6 m/s (a synthetic human swinging its welded cubes through the
+            # table top; the fixture's human moves at a quarter of that speed).  A cube dropped from the hand lands at 3 - 5 m/s and stays in.
             spd = np.abs(g["box"][k][:, :52].reshape(n, 4, 13)[:, :, 7:10]).max(2)
-            free = np.ones((n, 4), bool)
-            free[:, 2], free[:, 3] = g["phase"][k][:, 1] == 0, g["phase"][k][:, 2] == 0     # the cubes still welded to a hand follow it, however fast
-            live &= (spd * free).max(1) <= 3.0
+            pr = g["pairs"][k].astype(np.int32)
+            touching = np.stack([((pr[:, :, 0] == 36 + c) | (pr[:, :, 1] == 36 + c)).any(1) for c in range(4)], 1)
+            live &= (spd * touching).max(1) <= 6.0
         np.testing.assert_array_equal(i.cpu().numpy()[live], g["info"][k][live], err_msg=f"step {k}")
         np.testing.assert_array_equal(d.cpu().numpy()[live], g["done"][k][live])
         np.testing.assert_allclose(o.cpu().numpy()[live], g["obs"][k][live], rtol=1e-5, atol=1e-6)   # north_star: obs within 1e-5 rel

@@ -52,6 +52,8 @@ def clips_for(name):
     env_id = CASES[name].get("env_id", "ReachHuman")
     if env_id not in ("ReachHuman", "PickPlaceHumanCart"):
         from human_robot_gym_amd.mixed import task_clips
+        if env_id == "CollaborativeStackingCart":   # a human moving at a quarter of the synthetic clips' speed: its welded cubes are carried, not flung
+            return task_clips(env_id, 3, min_frames=480, max_frames=640, fps=480.0)
         return task_clips(env_id, 3, min_frames=120, max_frames=160)
     return hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
 
