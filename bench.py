@@ -12,8 +12,10 @@ One "step" = one `hrg_batch_step` launch over the rank's 4096 envs (+ one RCCL a
 outputs when N > 1).  Envs shard embarrassingly: rank r owns global env ids [r*4096, (r+1)*4096).
 
 STEADY STATE.  Before the W warm-up steps the batch is rolled, untimed, for `preroll` steps (one horizon, at most 1000:
-`config.preroll_steps`), so that episode phases are spread over the batch whatever --warmup says; a batch timed right
-after reset is ~25 % faster than the one a training run sees (fewer envs braking or in contact).
+`config.preroll_steps`), and the TimeLimit phase of the envs is staggered over the horizon once after the reset
+(`config.episode_phases_staggered`: ~n / horizon envs end their episode in every step instead of all of them every
+`horizon` steps), whatever --warmup says; a batch timed right after reset is ~25 % faster than the one a training run
+sees (fewer envs braking or in contact, no auto-resets).
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
   roofline     — HBM roofline of the step kernel: ALGORITHMIC bytes per launch / average kernel time measured
@@ -189,6 +191,7 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (the 16-thread leg gets 0.6 x)")
     ap.add_argument("--pmc-json", default=DEFAULT_PMC, help="committed PMC capture of this command (tools/profile_capture.sh): source of roofline.traffic / valu_* / fp64_*")
     ap.add_argument("--variant-lib", default=None, help="tuning experiments only: time another build of the library; echoed as `variant_lib` in the JSON line")
+    ap.add_argument("--no-stagger", action="store_true", help="leave every env at episode step 0 after the reset (all of them then time out in the same steps)")
     ap.add_argument("--force-gather", action="store_true", help="rehearse the N > 1 all-gather on one GPU (world size 1)")
     ap.add_argument("--gather-mode", default="serial", choices=["serial", "overlap"])
     args = ap.parse_args()
@@ -256,6 +259,10 @@ def main():
         G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
     dev = G.device
     G.reset()
+    staggered = False
+    if not mixed_tasks and not args.no_stagger:   # spread the TimeLimit phase: ~n / horizon envs time out in every step instead of all of them every `horizon` steps
+        G.stagger_episode_phases(int(desc.horizon))
+        staggered = True
     gen = torch.Generator(device=dev)
     gen.manual_seed(1234 + rank)
     pool = [torch.rand((n, C["HRG_ACT_DIM"]), generator=gen, device=dev, dtype=torch.float64) * 2 - 1 for _ in range(32)]
@@ -359,7 +366,7 @@ def main():
                                    + ("Cartesian random actions via IK + collision prevention" if args.ik else "random actions U(-1,1)^7")
                                    + f", 13 synthetic clips, auto-reset, steady state ({preroll}-step pre-roll)",
                        "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
-                       "preroll_steps": preroll,
+                       "preroll_steps": preroll, "episode_phases_staggered": staggered,
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if args.gather_mode == "serial" else " on a side stream") if publish is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,
             "roofline": roof,

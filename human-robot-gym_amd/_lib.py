@@ -220,6 +220,17 @@ class HipBatch:
         _check(self.lib, self.lib.hrg_batch_set_states(self.h, idx.ctypes.data_as(ctypes.c_void_p), len(idx), ctypes.byref(states),
                                                        ctypes.byref(boxes) if boxes is not None else None))
 
+    def stagger_episode_phases(self, horizon):
+        """Spread the TimeLimit phase over the batch: env e continues as if it were (e * horizon) // n policy steps into its episode.  A freshly reset batch
+        has every env at step 0, so that all of them time out in the same step, every `horizon` steps; a batch that has been training for a while has its
+        episode ends spread evenly (early successes and failures shift each env's phase).  Benchmarks call this once after reset."""
+        import numpy as np
+        idx = np.arange(self.n, dtype=np.int32)
+        st, bx = self.get_states(idx)
+        for e in range(self.n):
+            st[e].timestep = (e * int(horizon)) // self.n
+        self.set_states(idx, st, bx)
+
     def get_box(self, e):
         """The manipulation object of env e (PickPlaceHumanCart; zeros for ReachHuman)."""
         s = BoxState()

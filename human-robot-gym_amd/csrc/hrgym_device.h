@@ -816,6 +816,24 @@ DI void spd_inverse2(double a, double b, int lane, bool* ok, double* ia, double*
   *ok = good;
   *ia = a; *ib = b;
 }
+// the same sweep for one matrix (the Newton Hessian once a row has curvature)
+DI double spd_inverse1(double a, int lane, bool* ok) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    const double akk = __shfl(a, k * 9, 64);
+    if (!(akk > 0)) good = false;
+    const double pa = 1.0 / akk;
+    const double aik = __shfl(a, i * 8 + k, 64);
+    const double akj = __shfl(a, k * 8 + j, 64);
+    if (i == k) a = j == k ? pa : akj * pa;
+    else if (j == k) a = -aik * pa;
+    else a -= aik * akj * pa;
+  }
+  *ok = good;
+  return a;
+}
 // sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it
 DI double row8_sum(double v) {
   v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]

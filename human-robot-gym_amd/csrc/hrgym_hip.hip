@@ -809,25 +809,19 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
             if (hq != 0) sval += hq * L.Jc[q][NV + mi] * L.Jc[q][NV + mj];
           }
         STAMP(23);
-        if (__any(hh != 0 && rpart) || !h_is_m) {  // no robot row with curvature: the robot block is M, whose inverse is held in registers
-          const double hl = chol_lanes(hval, lane, &ok);
+        if (__any(hh != 0 && rpart) || !h_is_m) {  // a robot row has curvature: invert the robot block of the Hessian (until then it is M, whose inverse is already held)
+          Minv = spd_inverse1(hval, lane, &ok);
           if (!ok) break;
-          chol_store(hl, lane, L.H, L.Hinv);
           h_is_m = false;
-          wave_sync();
         }
-        double* Hs = L.hbp;         // factor of the cube block: 64 + 8 doubles of the (idle) Hessian buffer
-        {
-          const double sl = chol_lanes(sval, lane, &ok);
-          if (!ok) break;
-          chol_store(sl, lane, Hs, Hs + 64);
-          wave_sync();
-        }
+        // cube block: 6x6 padded to the 8x8 lane layout with a unit diagonal
+        const double Sinv = spd_inverse1(sval, lane, &ok);
+        if (!ok) break;
         STAMP(24);
-        const double x1 = h_is_m ? -matvec_lanes(Minv, L.g, lane) : chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
-        const double x2 = chol_solve_lanes(Hs, Hs + 64, lane < HRG_NBOXV ? -L.g[NV + lane] : 0.0, lane);
-        if (h_is_m) { if (mj == 0) L.d[mi] = x1; } else if (lane < NV) L.d[lane] = x1;
-        if (lane < HRG_NBOXV) L.d[NV + lane] = x2;
+        wave_sync();
+        const double x1 = -matvec_lanes(Minv, L.g, lane);
+        const double x2 = -row8_sum(Sinv * (mj < HRG_NBOXV ? L.g[NV + mj] : 0.0));
+        if (mj == 0) { L.d[mi] = x1; if (mi < HRG_NBOXV) L.d[NV + mi] = x2; }
       } else {
       // Hessian of the coupled 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
 #pragma unroll 1
@@ -877,19 +871,14 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
       if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
       COUNT(18, (__any(hh != 0) || !h_is_m) ? 1 : 0);  // Hessian factorizations
-      if (__any(hh != 0) || !h_is_m) {  // no row with curvature: H == M, whose inverse is held in registers
-        const double hl = chol_lanes(hval, lane, &ok);
+      if (__any(hh != 0) || !h_is_m) {  // a row has curvature: invert the Hessian (until then H == M, whose inverse is already held)
+        Minv = spd_inverse1(hval, lane, &ok);
         if (!ok) break;
-        chol_store(hl, lane, L.H, L.Hinv);
         h_is_m = false;
-        wave_sync();
       }
-      if (h_is_m) {   // no row with curvature so far: H == M, the direction is -M^-1 g
+      {
         const double x = -matvec_lanes(Minv, L.g, lane);
         if (mj == 0) L.d[mi] = x;
-      } else {
-        const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
-        if (lane < NV) L.d[lane] = x;
       }
       wave_sync();
       const double p = rowdot(L.d);

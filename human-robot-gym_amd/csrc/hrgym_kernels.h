@@ -189,6 +189,11 @@ DI void robot_point_vel(int b, const double* r, double* v) {
 // ================================================================================================ human
 // HumanEnv._control_human (human_env.py:1710-1767) + kinematics of the 24-body tree on lanes = bodies.
 DI int clip_of(ModelPtr dm, int64_t gid, int episode, int anim_index) {
+  // every argument is wave-uniform but arrives in VGPRs (loaded from the LDS image): moved to SGPRs, so that the four 64-bit mixing rounds of the hash run
+  // once on the scalar unit instead of on 64 lanes (this runs every substep)
+  episode = __builtin_amdgcn_readfirstlane(episode);
+  anim_index = __builtin_amdgcn_readfirstlane(anim_index);
+  gid = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)gid >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)gid));
   double u = rng_u01(dm->m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_ANIM, (uint64_t)anim_index);
   int c = (int)(u * dm->m.n_clips);
   return c >= dm->m.n_clips ? dm->m.n_clips - 1 : c;
@@ -548,9 +553,19 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
       double hv[3];
       for (int a = 0; a < 3; a++) hv[a] = 0.5 * (L.rc[c][3 + a] - L.rc[c][a]);
       rc_hl = sqrt(v3dot(hv, hv));
+      L.scap[0][c][0] = rc_hl;   // (this lane's own chain-kinematics entry, dead from here on: the verification loop reads the half length from LDS)
       if (dbg_r) for (int a = 0; a < 7; a++) dbg_r[((size_t)e * HRG_NSHIELD_RCAP + c) * 7 + a] = L.rc[c][a];
     }
     wave_sync();
+    double rbl[3], rbh[3];   // box around the robot reach capsules (each inflated by its radius), the same in every lane
+    {
+      double bl[3], bh[3];
+      if (lane < HRG_NSHIELD_RCAP) {
+        const double rr = L.rc[lane][6];
+        for (int a = 0; a < 3; a++) { const double p1 = L.rc[lane][a], p2 = L.rc[lane][3 + a]; bl[a] = (p1 < p2 ? p1 : p2) - rr; bh[a] = (p1 > p2 ? p1 : p2) + rr; }
+      } else for (int a = 0; a < 3; a++) { bl[a] = 1e300; bh[a] = -1e300; }
+      for (int a = 0; a < 3; a++) { rbh[a] = __shfl(row16_max(bh[a]), 0, 64); rbl[a] = -__shfl(row16_max(-bl[a]), 0, 64); }
+    }
     // lanes = human reach capsules
     const int nh = dm->hc_n;
     bool hit = false;
@@ -586,13 +601,18 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
       double hc[3], hh[3];
       for (int a = 0; a < 3; a++) { hc[a] = 0.5 * (c1[a] + c2[a]); hh[a] = 0.5 * (c2[a] - c1[a]); }
       const double hl = sqrt(v3dot(hh, hh));
+      // whole-robot cull: the box around the seven robot reach capsules against this capsule's bounding sphere (conservative: a culled lane cannot intersect
+      // any of them); the seven pair tests below run only for the lanes that come near
+      double d2b = 0;
+      for (int a = 0; a < 3; a++) { const double ee = hc[a] < rbl[a] ? rbl[a] - hc[a] : (hc[a] > rbh[a] ? hc[a] - rbh[a] : 0.0); d2b += ee * ee; }
+      const bool near_robot = d2b <= (hl + r + 1e-9) * (hl + r + 1e-9);
 #pragma unroll 1
-      for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+      for (int c = 0; c < (near_robot ? HRG_NSHIELD_RCAP : 0); c++) {
         double x1[3], x2[3], rcn[3], dc[3];
         const double rr = L.rc[c][6] + r;
         for (int a = 0; a < 3; a++) rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]);
         v3sub(dc, rcn, hc);
-        const double reach = __shfl(rc_hl, c, 64) + hl + rr + 1e-9;
+        const double reach = L.scap[0][c][0] + hl + rr + 1e-9;   // (from LDS: the loop runs under divergence, lanes 0..6 may be culled)
         if (v3dot(dc, dc) > reach * reach) continue;  // bounding spheres apart: cannot intersect
         if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true;
       }

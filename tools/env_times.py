@@ -11,6 +11,7 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 clips = hrg.synthetic_clips(13, seed=0)
 kw = dict(shield_type="SSM", control_freq=10, horizon=100, done_at_success=True, reward_shaping=True, seed=1234)
 G = HipBatch(hrg.build_model_desc(kw, n_clips=13), clips, n); G.reset()
+if os.environ.get("HRG_STAGGER", "1") != "0": G.stagger_episode_phases(100 if "ReachHuman" in str(getattr(G, "n", "")) or True else 100)
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
 acts = [torch.rand((n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(16)]
 for k in range(150): G.step(acts[k % 16])
