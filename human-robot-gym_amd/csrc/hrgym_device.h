@@ -834,6 +834,26 @@ DI double spd_inverse1(double a, int lane, bool* ok) {
   *ok = good;
   return a;
 }
+// ... and for four matrices at once (the four cube blocks of the stacking task's Newton system): the four dependency chains interleave
+DI void spd_inverse4(double* a, int lane, bool* ok) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+#pragma unroll
+  for (int k = 0; k < NV; k++) {
+    double akk[4], aik[4], akj[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { akk[q] = __shfl(a[q], k * 9, 64); aik[q] = __shfl(a[q], i * 8 + k, 64); akj[q] = __shfl(a[q], k * 8 + j, 64); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      if (!(akk[q] > 0)) good = false;
+      const double pa = 1.0 / akk[q];
+      if (i == k) a[q] = j == k ? pa : akj[q] * pa;
+      else if (j == k) a[q] = -aik[q] * pa;
+      else a[q] -= aik[q] * akj[q] * pa;
+    }
+  }
+  *ok = good;
+}
 // sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it
 DI double row8_sum(double v) {
   v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]

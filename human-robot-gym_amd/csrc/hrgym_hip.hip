@@ -124,13 +124,9 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const int nc = ncon < NCON_DYN ? ncon : NCON_DYN;
   bool ok;
   const double Mij = L.M[lane];
-  double l_damp;
-  {
-    double lm;
-    chol_lanes2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &lm, &l_damp);
-    if (!ok) return 1;
-    chol_store(lm, lane, L.H, L.Hinv);
-  }
+  double Minv, MDinv;   // entries (mi, mj) of M^-1 and (M + h D)^-1 of the robot tree
+  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  if (!ok) return 1;
   if (lane < NV) {
     double act = L.ctrl[lane];
     if (lane >= NARM) act = clampd(m.finger_kp * (act - s.qpos[lane]), m.finger_forcerange[0], m.finger_forcerange[1]);
@@ -145,8 +141,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   }
   wave_sync();
   {
-    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.Ma0[lane] : 0.0, lane);
-    if (lane < NV) L.a0[lane] = x;
+    const double x = matvec_lanes(Minv, L.Ma0, lane);
+    if (mj == 0) L.a0[mi] = x;
   }
   STAMP(20);
   // ---- per-contact bookkeeping: which cubes / whether the robot take part ----
@@ -265,9 +261,12 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   COUNT(19, __popcll(__ballot(R[0].active)) + __popcll(__ballot(R[1].active)));
   const bool any_row = __any(R[0].active || R[1].active);
   // a robot-cube contact couples the robot block of the Newton system to the cube block
-  bool cpl = false;
-  if (lane < nc) cpl = L.con_rob[lane] && (L.con_ca[lane] >= 0 || L.con_cb[lane] >= 0);
+  bool cpl = false, ccpl = false;
+  if (lane < nc) { cpl = L.con_rob[lane] && (L.con_ca[lane] >= 0 || L.con_cb[lane] >= 0); ccpl = L.con_ca[lane] >= 0 && L.con_cb[lane] >= 0; }
   const bool coupled = __any(cpl);
+  // ... and a cube-cube contact couples two cubes; without either, the Newton system is block diagonal: the robot block and four 6x6 cube blocks, each inverted
+  // in registers across the wave (the common case: cubes resting on the table, carried by the human's hands, falling)
+  const bool blocks = !coupled && !__any(ccpl);
   wave_sync();
   auto rowdot = [&](const SRow& w, const double* x) -> double {
     if (!w.active) return 0.0;
@@ -343,17 +342,19 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
           t += L.rg[lane];
           t += L.rg[NV + 2 * lane];
           t -= L.rg[NV + 2 * lane + 1];
-#pragma unroll 1
-          for (int c = 0; c < nc; c++)
-            if (L.con_rob[c])
-              for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][lane] * L.rg[SROW_CON0 + 4 * c + d];
+          // (the robot part of a contact row without a robot body is stored as zeros: no test per contact, the loads of successive rows overlap)
+#pragma unroll 4
+          for (int q = 0; q < 4 * nc; q++) t += L.Jc[q][lane] * L.rg[SROW_CON0 + q];
         } else {
           const int a = lane - NV, cu = a / 6, k = a - 6 * cu;
           if (cu >= HRG_CUBE_L) t += L.rg[SROW_WELD0 + 6 * (cu - HRG_CUBE_L) + k];
-#pragma unroll 1
-          for (int c = 0; c < nc; c++) {
-            if (L.con_ca[c] == cu) for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][8 + k] * L.rg[SROW_CON0 + 4 * c + d];
-            if (L.con_cb[c] == cu) for (int d = 0; d < 4; d++) t += L.Jc[4 * c + d][14 + k] * L.rg[SROW_CON0 + 4 * c + d];
+#pragma unroll 2
+          for (int c = 0; c < nc; c++) {   // branch-free: both cube parts of the four rows are loaded, the one that is this lane's cube is kept
+            const double wa = L.con_ca[c] == cu ? 1.0 : 0.0, wb = L.con_cb[c] == cu ? 1.0 : 0.0;
+            double ta = 0, tb = 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++) { const double rgq = L.rg[SROW_CON0 + 4 * c + d]; ta += L.Jc[4 * c + d][8 + k] * rgq; tb += L.Jc[4 * c + d][14 + k] * rgq; }
+            t += wa * ta + wb * tb;
           }
         }
         L.g[lane] = t;
@@ -369,14 +370,44 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       if (!coupled) {   // robot block in registers (lanes = (mi, mj)), as in the ReachHuman solver
         double hval = Mij;
         if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
-#pragma unroll 1
-        for (int c = 0; c < nc; c++)
-          if (L.con_rob[c])
-            for (int d = 0; d < 4; d++) { const double hq = L.rh[SROW_CON0 + 4 * c + d]; if (hq != 0) hval += hq * L.Jc[4 * c + d][mi] * L.Jc[4 * c + d][mj]; }
-        const double hl = chol_lanes(hval, lane, &ok);
+#pragma unroll 4
+        for (int q = 0; q < 4 * nc; q++) hval += L.rh[SROW_CON0 + q] * L.Jc[q][mi] * L.Jc[q][mj];   // (zeros where the row has no robot part or no curvature)
+        const double Hinv_ = spd_inverse1(hval, lane, &ok);
         if (!ok) break;
-        chol_store(hl, lane, L.H, L.Hinv);
+        const double x = -matvec_lanes(Hinv_, L.g, lane);
+        if (mj == 0) L.d[mi] = x;
       }
+      if (blocks) {   // four independent cube blocks: 6x6 padded to the 8x8 lane layout with a unit diagonal, inverted together
+        bool good = true;
+        double sv[NCUBE];
+#pragma unroll
+        for (int cu = 0; cu < NCUBE; cu++) {
+          sv[cu] = mi == mj ? (mi < 6 ? cube_mdiag(dm, NV + mi) : 1.0) : 0.0;
+          if (mi == mj && mi < 6 && cu >= HRG_CUBE_L) sv[cu] += L.rh[SROW_WELD0 + 6 * (cu - HRG_CUBE_L) + mi];
+        }
+        if (mi < 6 && mj < 6) {
+#pragma unroll 2
+          for (int c = 0; c < nc; c++) {
+            const int cu = L.con_cb[c];   // (without cube-cube contacts a cube is always geom 2: table, floor; -1: a robot-only contact, whose cube part is zero)
+            double t = 0;
+#pragma unroll
+            for (int d = 0; d < 4; d++) t += L.rh[SROW_CON0 + 4 * c + d] * L.Jc[4 * c + d][14 + mi] * L.Jc[4 * c + d][14 + mj];
+#pragma unroll
+            for (int q = 0; q < NCUBE; q++) sv[q] += cu == q ? t : 0.0;
+          }
+        }
+        spd_inverse4(sv, lane, &ok);
+        good = ok;
+#pragma unroll
+        for (int cu = 0; cu < NCUBE; cu++) {
+          const double x = -row8_sum(sv[cu] * (mj < 6 ? L.g[NV + 6 * cu + mj] : 0.0));
+          if (mj == 0 && mi < 6) L.d[NV + 6 * cu + mi] = x;
+        }
+        STAMP(23);
+        COUNT(18, 1);
+        if (!good) break;
+        STAMP(24);
+      } else {
 #pragma unroll 1
       for (int t = coupled ? 0 : NV / 2; t < NVS / 2; t++) {   // block-diagonal part of the packed Hessian
         const int i = 2 * t + (lane >> 5), j = lane & 31;
@@ -420,14 +451,9 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       if (!chol_stack(lane, coupled ? 0 : NV)) break;
       STAMP(24);
       {
-        double x;
-        if (coupled) x = chol_stack_solve(lane < NVS ? -L.g[lane] : 0.0, lane, 0);
-        else {
-          const double x1 = chol_solve_lanes(L.H, L.Hinv, lane < NV ? -L.g[lane] : 0.0, lane);
-          const double x2 = chol_stack_solve(lane >= NV && lane < NVS ? -L.g[lane] : 0.0, lane, NV);
-          x = lane < NV ? x1 : x2;
-        }
-        if (lane < NVS) L.d[lane] = x;
+        const double x = chol_stack_solve((coupled ? lane < NVS : (lane >= NV && lane < NVS)) ? -L.g[lane] : 0.0, lane, coupled ? 0 : NV);
+        if (coupled ? lane < NVS : (lane >= NV && lane < NVS)) L.d[lane] = x;
+      }
       }
       wave_sync();
 #pragma unroll
@@ -471,21 +497,17 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping for the robot tree
-  chol_store(l_damp, lane, L.H, L.Hinv);
-  if (lane < NV) {
-    s.qacc_warmstart[lane] = L.qacc[lane];
-    double t = 0;
-#pragma unroll
-    for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * L.qacc[j];
-    L.d[lane] = t;
-  }
-  wave_sync();
   {
-    const double x = chol_solve_lanes(L.H, L.Hinv, lane < NV ? L.d[lane] : 0.0, lane);
-    if (lane < NV) {
-      const double v = s.qvel[lane] + h * x;
-      s.qvel[lane] = v;
-      s.qpos[lane] = s.qpos[lane] + h * v;
+    const double t = matvec_lanes(Mij, L.qacc, lane);
+    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
+    wave_sync();
+    if (mj == 0) L.d[mi] = t;
+    wave_sync();
+    const double x = matvec_lanes(MDinv, L.d, lane);
+    if (mj == 0) {
+      const double v = s.qvel[mi] + h * x;
+      s.qvel[mi] = v;
+      s.qpos[mi] = s.qpos[mi] + h * v;
     }
   }
   { // the cubes' free joints: lanes 8..31 = (cube, component); quaternions by lanes 0..3 of each cube's group

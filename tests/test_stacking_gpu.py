@@ -55,12 +55,23 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
         msg = f"{name} step {k}"
         post = [O.get_state(e) for e in range(n)]
         psk = [O.get_stack(e) for e in range(n)]
-        violent = np.array([i_o[e, 11] != 0 or max(abs(v) for v in post[e].qvel) > 5.0 or max(abs(v) for c in range(4) for v in psk[e].vel[c][:3]) > 8.0 for e in range(n)])
+        po, no = O.contacts()
+        # chaotic from then on: a violent arm, a crash, a cube that touches something while it moves at > 3 m/s (one dropped from the hand lands at 4 - 5 m/s)
+        touching = [[bool(((po[e, :no[e], 0] == 36 + c) | (po[e, :no[e], 1] == 36 + c)).any()) for c in range(4)] for e in range(n)]
+        violent = np.array([i_o[e, 11] != 0 or max(abs(v) for v in post[e].qvel) > 5.0 or
+                            any(touching[e][c] and max(abs(v) for v in psk[e].vel[c][:3]) > 3.0 for c in range(4)) for e in range(n)])
         if not resync:
             live &= ~violent
         chk = live & ~violent if resync else live
-        po, no = O.contacts()
         pg, ng = G.contacts()
+        if not resync:
+            # a resting contact that carries no load sits AT distance zero (the soft constraint's equilibrium): whether it is in the list is decided by
+            # rounding-level state differences (measured: 3e-11 after 28 free-running steps, tools/debug_stack.py).  Such an env leaves the comparison and is
+            # counted in the dropped fraction -- but only while its cubes still agree to 1e-7, so that a real divergence cannot hide behind this
+            for e in np.nonzero(chk & ((ng != no) | (pg != po).any((1, 2))))[0]:
+                fo, fg = (np.array([x for c in range(4) for x in list(B.get_stack(e).pos[c]) + list(B.get_stack(e).quat[c])]) for B in (O, G))
+                assert np.abs(fo - fg).max() < 1e-7, f"{msg} env {e}: contact lists differ and so do the cubes ({np.abs(fo - fg).max():.2e})"
+                live[e] = chk[e] = False
         np.testing.assert_array_equal(ng[chk], no[chk], err_msg=msg)        # contact-pair indices bit-exact
         np.testing.assert_array_equal(pg[chk], po[chk], err_msg=msg)
         np.testing.assert_array_equal(i_g.cpu().numpy()[chk], i_o[chk], err_msg=msg)
@@ -95,7 +106,7 @@ def test_random_actions_parity_resync(shield):
 
 def test_random_actions_parity_free_running():
     O, G, _ = _pair(16, dict(shield_type="SSM", horizon=30, seed=3))
-    st = _rollout(O, G, 16, 50, 2, False, "random_free")   # incl. auto-resets
+    st = _rollout(O, G, 16, 50, 2, False, "random_free", min_live=0.5)   # incl. auto-resets; most envs leave when the human drops its first cube
     assert st["cube_contacts"] > 0
 
 
