@@ -705,6 +705,14 @@ __host__ DI void path_plan(hrg_path* P, double s0, double v0, double a0, double 
   P->jerk[0] = dir * jmax; P->jerk[1] = 0; P->jerk[2] = -dir * jmax;
 }
 __host__ DI double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
+// speed a profile ends at (what it was planned to brake to): the state after its three phases, snapped to the exact values 0 and 1 it can be planned for
+__host__ DI double path_vend(const hrg_path* P) {
+  double vv = P->v0, aa = P->a0;
+  for (int i = 0; i < 3; i++) { const double d = P->dur[i], jj = P->jerk[i]; vv += aa * d + 0.5 * jj * d * d; aa += jj * d; }
+  if (fabs(vv) < 1e-12) return 0.0;
+  if (fabs(vv - 1.0) < 1e-12) return 1.0;
+  return vv;
+}
 __host__ DI void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
   double ss = P->s0, vv = P->v0, aa = P->a0;
   for (int i = 0; i < 3; i++) {

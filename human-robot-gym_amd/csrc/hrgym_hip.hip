@@ -2248,8 +2248,11 @@ size_t hrg_stack_bytes(void) { return sizeof(hrg_stack_state); }
 
 int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
   if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
-  if (!(desc->failsafe_sdot >= 0.0 && desc->failsafe_sdot < 1.0)) return fail(HRG_ERR_INVALID, "failsafe_sdot must be in [0, 1)");
-  if (desc->shield_type != HRG_SHIELD_PFL && desc->failsafe_sdot != 0.0) return fail(HRG_ERR_INVALID, "failsafe_sdot > 0 only with shield_type PFL");
+  if (desc->failsafe_sdot != 0.0) return fail(HRG_ERR_INVALID, "failsafe_sdot must be 0: SSM / OFF brake to a stop, PFL computes its speed from pfl_v_safe / pfl_reach");
+  if (desc->shield_type == HRG_SHIELD_PFL) {
+    if (!(desc->pfl_v_safe > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_v_safe must be positive");
+    for (int j = 0; j < NARM; j++) if (!(desc->pfl_reach[j] > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_reach must be positive");
+  }
   if (clips->n_clips < 1 || clips->n_clips > HRG_MAX_CLIPS || clips->n_clips != desc->n_clips) return fail(HRG_ERR_INVALID, "clip table / desc.n_clips mismatch");
   for (int i = 0; i < NV; i++) {
     if ((i < NARM) != (desc->jnt_type[i] == 0)) return fail(HRG_ERR_INVALID, "expected 6 hinges followed by 2 slides");

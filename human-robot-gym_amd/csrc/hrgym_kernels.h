@@ -509,22 +509,33 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
   const double ps = use_cand ? 0.0 : s.path_s, pv = s.path_v, pa = s.path_a;
   hrg_path fs2;
   double s1, v1, a1, se, Tb;
-  if (pv == 1.0 && pa == 0.0) {
-    // steady state on the trajectory (the common case): the recovery step is s += dt and the fail-safe profile is the
-    // model constant "brake from full path speed" shifted to s1
-    s1 = ps + dt; v1 = 1.0; a1 = 0.0;
+  const bool pfl = m.shield_type == HRG_SHIELD_PFL, steady = pv == 1.0 && pa == 0.0;
+  if (steady) { s1 = ps + dt; v1 = 1.0; a1 = 0.0; }   // steady state on the trajectory (the common case): the recovery step is s += dt
+  else {
+    hrg_path rec;
+    path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
+    path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
+  }
+  // speed the fail-safe manoeuvre brakes to: a full stop (SSM), or under PFL the path speed at which no point of the arm exceeds pfl_v_safe on this trajectory:
+  // |v_point| <= s' sum_j |dq_j/ds| r_j with dq/ds taken where the manoeuvre starts (lanes = joints, one wave reduction; re-evaluated every cycle)
+  double ve_fs = m.failsafe_sdot;
+  if (pfl) {
+    double q_, d1_ = 0, d2_;
+    if (lane < NARM) ltt_eval(Lp, lane, s1, &q_, &d1_, &d2_);
+    const double vc = wave_sum(lane < NARM ? fabs(d1_) * m.pfl_reach[lane] : 0.0);
+    ve_fs = vc > m.pfl_v_safe ? m.pfl_v_safe / vc : 1.0;
+  }
+  if (steady && !pfl) {
+    // ... and the fail-safe profile is the model constant "brake from full path speed to a stop" shifted to s1
     fs2.s0 = s1; fs2.v0 = 1.0; fs2.a0 = 0.0; fs2.k = 0.0;
     for (int a = 0; a < 3; a++) { fs2.dur[a] = dm->brake_full.dur[a]; fs2.jerk[a] = dm->brake_full.jerk[a]; }
     Tb = dm->brake_T;
     se = s1 + dm->brake_ds;
   } else {
-    hrg_path rec;
     double ve_, ae;
-    path_plan(&rec, ps, pv, pa, 1.0, m.path_amax, m.path_jmax);
-    path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
-    path_plan(&fs2, s1, v1, a1, m.failsafe_sdot, m.path_amax, m.path_jmax);
+    path_plan(&fs2, s1, v1, a1, ve_fs, m.path_amax, m.path_jmax);
     Tb = path_total(&fs2);
-    path_eval(&fs2, Tb, m.failsafe_sdot, &se, &ve_, &ae);
+    path_eval(&fs2, Tb, ve_fs, &se, &ve_, &ae);
   }
   STAMP(11);
   if (shield_on && lane < NARM) {
@@ -647,10 +658,12 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     const double k = s.safe_path.k + 1.0;
     s.safe_path.k = k;
     double ns, nv, na;
-    path_eval(&s.safe_path, k * dt, m.failsafe_sdot, &ns, &nv, &na);
+    const hrg_path spc = s.safe_path;
+    const double vend = pfl ? path_vend(&spc) : m.failsafe_sdot;   // the speed that profile was planned to brake to
+    path_eval(&s.safe_path, k * dt, vend, &ns, &nv, &na);
     // already at (or below) the fail-safe speed — stopped under SSM, at the PFL safe speed under PFL: a new trajectory may
     // be swapped in although it is not verified safe (sara-shield swaps "if safe or stopped")
-    if (use_cand && s.path_v <= m.failsafe_sdot + 1e-9 && fabs(s.path_a) <= 1e-9) {
+    if (use_cand && s.path_v <= vend + 1e-9 && fabs(s.path_a) <= 1e-9) {
       const double adv = ns - s.path_s;
       double* dst = (double*)&s.ltt;
       const double* src = (const double*)&L.cand;
@@ -658,7 +671,7 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
       s.new_goal = 0;
       ns = adv;  // the candidate's path axis starts at the current position
       hrg_path sp;
-      path_plan(&sp, ns, nv, na, m.failsafe_sdot, m.path_amax, m.path_jmax);
+      path_plan(&sp, ns, nv, na, vend, m.path_amax, m.path_jmax);
       s.safe_path = sp;
     }
     s.path_s = ns; s.path_v = nv; s.path_a = na;

@@ -514,20 +514,18 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         reach = max(np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p1[c][:]) - base), np.linalg.norm(p[b] + R[b] @ np.asarray(d.scap_p2[c][:]) - base))
         d.scap_alpha[c] = reach * (sp["a_max_allowed"] + sp["v_max_allowed"] ** 2)
     d.secure_radius = sp["secure_radius"]
-    # fail-safe target path speed: SSM/OFF brake to a stop; PFL brakes to the path speed at which no link point can move
-    # faster than pfl_v_safe: bound sum_j v_max_ltt_j * (reach of everything downstream of joint j) on the link speeds
-    if d.shield_type == CONST["HRG_SHIELD_PFL"]:
-        v_cart = 0.0
-        for j in range(NARM):
-            rj = 0.0
-            for c in range(j, CONST["HRG_NSHIELD_RCAP"]):
-                b = d.scap_body[c]
-                for q in (d.scap_p1[c][:], d.scap_p2[c][:]):
-                    rj = max(rj, float(np.linalg.norm(p[b] + R[b] @ np.asarray(q) - p[j])) + d.scap_r[c])
-            v_cart += sp["v_max_ltt"] * rj
-        d.failsafe_sdot = min(0.9, sp["pfl_v_safe"] / v_cart)
-    else:
-        d.failsafe_sdot = 0.0
+    # fail-safe target path speed: SSM / OFF brake to a stop.  PFL brakes to the path speed at which no link point can move faster than pfl_v_safe ON THE
+    # TRAJECTORY PLANNED: |v_point| <= s' sum_j |dq_j/ds| r_j with r_j = reach of everything downstream of joint j (lever arm; a model constant), evaluated
+    # every cycle in the steppers -- an arm that already moves slowly keeps its own speed
+    d.failsafe_sdot = 0.0
+    d.pfl_v_safe = float(sp["pfl_v_safe"])
+    for j in range(NARM):
+        rj = 0.0
+        for c in range(j, CONST["HRG_NSHIELD_RCAP"]):
+            b = d.scap_body[c]
+            for q in (d.scap_p1[c][:], d.scap_p2[c][:]):
+                rj = max(rj, float(np.linalg.norm(p[b] + R[b] @ np.asarray(q) - p[j])) + d.scap_r[c])
+        d.pfl_reach[j] = rj
     d.n_bodypart = len(BODY_PARTS)
     for k, (a, b, th, vm, am, inpos) in enumerate(BODY_PARTS):
         d.bp_joint[k][:] = [HUMAN_JOINT_ELEMENTS.index(a), HUMAN_JOINT_ELEMENTS.index(b)]

@@ -207,7 +207,7 @@ typedef struct hrg_model_desc {
   double v_max_allowed[HRG_NARM], a_max_allowed[HRG_NARM], j_max_allowed[HRG_NARM];
   double v_max_ltt[HRG_NARM], a_max_ltt[HRG_NARM], j_max_ltt[HRG_NARM];
   double path_amax, path_jmax;  /* limits on s'' and s''' of fail-safe / recovery manoeuvres */
-  double failsafe_sdot;         /* path speed the fail-safe manoeuvre brakes to: 0 (SSM full stop) or the PFL safe speed */
+  double failsafe_sdot;         /* path speed the fail-safe manoeuvre brakes to under SSM / OFF: 0 (full stop).  PFL computes its own every cycle (pfl_* below) */
   int32_t scap_body[HRG_NSHIELD_RCAP];
   double scap_p1[HRG_NSHIELD_RCAP][3];
   double scap_p2[HRG_NSHIELD_RCAP][3];
@@ -279,6 +279,10 @@ typedef struct hrg_model_desc {
   double ik_target_rot[9];      /* end-effector orientation at init_qpos, held fixed (ik_position_delta_wrapper.py:74-82) */
   /* ---- CollaborativeStackingCart (collaborative_stacking_cartesian_env.py:316-480): box_half / box_mass / box_inertia describe each of the four cubes ---- */
   double stack_toppled_reward, second_cube_at_target_reward, fourth_cube_at_target_reward; /* _sparse_reward (700-744) */
+  /* ---- PFL (power and force limiting): the fail-safe manoeuvre brakes to the path speed at which no point of the arm moves faster than pfl_v_safe on the
+   *      trajectory actually planned: s'_pfl = min(1, pfl_v_safe / sum_j |dq_j/ds| pfl_reach[j]) (demos/demo_gym_functionality_Schunk_pfl_criterion.py:1-8) ---- */
+  double pfl_v_safe;            /* Cartesian speed [m/s] the arm may keep while the reachable sets intersect */
+  double pfl_reach[HRG_NARM];   /* largest distance of a point of the arm downstream of joint j from that joint (lever arm of its velocity) */
   double stack_weld_relpos[3];  /* relpose of the cube <-> hand mocap welds: mocap body origin in the cube frame, "0 0.045 0" (1263-1281) */
   uint64_t seed;
 } hrg_model_desc;

@@ -633,6 +633,14 @@ static void path_plan(hrg_path* P, double s0, double v0, double a0, double ve, d
   P->jerk[0] = dir * jmax; P->jerk[1] = 0; P->jerk[2] = -dir * jmax;
 }
 static double path_total(const hrg_path* P) { return P->dur[0] + P->dur[1] + P->dur[2]; }
+/* speed a profile ends at (what it was planned to brake to): the state after its three phases, snapped to the exact values 0 and 1 it can be planned for */
+static double path_vend(const hrg_path* P) {
+  double vv = P->v0, aa = P->a0;
+  for (int i = 0; i < 3; i++) { const double d = P->dur[i], jj = P->jerk[i]; vv += aa * d + 0.5 * jj * d * d; aa += jj * d; }
+  if (fabs(vv) < 1e-12) return 0.0;
+  if (fabs(vv - 1.0) < 1e-12) return 1.0;
+  return vv;
+}
 static void path_eval(const hrg_path* P, double t, double ve, double* s, double* v, double* a) {
   double ss = P->s0, vv = P->v0, aa = P->a0;
   for (int i = 0; i < 3; i++) {
@@ -765,9 +773,17 @@ static void shield_step(hrgo_batch* B, int e, double t) {
   double s1, v1, a1, se, ve_, ae;
   path_plan(&rec, ps, pv, pa, 1.0, m->path_amax, m->path_jmax);
   path_eval(&rec, dt, 1.0, &s1, &v1, &a1);
-  path_plan(&fs2, s1, v1, a1, m->failsafe_sdot, m->path_amax, m->path_jmax);
+  /* speed the fail-safe manoeuvre brakes to: a full stop (SSM), or under PFL the path speed at which no point of the arm exceeds pfl_v_safe on this
+   * trajectory: |v_point| <= s' sum_j |dq_j/ds| r_j, dq/ds taken where the manoeuvre starts (re-evaluated every cycle) */
+  double ve_fs = m->failsafe_sdot;
+  if (m->shield_type == HRG_SHIELD_PFL) {
+    double vc = 0;
+    for (int j = 0; j < NARM; j++) { double q_, d1_, d2_; ltt_eval(L, j, s1, &q_, &d1_, &d2_); vc += fabs(d1_) * m->pfl_reach[j]; }
+    ve_fs = vc > m->pfl_v_safe ? m->pfl_v_safe / vc : 1.0;
+  }
+  path_plan(&fs2, s1, v1, a1, ve_fs, m->path_amax, m->path_jmax);
   double Tb = path_total(&fs2);
-  path_eval(&fs2, Tb, m->failsafe_sdot, &se, &ve_, &ae);
+  path_eval(&fs2, Tb, ve_fs, &se, &ve_, &ae);
   int safe = 1;
   if (m->shield_type != HRG_SHIELD_OFF) {
     /* robot reach over [current config, config at the end of the brake] */
@@ -807,14 +823,15 @@ static void shield_step(hrgo_batch* B, int e, double t) {
     /* follow the last verified fail-safe profile */
     double ns, nv_, na_;
     s->safe_path.k += 1.0;
-    path_eval(&s->safe_path, s->safe_path.k * dt, m->failsafe_sdot, &ns, &nv_, &na_);
+    const double vend = m->shield_type == HRG_SHIELD_PFL ? path_vend(&s->safe_path) : m->failsafe_sdot; /* the speed that profile was planned to brake to */
+    path_eval(&s->safe_path, s->safe_path.k * dt, vend, &ns, &nv_, &na_);
     /* the robot already moves at (or below) the fail-safe speed — stopped under SSM, at the PFL safe speed under PFL: a new
      * trajectory may be swapped in although it is not verified safe (sara-shield swaps "if safe or stopped") */
-    if (use_cand && s->path_v <= m->failsafe_sdot + 1e-9 && fabs(s->path_a) <= 1e-9) {
+    if (use_cand && s->path_v <= vend + 1e-9 && fabs(s->path_a) <= 1e-9) {
       double adv = ns - s->path_s;
       s->ltt = cand; s->new_goal = 0;
       ns = adv;  /* the candidate's path axis starts at the current position */
-      path_plan(&s->safe_path, ns, nv_, na_, m->failsafe_sdot, m->path_amax, m->path_jmax);
+      path_plan(&s->safe_path, ns, nv_, na_, vend, m->path_amax, m->path_jmax);
     }
     s->path_s = ns; s->path_v = nv_; s->path_a = na_;
   }

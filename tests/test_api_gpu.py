@@ -72,7 +72,7 @@ def test_kernel_timer_and_errors():
         G.step(torch.zeros((63, 7), dtype=torch.float64, device="cuda"))
     G.close()
     bad = hrg.build_model_desc(dict(shield_type="SSM"), n_clips=2)
-    bad.failsafe_sdot = 0.3                                # only PFL may keep moving when unsafe
+    bad.failsafe_sdot = 0.3                                # SSM / OFF brake to a full stop; PFL takes its speed from pfl_v_safe
     with pytest.raises(HrgError, match="failsafe_sdot"):
         HipBatch(bad, clips, 4)
 
