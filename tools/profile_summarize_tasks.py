@@ -1,13 +1,13 @@
 #!/usr/bin/env python3
 """Condense gpurun_out/<tag>_<task>_{trace,fetch,write,bench} (tools/profile_capture_tasks*.sh) into profiles/<tag>_tasks_summary.md + bench JSONs."""
 import csv, glob, json, os, sys
-tag = sys.argv[1] if len(sys.argv) > 1 else "r01t"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r02t"
 go, pr = "gpurun_out", "profiles"
-tasks = ["HumanObjectInspectionCart", "HumanRobotHandoverCart", "RobotHumanHandoverCart", "CollaborativeLiftingCart"]
+tasks = ["HumanObjectInspectionCart", "HumanRobotHandoverCart", "RobotHumanHandoverCart", "CollaborativeLiftingCart", "CollaborativeStackingCart"]
 L = [f"# rocprofv3 summary `{tag}` — the collaboration tasks' kernel variants (`bash tools/profile_capture_tasks.sh {tag}`, 1 x MI355X, 4096 envs each)", "",
-     "`rocprofv3 --kernel-trace --stats -- python3 bench.py --env TASK --steps 60 --warmup 10 --no-cpu-baseline` per task (kernel_stats.csv row of the step kernel), and the",
-     f"un-profiled `python3 bench.py --env TASK --steps 100 --warmup 20` JSON line (`{tag}_<task>_bench.json`).", "",
-     "| task | step kernel | calls | average ns (rocprof) | min ns | max ns | bench: env steps/s | ms/step | kernel ms (HIP events) | algorithmic MB/launch | roofline frac | CPU oracle steps/s (16 threads) |",
+     "`rocprofv3 --kernel-trace --stats -- python3 bench.py --env TASK --steps 40 --warmup 10 --preroll 200 --no-cpu-baseline` per task (kernel_stats.csv row of the step kernel), and the",
+     f"un-profiled `python3 bench.py --env TASK --steps 60 --warmup 10 --cpu-budget 6` JSON line (steady state: pre-roll of min(horizon, 1000) steps, staggered episode phases) (`{tag}_<task>_bench.json`).", "",
+     "| task | step kernel | calls | average ns (rocprof) | min ns | max ns | bench: env steps/s | ms/step | kernel ms (HIP events) | algorithmic MB/launch | roofline frac | CPU oracle steps/s (all physical cores / 16 threads) |",
      "|---|---|---|---|---|---|---|---|---|---|---|---|"]
 T = ["", f"## HBM traffic per launch (separate `--pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes, `bash tools/profile_capture_tasks_pmc.sh {tag}`; KiB counters, FETCH_SIZE doubled as "
      "MI355X_MICROARCH.md prescribes for gfx950)", "",
@@ -19,7 +19,7 @@ for t in tasks:
     json.dump(b, open(f"{pr}/{tag}_{t}_bench.json", "w"))
     rf = b["roofline"]
     L.append(f"| {t} | `{rf['kernel']}` | {row['Calls']} | {float(row['AverageNs']):.0f} | {row['MinNs']} | {row['MaxNs']} | {b['value']:.0f} | {b['ms_per_step']:.3f} | {rf['kernel_ms']:.3f} | "
-             f"{rf['algorithmic_bytes_per_launch'] / 1e6:.1f} | {rf['frac']:.5f} | {b['cpu_baseline']['value']:.0f} |")
+             f"{rf['algorithmic_bytes_per_launch'] / 1e6:.1f} | {rf['frac']:.5f} | {b['cpu_baseline']['value']:.0f} ({b['cpu_baseline']['cores']} cores) / {b['cpu_baseline'].get('value_16_threads', 0):.0f} |")
     v = {}
     for sub, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
         g = sorted(glob.glob(f"{go}/{tag}_{t}_{sub}/*/*_counter_collection.csv"), key=os.path.getmtime)
@@ -32,8 +32,7 @@ for t in tasks:
         fm, wm = v["FETCH_SIZE"] * 1024 / 1e6, v["WRITE_SIZE"] * 1024 / 1e6
         T.append(f"| {t} | {v['FETCH_SIZE']:.0f} | {v['WRITE_SIZE']:.0f} | {fm:.1f} (x2 = {2 * fm:.1f}) | {wm:.1f} | **{2 * fm + wm:.1f}** | {rf['algorithmic_bytes_per_launch'] / 1e6:.1f} | {v['vgpr']} | {v['scratch']} |")
 L += ["", "Shield types as in `training/icra_2024_run_experiments.sh:4-9` (PFL for the handover tasks, SSM otherwise); 13 synthetic clips with the animation info each task reads",
-      "(`mixed.task_clips`); random joint-space actions U(-1,1)^7.  The handover kernel runs two physics passes per shield cycle (the reference's extra `sim.step()`); it is built for",
-      "2 waves per SIMD with the end of its first pass as a real function: at 3 waves, fully inlined, its 648 B/lane of scratch moved 2 879 MB (H2R) / 1 780 MB (R2H) through HBM per launch",
-      "and it was 10 % / 4 % slower."]
+      "(`mixed.task_clips`); random joint-space actions U(-1,1)^7.  The handover kernel runs two physics passes per shield cycle (the reference's extra `sim.step()`); the stacking",
+      "kernel steps a 32-DoF system (robot tree + four free cubes) at one wave per SIMD (38 KB of LDS per env)."]
 open(f"{pr}/{tag}_tasks_summary.md", "w").write("\n".join(L + T) + "\n")
 print("\n".join(L[7:11] + T[5:]))
