@@ -1245,7 +1245,12 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
 #if HRG_BOX
     // PickPlaceHumanCart._setup_observables (pick_place_human_cartesian_env.py:726-841), gripper_aperture (human_env.py:1508-1524)
     const hrg_box_state& bx = L.bx;
+    if (m.task == HRG_TASK_REACH_BOX) {}   // ReachHuman does not observe its smallBox: the ReachHuman layout above stands
+    else
     if ((lane >= 12 && lane < 18) || (lane >= 33 && lane < 39)) v = 0.0;
+    if (m.task == HRG_TASK_REACH_BOX) {}
+    else
+    if (lane >= 12 && lane < 16) v = bx.quat[lane == 15 ? 0 : lane - 11];   // object_quat, (x, y, z, w) like T.convert_quat(..., to="xyzw") (human_robot_handover_cartesian_env.py:849-858)
     else if (lane == 39) v = (double)bx.gripped;
     else if (lane >= 40 && lane < 43) v = bx.obs_pos[lane - 40] - s.eef_pos[lane - 40];
     else if (lane >= 43 && lane < 46) v = bx.target[lane - 43] - s.eef_pos[lane - 43];
@@ -1488,6 +1493,7 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     }
 #endif
   }
+  if (m.task == HRG_TASK_REACH_BOX) goal_sample(dm_, lane, gid, 0);   // ReachHuman with its smallBox: the reach goals of ReachHuman._reset_internal
 #elif HRG_STACK
   { // CollaborativeStackingCart._reset_internal (938-959): the robot's cubes in their bin, the human's cubes in the hands, phase APPROACH
     hrg_stack_state& sk = L.sk;
@@ -1726,13 +1732,26 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   const int in_zone = sqrt(o2t) <= m.goal_dist;
   // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
   const int inspection = m.task == HRG_TASK_INSPECTION || m.task == HRG_TASK_HANDOVER_H2R;   // success = the task's animation ran to its end
-  const int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : ((inspection || m.task == HRG_TASK_LIFTING) ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
+  int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : ((inspection || m.task == HRG_TASK_LIFTING) ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
   double r = goal_reached ? m.task_reward : ((inspection && in_zone) ? m.object_at_target_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
+#if !HRG_HANDOVER && !HRG_LIFT
+  double reach_dist = 0;
+  if (m.task == HRG_TASK_REACH_BOX) {   // ReachHuman with its smallBox: the task logic of ReachHuman (reach_human_env.py:437-475; human_env.py:666-691)
+    double dist2 = 0;
+    for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
+    reach_dist = sqrt(dist2);
+    goal_reached = !crash && reach_dist <= m.goal_dist;
+    r = goal_reached ? m.task_reward : -1.0;
+  }
+#endif
 #if HRG_HANDOVER
   if (m.task == HRG_TASK_HANDOVER_R2H)   // robot_human_handover_cartesian_env.py:507-555
     r = goal_reached ? m.task_reward : (bx.task_phase == HRG_R2H_RETREAT ? m.object_in_human_hand_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
 #endif
   double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
+#if !HRG_HANDOVER && !HRG_LIFT
+  if (m.task == HRG_TASK_REACH_BOX) dense = -0.1 * reach_dist;
+#endif
 #if HRG_LIFT
   double balance = 1.0;
   if (m.task == HRG_TASK_LIFTING) { // collaborative_lifting_cartesian_env.py:429-507: success = the animation ran to its end; base reward +1; dense = normalised balance angle - 2
@@ -1916,6 +1935,14 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
     bx.task_phase = nph;
     wave_sync();
   } else
+#if !HRG_HANDOVER && !HRG_LIFT
+  if (m.task == HRG_TASK_REACH_BOX) {
+    if (goal_reached && !d) { // reach_human_env.py:399-407
+      s.goal_index = (s.goal_index + 1) % m.n_goals;
+      goal_sample(dm_, lane, gid, s.goal_index);   // (the step's observation, written above, still shows the goal that was reached)
+    }
+  } else
+#endif
   if (goal_reached && !d) { // _on_goal_reached (440-453): next target, object teleported to its next placement (velocity kept)
     const int ti = (bx.tgt_index + 1) % m.n_targets, oi = (bx.obj_index + 1) % m.n_obj_placements;
     double po[3], pt[3];
@@ -2263,7 +2290,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_STACKING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_REACH_BOX) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
   if (desc->task == HRG_TASK_STACKING) {
     if (!(desc->box_inertia[0] == desc->box_inertia[1] && desc->box_inertia[1] == desc->box_inertia[2]))
       return fail(HRG_ERR_UNSUPPORTED, "CollaborativeStackingCart: the HIP stepper stacks cubes (object_full_size with three equal edges)");

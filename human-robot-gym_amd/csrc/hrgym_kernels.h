@@ -1185,7 +1185,8 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
 }
 
 // the manipulation object is whitelisted -> COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717)
-DI int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }   // GEOM_BOX + c: cube c of the stacking task
+// GEOM_BOX + c: cube c of the stacking task; ReachHuman's smallBox is NOT whitelisted (a robot contact with it is a static collision)
+DI int geom_class(int g, int task) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX && task != HRG_TASK_REACH_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
@@ -1201,7 +1202,7 @@ PH_CLASSIFY void classify(const DevModel* __restrict__ dm_, int ncon, int* has_c
   const int n_prev = s.n_prev;
   for (int c = 0; c < ncon; c++) {
     const int g1 = s.con_pairs[c][0], g2 = s.con_pairs[c][1];
-    const int t1 = geom_class(g1), t2 = geom_class(g2);
+    const int t1 = geom_class(g1, m.task), t2 = geom_class(g2, m.task);
     if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
     const int h12 = cantor(g1, g2), h21 = cantor(g2, g1);
     if (ncur + 2 <= HRG_NPREV_MAX) { cur[ncur++] = h12; cur[ncur++] = h21; }

@@ -296,13 +296,15 @@ def _check_env_kwargs(env_id, known, given):
 
 
 def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True,
-                     env_id="ReachHuman", ik_position_delta=None):
+                     env_id="ReachHuman", ik_position_delta=None, reach_box=False):
     """Return a filled `ModelDesc` for `env_id` ("ReachHuman" or "PickPlaceHumanCart") on the Schunk arm.
 
     `env_kwargs` takes the same keys as the reference's environment config
     (training/config/environment/reach_human.yaml, default/human_env.yaml).
     `collision_prevention` takes the keys of config/wrappers/collision_prevention/*.yaml (replace_type, n_resamples);
     None = wrapper not in the stack.  `goal_check=False` takes the non-pinocchio branch of `_sample_valid_pos`.
+    `reach_box=True` (ReachHuman only) adds the task's free `smallBox` object (reach_human_env.py:573-579) and steps the task with the cube kernel; the default
+    is the lean model without it (the box is not observed and only matters when the arm happens to hit it).
     `ik_position_delta` takes the keys of config/wrappers/ik_position_delta/*.yaml (action_limit, x_output_max,
     x_position_limits, residual_threshold, max_iter): actions become [dx, dy, dz, gripper]; None = joint-space actions."""
     if env_id not in ENV_DEFAULTS:
@@ -574,6 +576,23 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     for f in range(CONST["HRG_NFINGER"]):
         d.finger_qpos_range[0][f], d.finger_qpos_range[1][f] = FINGER_QPOS_RANGE[0][f], FINGER_QPOS_RANGE[1][f]
     d.task = CONST["HRG_TASK_REACH"]
+    if reach_box:
+        if env_id != "ReachHuman":
+            raise ValueError("reach_box: the smallBox object belongs to ReachHuman")
+        d.task = CONST["HRG_TASK_REACH_BOX"]
+        size = [0.05, 0.05, 0.05]                       # box_size of reach_human_env.py:573
+        half = [0.5 * x for x in size]
+        d.box_half[:] = half
+        d.box_mass = 1000.0 * size[0] * size[1] * size[2]
+        d.box_inertia[:] = [d.box_mass * size[0] ** 2 / 6.0] * 3
+        d.box_inertia_mean = d.box_inertia[0]
+        d.box_invweight_rot = 1.0 / d.box_inertia[0]
+        tx, ty = kw.get("table_full_size", [1.5, 2.0, 0.05])[:2]
+        bx, by = 0.5 * tx - 0.05, 0.5 * ty - 0.05       # the sampler covers the whole table (581-589)
+        d.obj_bin[:] = [-bx, bx, -by, by]
+        d.tgt_bin[:] = [-bx, bx, -by, by]
+        d.obj_z = d.tgt_z = 0.8 + half[2]
+        d.n_obj_placements = d.n_targets = 1
     if env_id in BOX_TASKS:
         d.task = CONST[_TASK_OF[env_id]]
         d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 616

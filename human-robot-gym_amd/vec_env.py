@@ -97,6 +97,7 @@ OBS_COLUMNS = {
     # first target column
     "board_pos": range(47, 50), "vec_eef_to_board": range(40, 43), "board_gripped": range(39, 40), "board_balance": range(50, 51),
     "board_quat": [43, 44, 45, 51],
+    "object_quat": range(12, 16),   # the cube tasks: orientation of the manipulation object, (x, y, z, w)
     # CollaborativeStackingCart (collaborative_stacking_cartesian_env.py:1306-1524): the vectors to the four cubes (a, b, l, r) take the 12 joint-space columns the cube
     # tasks leave empty; vec_eef_to_object / object_pos follow the cube the robot has to place next; next_target_pos sits in the target columns
     "vec_eef_to_all_objects": list(range(12, 18)) + list(range(33, 39)), "vec_eef_to_object_a": range(12, 15), "vec_eef_to_object_b": range(15, 18),
@@ -234,7 +235,7 @@ class HipVecEnv(_VecEnvBase):
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
-                 expert_obs_keys=None, goal_env=False, obs_norm=None, monitor_dir=None, monitor_kwargs=None):
+                 expert_obs_keys=None, goal_env=False, obs_norm=None, monitor_dir=None, monitor_kwargs=None, reach_box=False):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
@@ -274,8 +275,9 @@ class HipVecEnv(_VecEnvBase):
         # ik_position_delta: dict(action_limit=0.15, x_output_max=1, ...) = config/wrappers/ik_position_delta/*.yaml: actions become
         # [dx, dy, dz, gripper] (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py), converted in the kernel
         self._cp, self._goal_check, self._ik = collision_prevention, goal_check, ik_position_delta
+        self._reach_box = bool(reach_box)   # ReachHuman with its free smallBox object (stepped by the cube kernel); default: the lean model
         self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id,
-                                      ik_position_delta=ik_position_delta)
+                                      ik_position_delta=ik_position_delta, reach_box=self._reach_box)
         self._device, self._env_id0 = device, env_id0
         if backend is not None and (isinstance(backend, type) or not hasattr(backend, "step_async")):   # a factory (desc, clips, n_envs, env_id0) -> backend: the caller cannot build the
             backend = backend(self._desc, self._clips, n_envs, env_id0)    # backend itself when the model description is composed here (create_training_vec_env)
@@ -404,7 +406,7 @@ class HipVecEnv(_VecEnvBase):
             return [None] * self.num_envs
         self.env_kwargs["seed"] = int(seed)
         self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check,
-                                      env_id=self.env_id, ik_position_delta=self._ik)
+                                      env_id=self.env_id, ik_position_delta=self._ik, reach_box=self._reach_box)
         if isinstance(self._backend, _TorchBackend):
             self._backend.close()
             self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)

@@ -60,6 +60,7 @@ extern "C" {
 #define HRG_OBS_DIM 57    /* superset of the flat observation; the host selects columns by obs_keys:
                           *  [0:12] object-state  [12:18] goal_difference  [18:24] robot0_joint_pos  [24:30] robot0_joint_vel
                           *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666)
+                          *  the cube tasks serve object_quat (x, y, z, w) in [12:16] (those columns are joint-space entries of ReachHuman only)
                           *  PickPlaceHumanCart (pick_place_human_cartesian_env.py:726-841; zero for ReachHuman):
                           *  [39] object_gripped  [40:43] vec_eef_to_object  [43:46] vec_eef_to_target  [46] gripper_aperture
                           *  [47:50] object_pos  [50:53] target_pos
@@ -113,7 +114,9 @@ enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* H
        HRG_TASK_HANDOVER_H2R = 4 /* HumanRobotHandoverCart (human_robot_handover_cartesian_env.py) */,
        HRG_TASK_HANDOVER_R2H = 5 /* RobotHumanHandoverCart (robot_human_handover_cartesian_env.py) */,
        HRG_TASK_LIFTING = 6 /* CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board together */,
-       HRG_TASK_STACKING = 7 /* CollaborativeStackingCart (collaborative_stacking_cartesian_env.py): human and robot build a stack of four cubes in turns */ };
+       HRG_TASK_STACKING = 7 /* CollaborativeStackingCart (collaborative_stacking_cartesian_env.py): human and robot build a stack of four cubes in turns */,
+       HRG_TASK_REACH_BOX = 8 /* ReachHuman with its free `smallBox` object (reach_human_env.py:573-579, 5 cm cube placed anywhere on the table; not whitelisted: a
+                               * robot contact with it is a static collision); task logic of ReachHuman, stepped by the cube kernel */ };
 #define HRG_IS_HANDOVER(task) ((task) == HRG_TASK_HANDOVER_H2R || (task) == HRG_TASK_HANDOVER_R2H)
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };

@@ -1048,7 +1048,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
 }
 
 /* the manipulation object is whitelisted: COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717) */
-static int geom_class(int g) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); } /* GEOM_BOX + c: cube c of the stacking task (1526-1549) */
+static int geom_class_t(int g, int task) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX && task != HRG_TASK_REACH_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); } /* GEOM_BOX + c: cube c of the stacking task (1526-1549) */
 static int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; } /* utils/pairing.py:4-16 */
 
 /* HumanEnv._collision_detection + _on_*_detected, human_env.py:966-1123 */
@@ -1058,7 +1058,7 @@ static void classify(const hrg_model_desc* m, const robot_kin* k, hrg_env_state*
   double tm = s->debounce_timer - m->timestep; /* human_env.py:1090 */
   s->debounce_timer = tm > 0 ? tm : 0;
   for (int c = 0; c < ncon; c++) {
-    int t1 = geom_class(con[c].g1), t2 = geom_class(con[c].g2);
+    int t1 = geom_class_t(con[c].g1, m->task), t2 = geom_class_t(con[c].g2, m->task); /* ReachHuman's smallBox is not whitelisted (reach_human_env.py has no _setup_collision_info override) */
     if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
     int h12 = cantor(con[c].g1, con[c].g2), h21 = cantor(con[c].g2, con[c].g1);
     if (ncur + 2 <= HRG_NPREV_MAX) { cur[ncur++] = h12; cur[ncur++] = h21; }
@@ -1244,8 +1244,10 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const h
   for (int a = 0; a < 3; a++) obs[30 + a] = (float)s->eef_pos[a];
   for (int c = 39; c < HRG_OBS_DIM; c++) obs[c] = 0.0f;
   for (int f = 0; f < HRG_NFINGER; f++) { obs[53 + f] = (float)s->qpos[NARM + f]; obs[55 + f] = (float)s->qvel[NARM + f]; }
-  if (bx) { /* PickPlaceHumanCart._setup_observables, pick_place_human_cartesian_env.py:726-841; gripper_aperture human_env.py:1508-1524 */
+  if (bx && m->task != HRG_TASK_REACH_BOX) { /* PickPlaceHumanCart._setup_observables, pick_place_human_cartesian_env.py:726-841; gripper_aperture human_env.py:1508-1524 (ReachHuman does not observe its box) */
     for (int j = 0; j < NARM; j++) { obs[12 + j] = 0.0f; obs[33 + j] = 0.0f; }
+    for (int a = 0; a < 3; a++) obs[12 + a] = (float)bx->quat[1 + a]; /* object_quat, (x, y, z, w) like T.convert_quat(..., to="xyzw") (human_robot_handover_cartesian_env.py:849-858) */
+    obs[15] = (float)bx->quat[0];
     obs[39] = (float)bx->gripped;
     double ap = 0;
     for (int f = 0; f < HRG_NFINGER; f++) ap += (s->qpos[NARM + f] - m->finger_qpos_range[0][f]) / (m->finger_qpos_range[1][f] - m->finger_qpos_range[0][f]);
@@ -1609,6 +1611,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
       handover_mocap(B, gid, s, bx, &hk);
     }
     if (m->task != HRG_TASK_LIFTING) v3cpy(bx->obs_pos, bx->pos);
+    if (m->task == HRG_TASK_REACH_BOX) goal_of(B, gid, s, 0, s->cur_goal);
   } else goal_of(B, gid, s, 0, s->cur_goal);
   if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
 }
@@ -1863,7 +1866,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
   double dist2 = 0, dense;
   int goal_reached;
   double r;
-  if (bx) { /* PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611) */
+  if (bx && m->task != HRG_TASK_REACH_BOX) { /* PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611) */
     double e2o = 0, o2t = 0;
     for (int a = 0; a < 3; a++) { e2o += (bx->obs_pos[a] - s->eef_pos[a]) * (bx->obs_pos[a] - s->eef_pos[a]); o2t += (bx->target[a] - bx->obs_pos[a]) * (bx->target[a] - bx->obs_pos[a]); }
     const int in_zone = sqrt(o2t) <= m->goal_dist; /* _check_object_in_target_zone, 550-572 */
@@ -2008,7 +2011,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
      * when it leaves it by more than goal_exit_tolerance */
     if (bx->task_phase == HRG_PHASE_READY && sqrt(o2t) <= m->goal_dist) bx->task_phase = HRG_PHASE_INSPECTION;
     else if (bx->task_phase == HRG_PHASE_INSPECTION && !(sqrt(o2t) - m->goal_exit_tolerance <= m->goal_dist)) bx->task_phase = HRG_PHASE_READY;
-  } else if (goal_reached && bx) { /* _on_goal_reached, pick_place_human_cartesian_env.py:440-453: next target, object teleported to its next placement (velocity kept) */
+  } else if (goal_reached && bx && m->task != HRG_TASK_REACH_BOX) { /* _on_goal_reached, pick_place_human_cartesian_env.py:440-453: next target, object teleported to its next placement (velocity kept) */
     bx->tgt_index = (bx->tgt_index + 1) % m->n_targets;
     bx->obj_index = (bx->obj_index + 1) % m->n_obj_placements;
     placement_of(B, gid, s->episode, bx->tgt_index, 1, bx->target);

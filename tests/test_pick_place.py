@@ -45,7 +45,7 @@ def test_reset_places_object_and_target_in_their_bins_and_observes_them():
         np.testing.assert_allclose(obs[e, 40:43], np.array(bx.pos) - np.array(s.eef_pos), rtol=1e-5, atol=1e-7)
         np.testing.assert_allclose(obs[e, 43:46], np.array(bx.target) - np.array(s.eef_pos), rtol=1e-5, atol=1e-7)
         assert obs[e, 39] == 0 and abs(obs[e, 46] - 1.0) < 1e-6          # not gripped, gripper fully open (qpos_range[1])
-        assert not obs[e, 12:18].any() and not obs[e, 33:39].any()
+        assert list(obs[e, 12:16]) == [0, 0, 0, 1] and not obs[e, 16:18].any() and not obs[e, 33:39].any()   # object_quat (x, y, z, w); no joint-space columns
     assert len({round(B.get_box(e).pos[0], 9) for e in range(16)}) == 16   # per-env streams
     B.close()
 
@@ -310,3 +310,37 @@ def test_scripted_expert_picks_the_cube_up_and_delivers_it():
         wins, grip_steps = np.maximum(wins, info[:, 9]), grip_steps + int(gr.sum())
     assert (wins >= 1).all() and paid >= n and grip_steps > 400, (wins, paid, grip_steps)
     B.close()
+
+
+def test_reach_human_with_its_small_box():
+    """ReachHuman's free smallBox (reach_human_env.py:573-579) on the cube path of the oracle: the task is unchanged (the box is not observed and
+    not whitelisted) -- identical observations and rewards to the lean model while nothing touches the box -- and an arm that hits it collects a STATIC collision."""
+    from oracle.oracle import OracleBatch
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+    kw = dict(shield_type="OFF", horizon=40, reward_shaping=True, seed=4)
+    A = OracleBatch(hrg.build_model_desc(kw, n_clips=3), clips, 6)
+    d = hrg.build_model_desc(kw, n_clips=3, reach_box=True)
+    assert d.task == CONST["HRG_TASK_REACH_BOX"] and list(d.box_half) == [0.025] * 3 and d.obj_bin[0] == -d.obj_bin[1]
+    B = OracleBatch(d, clips, 6)
+    np.testing.assert_array_equal(A.reset(), B.reset())
+    rng = np.random.RandomState(0)
+    for k in range(12):
+        a = rng.uniform(-1, 1, (6, 7))
+        xa, xb = A.step(a), B.step(a)
+        for u, v in zip(xa, xb):
+            np.testing.assert_array_equal(u, v)
+        z = np.array([B.get_box(e).pos[2] for e in range(6)])
+    assert np.all(np.abs(z - (d.table_top_z + 0.025)) < 2e-3)              # the box has popped out of the table top and rests on it
+    # put the box where the forearm sweeps: a robot - box contact is a static collision (the box is not whitelisted)
+    for e in range(6):
+        s, bx = B.get_state(e), B.get_box(e)
+        bx.pos[:] = [s.eef_pos[0], s.eef_pos[1], s.eef_pos[2] - 0.02]
+        bx.vel[:] = [0.0] * 6
+        B.set_box(e, bx)
+    before = B.info[:, CONST["HRG_INFO_N_COLLISIONS_STATIC"]].copy()
+    flags = np.zeros(6, np.int32)
+    for k in range(3):
+        o, r, dn, info = B.step(np.zeros((6, 7)))
+        flags |= info[:, CONST["HRG_INFO_COLLISION_TYPE"]]          # (edge triggered: the flag is raised in the step a contact is new)
+    assert np.all(info[:, CONST["HRG_INFO_N_COLLISIONS_STATIC"]] > before) and np.all(flags & CONST["HRG_COL_STATIC"])
+    A.close(); B.close()

@@ -260,3 +260,46 @@ def test_scripted_expert_delivers_on_the_hip_stepper_end_to_end():
         wins = np.maximum(wins, [i["n_goal_reached"] for i in infos])
     assert (wins >= 1).sum() >= n - 2, wins
     env.close()
+
+
+def test_reach_human_with_its_small_box_parity():
+    """ReachHuman + smallBox (task HRG_TASK_REACH_BOX, cube kernel with ReachHuman's task logic): HIP vs oracle, incl. an arm that is handed the box."""
+    import torch
+    import human_robot_gym_amd as hrg
+    from oracle.oracle import OracleBatch
+    from human_robot_gym_amd._lib import HipBatch
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=300, max_frames=600)
+    kw = dict(shield_type="SSM", horizon=25, reward_shaping=True, seed=6)
+    O = OracleBatch(hrg.build_model_desc(kw, n_clips=3, reach_box=True), clips, 12)
+    G = HipBatch(hrg.build_model_desc(kw, n_clips=3, reach_box=True), clips, 12)
+    L = HipBatch(hrg.build_model_desc(kw, n_clips=3), clips, 12)                     # the lean kernel: same episodes while nothing touches the box
+    np.testing.assert_allclose(G.reset().cpu().numpy(), O.reset(), rtol=RTOL, atol=ATOL)
+    L.reset()
+    rng = np.random.RandomState(3)
+    n_static = 0
+    for k in range(40):
+        a = rng.uniform(-1, 1, (12, 7))
+        if k == 8:    # hand the box to the arm
+            for e in range(0, 12, 2):
+                s, bx = O.get_state(e), O.get_box(e)
+                bx.pos[:] = [s.eef_pos[0], s.eef_pos[1], s.eef_pos[2] - 0.02]
+                bx.vel[:] = [0.0] * 6
+                O.set_box(e, bx); G.set_box(e, bx)
+        o_o, r_o, d_o, i_o = O.step(a)
+        o_g, r_g, d_g, i_g = G.step(torch.from_numpy(a).cuda())
+        o_l, r_l, d_l, i_l = L.step(torch.from_numpy(a).cuda())
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(i_g.cpu().numpy(), i_o, err_msg=f"step {k}")
+        np.testing.assert_array_equal(d_g.cpu().numpy(), d_o)
+        np.testing.assert_allclose(o_g.cpu().numpy(), o_o, rtol=RTOL, atol=1e-6)
+        np.testing.assert_allclose(r_g.cpu().numpy(), r_o, rtol=RTOL, atol=1e-6)
+        if k < 8:
+            np.testing.assert_allclose(o_l.cpu().numpy(), o_o, rtol=RTOL, atol=1e-6)    # lean model == box model while the box is left alone
+        n_static += int(i_o[:, 3].sum())
+        for e in range(12):
+            post, pbox = O.get_state(e), O.get_box(e)
+            assert_state_close(post, G.get_state(e), f"step {k} env {e}")
+            assert_state_close(pbox, G.get_box(e), f"step {k} env {e} box")
+            G.set_state(e, post); G.set_box(e, pbox)
+    assert n_static > 0
+    O.close(); G.close(); L.close()
