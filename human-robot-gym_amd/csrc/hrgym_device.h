@@ -129,6 +129,7 @@ static __device__ unsigned long long g_stamps[32];
 static __device__ unsigned long long g_stamps_slow[34];     // the same sums over the waves that lived longer than g_slow_thresh cycles ([32] = their number, [33] = their total lifetime)
 static __device__ unsigned long long g_slow_thresh = ~0ull;
 static __device__ unsigned long long g_envcyc[16384][3];   // per env: start, end timestamp of its last step
+static __device__ unsigned long long g_envacc[16384][32];  // per env: the phase sums / counters of its last step
 __shared__ unsigned long long g_tbeg;
 __shared__ unsigned long long g_acc[32];   // per-wave accumulators (diagnostic build only: costs one workgroup of occupancy)
 __shared__ unsigned long long g_t0;
@@ -138,7 +139,7 @@ __shared__ unsigned long long g_t0;
 #define STAMP(k) do { unsigned long long _t; STAMP_NOW(_t); if (threadIdx.x == 0) { g_acc[k] += _t - g_t0; g_t0 = _t; } } while (0)
 #define STAMP_FLUSH(lane)
 #define COUNT(k, n) do { if (threadIdx.x == 0) g_acc[k] += (n); } while (0)
-#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); { unsigned long long _te; STAMP_NOW(_te); if (_te - g_tbeg > g_slow_thresh) { if ((lane) < 32) atomicAdd(&g_stamps_slow[lane], g_acc[lane]); if ((lane) == 32) atomicAdd(&g_stamps_slow[32], 1ull); if ((lane) == 33) atomicAdd(&g_stamps_slow[33], _te - g_tbeg); } } if ((lane) == 0 && blockIdx.x < 16384) { unsigned long long _t; STAMP_NOW(_t); g_envcyc[blockIdx.x][0] = g_tbeg; g_envcyc[blockIdx.x][1] = _t; unsigned _hw, _xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); g_envcyc[blockIdx.x][2] = ((unsigned long long)_xcc << 32) | _hw; } } while (0)
+#define STAMP_FINAL(lane) do { __syncthreads(); if ((lane) < 32) atomicAdd(&g_stamps[lane], g_acc[lane]); { unsigned long long _te; STAMP_NOW(_te); if (_te - g_tbeg > g_slow_thresh) { if ((lane) < 32) atomicAdd(&g_stamps_slow[lane], g_acc[lane]); if ((lane) == 32) atomicAdd(&g_stamps_slow[32], 1ull); if ((lane) == 33) atomicAdd(&g_stamps_slow[33], _te - g_tbeg); } } if ((lane) < 32 && blockIdx.x < 16384) g_envacc[blockIdx.x][lane] = g_acc[lane]; if ((lane) == 0 && blockIdx.x < 16384) { unsigned long long _t; STAMP_NOW(_t); g_envcyc[blockIdx.x][0] = g_tbeg; g_envcyc[blockIdx.x][1] = _t; unsigned _hw, _xcc; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(_hw), "=s"(_xcc)); g_envcyc[blockIdx.x][2] = ((unsigned long long)_xcc << 32) | _hw; } } while (0)
 #else
 #define STAMP_DECL
 #define STAMP_INIT(lane)

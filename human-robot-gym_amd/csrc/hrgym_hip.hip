@@ -1559,6 +1559,10 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
   STAMP(0);
+#ifdef HRG_PRIO
+  // the kernel ends with its slowest wave: an env in contact or under a fail-safe manoeuvre has the longer instruction stream, so it issues first
+  if (s.ncon > 0 || !s.is_safe) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
   if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
     if (lane < NARM) {
       const double scale = fabs(m.act_out_max - m.act_out_min) / fabs(m.act_in_max - m.act_in_min);
@@ -2223,6 +2227,7 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
   return 0;
 }
 #if !HRG_BOX && !HRG_STACK
+extern "C" int hrg_debug_envacc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envacc), sizeof(unsigned long long) * 32 * n) == hipSuccess ? 0 : -1; }
 extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envcyc), sizeof(unsigned long long) * 3 * n) == hipSuccess ? 0 : -1; }
 #endif
 #endif

@@ -34,5 +34,7 @@ for t in tasks:
 L += ["", "Shield types as in `training/icra_2024_run_experiments.sh:4-9` (PFL for the handover tasks, SSM otherwise); 13 synthetic clips with the animation info each task reads",
       "(`mixed.task_clips`); random joint-space actions U(-1,1)^7.  The handover kernel runs two physics passes per shield cycle (the reference's extra `sim.step()`); the stacking",
       "kernel steps a 32-DoF system (robot tree + four free cubes) at one wave per SIMD (38 KB of LDS per env)."]
+if len(T) == 5:   # no PMC passes were captured for this tag
+    T = ["", "HBM traffic (PMC) was not captured for the task variants under this tag; `profiles/r01t_tasks_summary.md` holds round 1's."]
 open(f"{pr}/{tag}_tasks_summary.md", "w").write("\n".join(L + T) + "\n")
 print("\n".join(L[7:11] + T[5:]))
