@@ -614,20 +614,26 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
     w = w_hi;
     tc = w > 0 ? (Dm - dist_nocruise(vm, w, amax, jmax)) / w : 0;
   } else {
-    /* root of the increasing function f(w) = dist_nocruise(vm, w) - Dm on [w_lo, w_hi]: Newton with the analytic
-     * derivative, safeguarded by the bracket (falls back to bisection when a step leaves it) */
+    /* root of the increasing, convex, C1 function f(w) = dist_nocruise(vm, w) - Dm on [w_lo, w_hi]: Newton with the analytic derivative, safeguarded by
+     * the bracket (bisection when a step leaves it).  Start: the cruise speed of an all-trapezoidal profile from rest over Dm plus the ramp 0 -> vm (the root
+     * itself when vm = 0 and both ramps reach amax).  An iterate that hits the root (f == 0, or a step that no longer moves) ends the search: it must not
+     * be mistaken for a step onto the bracket's edge, which would send the search bisecting around the root it already has. */
     double lo = w_lo, hi = w_hi;
     const double vtri = amax * amax / jmax;
-    w = 0.5 * (lo + hi);
+    const double De = Dm + 0.5 * vm * scurve_time(vm, amax, jmax);
+    w = 0.5 * (sqrt(vtri * vtri + 4.0 * amax * De) - vtri);
+    if (!(w > lo)) w = lo;
+    if (!(w < hi)) w = hi;
     for (int it = 0; it < 80; it++) {
       const double d1 = w - vm, T1 = scurve_time(d1, amax, jmax), T2 = scurve_time(w, amax, jmax);
       const double f = 0.5 * (vm + w) * T1 + 0.5 * w * T2 - Dm;
-      if (f <= 0) lo = w; else hi = w;
+      if (f == 0) break;
+      if (f < 0) lo = w; else hi = w;
       const double T1p = fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / sqrt(jmax * fabs(d1)) : 0.0);
       const double T2p = fabs(w) >= vtri ? 1.0 / amax : (fabs(w) > 0 ? 1.0 / sqrt(jmax * fabs(w)) : 0.0);
       const double fp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
       double nw = fp > 0 ? w - f / fp : 0.5 * (lo + hi);
-      if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);
+      if (!(nw >= lo && nw <= hi)) nw = 0.5 * (lo + hi);
       const double step = fabs(nw - w);
       w = nw;
       if (step <= 4e-16 * (1.0 + fabs(w)) || hi - lo <= 4e-16 * (1.0 + hi)) break;

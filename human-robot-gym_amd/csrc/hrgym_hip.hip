@@ -267,6 +267,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   // ... and a cube-cube contact couples two cubes; without either, the Newton system is block diagonal: the robot block and four 6x6 cube blocks, each inverted
   // in registers across the wave (the common case: cubes resting on the table, carried by the human's hands, falling)
   const bool blocks = !coupled && !__any(ccpl);
+  const bool busy_rows = !blocks || __any(lane < nc && L.con_rob[lane]);
   wave_sync();
   auto rowdot = [&](const SRow& w, const double* x) -> double {
     if (!w.active) return 0.0;
@@ -464,6 +465,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
       double al = 1.0, lo = 0, hi = -1;
       const double d1_0 = gd0 + wave_sum(gg[0] * R[0].p + gg[1] * R[1].p);
+      const double noise = fabs(gd0) + dMd + wave_sum(fabs(gg[0] * R[0].p) + fabs(gg[1] * R[1].p));   // magnitude of the terms phi' is summed from
 #pragma unroll 1
       for (int ls = 0; ls < 40; ls++) {
         COUNT(17, 1);
@@ -477,7 +479,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
           }
         const double d1 = gd0 + al * dMd + wave_sum(sg_);
         const double d2 = dMd + wave_sum(sh_);
-        if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+        if (fabs(d1) <= 1e-10 * fabs(d1_0) || fabs(d1) <= 1e-14 * noise) break;   // converged, or down at the rounding noise of the sum's own terms
         if (d1 < 0) lo = al; else hi = al;
         double nx = al - d1 / d2;
         if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
@@ -535,7 +537,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     }
   }
   wave_sync();
-  return 0;
+  return busy_rows ? 2 : 0;   // bit 0: diverged; bit 1: the robot tree carries contact rows or cubes are stacked (the caller's measure of how busy this env is)
 }
 #else
 PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
@@ -741,6 +743,13 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   STAMP(21);
   COUNT(19, __popcll(mask));  // active rows
   wave_sync();
+  // the contact rows in the sums below: ALL rows of the substep's contacts, in slot order, unrolled by contact -- an inactive row carries g = h = 0 over a finite
+  // Jacobian row, so it adds an exact zero and the sums are those over the active rows (the oracle's), but the LDS reads of a contact's four rows are
+  // independent of each other instead of hanging on a find-first-set chain through the row mask
+  const int nq = 4 * (ncon < NCON_DYN ? ncon : NCON_DYN);
+#if HRG_LIFT
+  const uint64_t wmask = bmask >> (ROW_WELD0 - ROW_CON0);   // the connect rows behind the contact rows (their Jacobian rows exist only while the grip holds)
+#endif
   // J_r . x for a wave-shared vector x (LDS)
   auto rowdot = [&](const double* x) -> double {
     if (!active) return 0.0;
@@ -792,14 +801,19 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         t += L.rg[lane];
         t += L.rg[NV + 2 * lane];
         t -= L.rg[NV + 2 * lane + 1];
-        for (uint64_t mm = rmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+#pragma unroll 4
+        for (int q = 0; q < nq; q++) t += L.Jc[q][lane] * L.rg[ROW_CON0 + q];
         L.g[lane] = t;
       }
 #if HRG_BOX
       else if (lane < NVT) {
         double t = -L.Ma0[lane] + box_Mrow(m.box_mass, lane - NV, &L.qacc[NV]);
         gm = t;
-        for (uint64_t mm = bmask; mm;) { const int q = __ffsll((long long)mm) - 1; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+#pragma unroll 4
+        for (int q = 0; q < nq; q++) t += L.Jc[q][lane] * L.rg[ROW_CON0 + q];
+#if HRG_LIFT
+        for (uint64_t mm = wmask; mm;) { const int q = __ffsll((long long)mm) - 1 + ROW_WELD0 - ROW_CON0; mm &= mm - 1; t += L.Jc[q][lane] * L.rg[ROW_CON0 + q]; }
+#endif
 #if HRG_HANDOVER
         t += L.rg[ROW_WELD0 + lane - NV];   // weld row of this DoF (0 when the weld is off)
 #endif
@@ -814,22 +828,24 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         // robot block (as in the ReachHuman solver) and cube block (6x6 padded to 8x8 with a unit diagonal), lanes = (mi, mj)
         double hval = Mij;
         if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
-        for (uint64_t mm = rmask; mm;) {
-          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
-          const double hq = L.rh[ROW_CON0 + q];
-          if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
-        }
+#pragma unroll 4
+        for (int q = 0; q < nq; q++) hval += L.rh[ROW_CON0 + q] * L.Jc[q][mi] * L.Jc[q][mj];
         double sval = mi == mj ? (mi < 3 ? m.box_mass : 1.0) : 0.0;
         if (mi >= 3 && mi < HRG_NBOXV && mj >= 3 && mj < HRG_NBOXV) sval = L.bMr[3 * (mi - 3) + (mj - 3)];
 #if HRG_HANDOVER
         if (mi == mj && mi < HRG_NBOXV) sval += L.rh[ROW_WELD0 + mi];
 #endif
-        if (mi < HRG_NBOXV && mj < HRG_NBOXV)
-          for (uint64_t mm = bmask; mm;) {
-            const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
+        if (mi < HRG_NBOXV && mj < HRG_NBOXV) {
+#pragma unroll 4
+          for (int q = 0; q < nq; q++) sval += L.rh[ROW_CON0 + q] * L.Jc[q][NV + mi] * L.Jc[q][NV + mj];
+#if HRG_LIFT
+          for (uint64_t mm = wmask; mm;) {
+            const int q = __ffsll((long long)mm) - 1 + ROW_WELD0 - ROW_CON0; mm &= mm - 1;
             const double hq = L.rh[ROW_CON0 + q];
             if (hq != 0) sval += hq * L.Jc[q][NV + mi] * L.Jc[q][NV + mj];
           }
+#endif
+        }
         STAMP(23);
         if (__any(hh != 0 && rpart) || !h_is_m) {  // a robot row has curvature: invert the robot block of the Hessian (until then it is M, whose inverse is already held)
           Minv = spd_inverse1(hval, lane, &ok);
@@ -882,11 +898,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
 #else
       double hval = Mij;
       if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
-      for (uint64_t mm = cmask; mm;) {
-        const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
-        const double hq = L.rh[ROW_CON0 + q];
-        if (hq != 0) hval += hq * L.Jc[q][mi] * L.Jc[q][mj];
-      }
+#pragma unroll 4
+      for (int q = 0; q < nq; q++) hval += L.rh[ROW_CON0 + q] * L.Jc[q][mi] * L.Jc[q][mj];
       wave_sync();
       double gn = 0, sc = 0;
 #pragma unroll
@@ -915,6 +928,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
       double al = 1.0, lo = 0, hi = -1;
       const double d1_0 = gd0 + wave_sum(gg * p);
+      const double noise = fabs(gd0) + dMd + wave_sum(fabs(gg * p));   // magnitude of the terms phi' is summed from
 #pragma unroll 1
       for (int ls = 0; ls < 40; ls++) {
         COUNT(17, 1);  // line-search evaluations
@@ -922,7 +936,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         if (active) row_cost(type, D, floss, flim, y + al * p, &c2, &g2, &h2);
         const double d1 = gd0 + al * dMd + wave_sum(g2 * p);
         const double d2 = dMd + wave_sum(h2 * p * p);
-        if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+        if (fabs(d1) <= 1e-10 * fabs(d1_0) || fabs(d1) <= 1e-14 * noise) break;   // converged, or down at the rounding noise of the sum's own terms
         if (d1 < 0) lo = al; else hi = al;
         double nx = al - d1 / d2;
         if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
@@ -978,7 +992,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   }
 #endif
   wave_sync();
-  return 0;
+  return rmask != 0 ? 2 : 0;   // bit 0: diverged; bit 1: the robot tree carries contact rows (the caller's measure of how busy this env is)
 }
 #endif   // HRG_STACK
 
@@ -1551,7 +1565,7 @@ __device__ __noinline__
 #else
 DI
 #endif
-int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, int busy, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
   // opaque per cycle: nothing derived from the lane id is hoisted out of the 25-cycle loop and kept live (spilled)
   asm volatile("" : "+v"(lane));
   const ModelPtr dm = uniform_model(dm_);
@@ -1559,9 +1573,12 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
   STAMP(0);
-#ifdef HRG_PRIO
-  // the kernel ends with its slowest wave: an env in contact or under a fail-safe manoeuvre has the longer instruction stream, so it issues first
-  if (s.ncon > 0 || !s.is_safe) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#ifndef HRG_NO_PRIO
+  // a launch ends with its slowest wave, and the waves of a SIMD share its issue slots: an env whose robot was in contact in the last substep (Newton
+  // iterations, Hessian inversions) or that is under a fail-safe manoeuvre (replanning every cycle) has the longer instruction stream ahead of it, so its
+  // wave issues first (measured with ReachHuman at 4096 envs: 2.06 -> 1.79 ms per step)
+  // (the condition goes through readfirstlane: s_setprio is a scalar instruction that ignores the exec mask, so a lane-masked if/else would run both arms)
+  if (__builtin_amdgcn_readfirstlane((busy || !s.is_safe) ? 1 : 0)) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
 #endif
   if (cyc == 0) { // FailsafeController.set_goal, failsafe_controller.py:252-300
     if (lane < NARM) {
@@ -1615,7 +1632,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 #endif
   STAMP(4);
   int ncon = 0;
-  int crash = 0;
+  int crash = 0, busy_out = 0;
 #if HRG_HANDOVER
   // HumanRobotHandoverCart._control_human (human_robot_handover_cartesian_env.py:598-633) runs one more sim.step() with the new human pose
   // (no bookkeeping), then re-poses the hand mocap body and sim.forward() runs again: pass 0 = that step, pass 1 = the cycle's regular step.
@@ -1629,11 +1646,11 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
     STAMP(5);
     if (pass == 1) {
       int hc = L.acc_has_collision, ct = L.acc_collision_type;
-      classify(dm_, ncon, &hc, &ct);
+      classify(dm_, lane, ncon, &hc, &ct);
       L.acc_has_collision = hc; L.acc_collision_type = ct;
       STAMP(6);
     }
-    crash = dynamics_step(dm_, lane, ncon);
+    { const int r = dynamics_step(dm_, lane, ncon); crash = r & 1; busy_out |= r & 2; }
     STAMP(7);
     if (pass == 0 && !crash) {
       handover_first_pass_tail(dm_, lane, gid);
@@ -1644,10 +1661,10 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   if (pm & 8) collide(dm_, lane, &ncon);
   STAMP(5);
   int hc = L.acc_has_collision, ct = L.acc_collision_type;
-  classify(dm_, ncon, &hc, &ct);
+  classify(dm_, lane, ncon, &hc, &ct);
   L.acc_has_collision = hc; L.acc_collision_type = ct;
   STAMP(6);
-  if (pm & 16) crash = dynamics_step(dm_, lane, ncon);
+  if (pm & 16) { const int r = dynamics_step(dm_, lane, ncon); crash = r & 1; busy_out |= r & 2; }
   STAMP(7);
 #endif
   if (!crash) {
@@ -1657,7 +1674,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   }
   wave_sync();
   STAMP_FLUSH(lane);
-  return crash;
+  return crash | busy_out;
 }
 
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
@@ -1683,7 +1700,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
   wave_sync();
 #pragma unroll 1
-  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) crash = cycle_body(dm_, lane, e, gid, cyc, dbg_r, dbg_h, dbg_nh);
+  for (int cyc = 0, busy = 0 /* of the previous substep; a step starts unbiased */; cyc < m.n_cycles && !crash; cyc++) { const int r = cycle_body(dm_, lane, e, gid, cyc, busy, dbg_r, dbg_h, dbg_nh); crash = r & 1; busy = r >> 1; }
   has_collision = L.acc_has_collision; collision_type = L.acc_collision_type;
   // ---- observation / success / info / reward / done ----
   double goal[NARM];

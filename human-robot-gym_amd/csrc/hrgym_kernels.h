@@ -1189,41 +1189,66 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
 DI int geom_class(int g, int task) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX && task != HRG_TASK_REACH_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
-// HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080); wave-uniform, ncon is usually 0
-PH_CLASSIFY void classify(const DevModel* __restrict__ dm_, int ncon, int* has_collision, int* collision_type) {
+// HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080).  lanes = contacts of the substep; the reference's loop over the contact list is
+// sequential in two places only: the list of remembered pairs is appended in contact order (prefix count of a ballot), and the debounce timer lets the
+// FIRST new human contact through and mutes the ones behind it (lowest set bit of a ballot).  Everything else is a count.
+PH_CLASSIFY void classify(const DevModel* __restrict__ dm_, int lane, int ncon, int* has_collision, int* collision_type) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
-  int* cur = L.cur;  // scratch in the (dead) collide area of the LDS union
-  int ncur = 0;
   const double tm = s.debounce_timer - m.timestep;
   double deb = tm > 0 ? tm : 0;
+  if (ncon == 0) {   // the usual case
+    wave_sync();
+    s.debounce_timer = deb;
+    s.n_prev = 0;
+    return;
+  }
   const int n_prev = s.n_prev;
-  for (int c = 0; c < ncon; c++) {
-    const int g1 = s.con_pairs[c][0], g2 = s.con_pairs[c][1];
+  bool rob = false, fresh = false;
+  int h12 = 0, h21 = 0, rg = 0, ot = 0;
+  if (lane < ncon) {
+    const int g1 = s.con_pairs[lane][0], g2 = s.con_pairs[lane][1];
     const int t1 = geom_class(g1, m.task), t2 = geom_class(g2, m.task);
-    if (t1 != HRG_GEOM_ROBOT && t2 != HRG_GEOM_ROBOT) continue;
-    const int h12 = cantor(g1, g2), h21 = cantor(g2, g1);
-    if (ncur + 2 <= HRG_NPREV_MAX) { cur[ncur++] = h12; cur[ncur++] = h21; }
-    int seen = 0;
-    for (int i = 0; i < n_prev; i++) if (s.prev_pairs[i] == h12) seen = 1;
-    if (seen) continue;
-    const int rg = t1 == HRG_GEOM_ROBOT ? g1 : g2;
-    const int ot = t1 == HRG_GEOM_ROBOT ? t2 : t1;
-    *has_collision = 1;
-    if (ot == HRG_GEOM_ROBOT) { *collision_type |= HRG_COL_ROBOT; s.n_collisions_robot = s.n_collisions_robot + 1; }
-    else if (ot == HRG_GEOM_HUMAN) {
-      if (deb > 0) continue;
-      deb = m.collision_debounce_delay;
+    rob = t1 == HRG_GEOM_ROBOT || t2 == HRG_GEOM_ROBOT;
+    h12 = cantor(g1, g2); h21 = cantor(g2, g1);
+    rg = t1 == HRG_GEOM_ROBOT ? g1 : g2;
+    ot = t1 == HRG_GEOM_ROBOT ? t2 : t1;
+    bool seen = false;
+    for (int i = 0; i < n_prev; i++) seen |= s.prev_pairs[i] == h12;
+    fresh = rob && !seen;
+  }
+  const uint64_t rmask = __ballot(rob), lt = (1ull << lane) - 1;
+  const int idx = 2 * __popcll(rmask & lt);
+  int ncur = 2 * __popcll(rmask);
+  if (ncur > HRG_NPREV_MAX) ncur = HRG_NPREV_MAX & ~1;
+  const uint64_t m_rr = __ballot(fresh && ot == HRG_GEOM_ROBOT), m_hu = __ballot(fresh && ot == HRG_GEOM_HUMAN);
+  const uint64_t m_al = __ballot(fresh && ot == HRG_GEOM_ALLOWED), m_st = __ballot(fresh && ot == HRG_GEOM_STATIC);
+  int ct = *collision_type;
+  bool crit = false;
+  const bool human_counts = m_hu != 0 && !(deb > 0);
+  if (human_counts) {
+    const int first = __ffsll((long long)m_hu) - 1;
+    if (lane == first) {
       double v[3];
       robot_point_vel(m.rcap_body[rg], L.rcen[rg], v);
-      if (v3norm(v) <= m.safe_vel) { *collision_type |= HRG_COL_HUMAN; s.n_collisions_human = s.n_collisions_human + 1; }
-      else { *collision_type |= HRG_COL_HUMAN_CRIT; s.n_collisions_critical = s.n_collisions_critical + 1; }
-    } else if (ot == HRG_GEOM_ALLOWED) { *collision_type |= HRG_COL_ALLOWED; }
-    else { *collision_type |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + 1; }
+      crit = !(v3norm(v) <= m.safe_vel);
+    }
+    crit = __any(crit);
+    deb = m.collision_debounce_delay;
   }
+  wave_sync();   // every lane has read the remembered pairs and the counters
+  if (rob && idx + 2 <= HRG_NPREV_MAX) { s.prev_pairs[idx] = h12; s.prev_pairs[idx + 1] = h21; }
+  if ((m_rr | m_hu | m_al | m_st) != 0) *has_collision = 1;
+  if (m_rr) { ct |= HRG_COL_ROBOT; s.n_collisions_robot = s.n_collisions_robot + __popcll(m_rr); }
+  if (human_counts) {
+    if (crit) { ct |= HRG_COL_HUMAN_CRIT; s.n_collisions_critical = s.n_collisions_critical + 1; }
+    else { ct |= HRG_COL_HUMAN; s.n_collisions_human = s.n_collisions_human + 1; }
+  }
+  if (m_al) ct |= HRG_COL_ALLOWED;
+  if (m_st) { ct |= HRG_COL_STATIC; s.n_collisions_static = s.n_collisions_static + __popcll(m_st); }
+  *collision_type = ct;
   s.debounce_timer = deb;
   s.n_prev = ncur;
-  for (int i = 0; i < HRG_NPREV_MAX; i++) if (i < ncur) s.prev_pairs[i] = cur[i];
 }

@@ -551,20 +551,26 @@ static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, d
     w = w_hi;
     tc = w > 0 ? (Dm - dist_nocruise(vm, w, amax, jmax)) / w : 0;
   } else {
-    /* root of the increasing function f(w) = dist_nocruise(vm, w) - Dm on [w_lo, w_hi]: Newton with the analytic
-     * derivative, safeguarded by the bracket (falls back to bisection when a step leaves it) */
+    /* root of the increasing, convex, C1 function f(w) = dist_nocruise(vm, w) - Dm on [w_lo, w_hi]: Newton with the analytic derivative, safeguarded by
+     * the bracket (bisection when a step leaves it).  Start: the cruise speed of an all-trapezoidal profile from rest over Dm plus the ramp 0 -> vm (the root
+     * itself when vm = 0 and both ramps reach amax).  An iterate that hits the root (f == 0, or a step that no longer moves) ends the search: it must not
+     * be mistaken for a step onto the bracket's edge, which would send the search bisecting around the root it already has. */
     double lo = w_lo, hi = w_hi;
     const double vtri = amax * amax / jmax;
-    w = 0.5 * (lo + hi);
+    const double De = Dm + 0.5 * vm * scurve_time(vm, amax, jmax);
+    w = 0.5 * (sqrt(vtri * vtri + 4.0 * amax * De) - vtri);
+    if (!(w > lo)) w = lo;
+    if (!(w < hi)) w = hi;
     for (int it = 0; it < 80; it++) {
       const double d1 = w - vm, T1 = scurve_time(d1, amax, jmax), T2 = scurve_time(w, amax, jmax);
       const double f = 0.5 * (vm + w) * T1 + 0.5 * w * T2 - Dm;
-      if (f <= 0) lo = w; else hi = w;
+      if (f == 0) break;
+      if (f < 0) lo = w; else hi = w;
       const double T1p = fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / sqrt(jmax * fabs(d1)) : 0.0);
       const double T2p = fabs(w) >= vtri ? 1.0 / amax : (fabs(w) > 0 ? 1.0 / sqrt(jmax * fabs(w)) : 0.0);
       const double fp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
       double nw = fp > 0 ? w - f / fp : 0.5 * (lo + hi);
-      if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);
+      if (!(nw >= lo && nw <= hi)) nw = 0.5 * (lo + hi);
       const double step = fabs(nw - w);
       w = nw;
       if (step <= 4e-16 * (1.0 + fabs(w)) || hi - lo <= 4e-16 * (1.0 + hi)) break;
@@ -1198,7 +1204,10 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
     /* exact line search on phi(al) = cost(a + al d): safeguarded Newton on phi' */
     double dMd = 0, gd0 = 0;
     for (int i = 0; i < nv; i++) { dMd += d[i] * Md[i]; double t = -Ma0[i]; for (int j = 0; j < nv; j++) t += M[i * nv + j] * a[j]; gd0 += d[i] * t; }
-    double al = 1.0, lo = 0, hi = -1, d1_0 = 0;
+    double al = 1.0, lo = 0, hi = -1, d1_0 = 0, noise = 0;
+#ifdef HRG_LS_DEBUG
+    double tr_al[40], tr_d1[40]; int tr_n = 0;
+#endif
     for (int ls = 0; ls < 40; ls++) {
       double d1 = gd0 + al * dMd, d2 = dMd;
       for (int r = 0; r < E->n; r++) {
@@ -1209,15 +1218,26 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
       }
       if (ls == 0) { /* also need phi'(0) for the stopping scale */
         d1_0 = gd0;
-        for (int r = 0; r < E->n; r++) { double cc, gg, hh; row_cost(E, r, x[r], &cc, &gg, &hh); d1_0 += gg * p[r]; }
+        noise = fabs(gd0) + dMd; /* magnitude of the terms phi' is summed from: 1e-14 of it is rounding noise, not slope */
+        for (int r = 0; r < E->n; r++) { double cc, gg, hh; row_cost(E, r, x[r], &cc, &gg, &hh); d1_0 += gg * p[r]; noise += fabs(gg * p[r]); }
       }
-      if (fabs(d1) <= 1e-10 * fabs(d1_0)) break;
+#ifdef HRG_LS_DEBUG
+      tr_al[tr_n] = al; tr_d1[tr_n++] = d1;
+#endif
+      if (fabs(d1) <= 1e-10 * fabs(d1_0) || fabs(d1) <= 1e-14 * noise) break; /* converged, or down at the rounding noise of the sum's own terms */
       if (d1 < 0) lo = al; else hi = al;
       double nx = al - d1 / d2;
       if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
       else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
       al = nx;
     }
+#ifdef HRG_LS_DEBUG
+    if (tr_n >= 12) {
+      fprintf(stderr, "LS it %d n %d rows %d d1_0 %.3e gd0 %.3e dMd %.3e:", it, tr_n, E->n, d1_0, gd0, dMd);
+      for (int k = 0; k < tr_n; k++) fprintf(stderr, " (%.17g %.2e)", tr_al[k], tr_d1[k]);
+      fprintf(stderr, "\n");
+    }
+#endif
     /* a full Newton step that stayed inside one quadratic piece of every row solves the problem exactly: the gradient at the
      * new point is zero up to rounding, so the next iteration would only confirm convergence */
     int exact = al == 1.0;
