@@ -283,6 +283,11 @@ __shared__ Lds g_Lw[HRG_WG_WAVES];
 __shared__ Lds g_L;
 #endif
 DI int hrg_lane() { return (int)(threadIdx.x & 63u); }
+// Launch order of a step: workgroup i steps env cur[i].  Every wave leaves its env in the order of the NEXT launch -- envs that were busy (robot contacts, fail-safe
+// manoeuvre) from the front, the others from the back -- so busy envs start first and, with the dispatcher's placement (consecutive workgroups go round the 256 CUs, and
+// round the 4 SIMDs of a CU every 256), land on different SIMDs instead of piling their long instruction streams onto one.  buf = [order A (n) | order B (n) |
+// front/back counters A (2) | counters B (2)]; the launch with parity p reads order p, fills order 1-p through counters 1-p and clears counters p for the launch after it.
+struct StepOrder { int32_t* buf; int32_t n; int32_t parity; };
 DI int hrg_env() { return (int)blockIdx.x * HRG_WG_WAVES + (int)(threadIdx.x >> 6); }
 #define HRG_LAUNCH_DIMS(n) dim3(((n) + HRG_WG_WAVES - 1) / HRG_WG_WAVES), dim3(64 * HRG_WG_WAVES)
 

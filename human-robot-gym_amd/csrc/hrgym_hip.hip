@@ -1679,7 +1679,7 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
-DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_gid, double* __restrict__ action, float* obs, float* term_obs,
+DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_gid, double* __restrict__ action, float* obs, float* term_obs,
                  float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -1699,8 +1699,9 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
   s.timestep = s.timestep + 1;
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
   wave_sync();
+  int busy = 0;   // of the previous substep; a step starts unbiased
 #pragma unroll 1
-  for (int cyc = 0, busy = 0 /* of the previous substep; a step starts unbiased */; cyc < m.n_cycles && !crash; cyc++) { const int r = cycle_body(dm_, lane, e, gid, cyc, busy, dbg_r, dbg_h, dbg_nh); crash = r & 1; busy = r >> 1; }
+  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) { const int r = cycle_body(dm_, lane, e, gid, cyc, busy, dbg_r, dbg_h, dbg_nh); crash = r & 1; busy = r >> 1; }
   has_collision = L.acc_has_collision; collision_type = L.acc_collision_type;
   // ---- observation / success / info / reward / done ----
   double goal[NARM];
@@ -2040,6 +2041,7 @@ DI void env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_
 #endif
   STAMP(9);
   STAMP_FINAL(lane);
+  return (busy || !s.is_safe) && !d;   // a freshly reset env starts like any other
 }
 
 // ================================================================================================ kernels
@@ -2102,9 +2104,11 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
 __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_kernel(const DevModel* __restrict__ dm, hrg_env_state* __restrict__ states, double* __restrict__ actions,
                                                      float* __restrict__ obs, float* __restrict__ term_obs, float* __restrict__ reward, uint8_t* __restrict__ done,
                                                      int32_t* __restrict__ info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* __restrict__ scratch_obs,
-                                                     ObjState* __restrict__ boxes, int n_envs) {
-  const int e = hrg_env(), lane = hrg_lane();
-  if (e >= n_envs) return;   // a partly filled last workgroup (HRG_WG_WAVES > 1); the waves of a workgroup never wait for each other
+                                                     ObjState* __restrict__ boxes, int n_envs, StepOrder ord) {
+  const int slot = hrg_env(), lane = hrg_lane();
+  if (slot >= n_envs) return;   // a partly filled last workgroup (HRG_WG_WAVES > 1); the waves of a workgroup never wait for each other
+  const int e = __builtin_amdgcn_readfirstlane(ord.buf[(size_t)ord.parity * ord.n + slot]);
+  if ((unsigned)e >= (unsigned)n_envs) return;   // cannot happen while the two orders are permutations; never index the batch with anything else
   Lds& L = g_L;
   (void)boxes;  // the cube's state array: only the HRG_BOX variant streams it
   const double* src = (const double*)(states + e);
@@ -2116,9 +2120,15 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_
 #endif
   wave_sync();
   float* tobs = term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : scratch_obs + (size_t)e * HRG_OBS_DIM;
-  env_step(dm, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
-           info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh);
+  const int busy = env_step(dm, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
+                            info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh);
   wave_sync();
+  if (lane == 0) {   // this env's place in the next launch
+    int32_t* ctr = ord.buf + 2 * (size_t)ord.n + 2 * (1 - ord.parity);
+    const int at = busy ? atomicAdd(ctr, 1) : ord.n - 1 - atomicAdd(ctr + 1, 1);
+    ord.buf[(size_t)(1 - ord.parity) * ord.n + at] = e;
+    if (slot == 0) { int32_t* mine = ord.buf + 2 * (size_t)ord.n + 2 * ord.parity; mine[0] = 0; mine[1] = 0; }
+  }
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
 #if HRG_BOX || HRG_STACK
@@ -2171,14 +2181,14 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_check
 // launch shims of the cube variant: defined by hrgym_box.hip (this file compiled with HRG_BOX=1), called by the host side below
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                            float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
-                                                                           float* scratch_obs, hrg_box_state* boxes);
+                                                                           float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                             int64_t env_id0, hrg_box_state* boxes);
 #if !HRG_BOX && !HRG_STACK
 // ... of the stacking variant (hrgym_stack.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                              float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
-                                                                             float* scratch_obs, hrg_stack_state* stacks);
+                                                                             float* scratch_obs, hrg_stack_state* stacks, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                               int64_t env_id0, hrg_stack_state* stacks);
 #endif
@@ -2186,20 +2196,20 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_reset(int
 // the same shims of the handover variant (hrgym_handover.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                           float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
-                                                                          float* scratch_obs, hrg_box_state* boxes);
+                                                                          float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                            int64_t env_id0, hrg_box_state* boxes);
 // ... and of the lifting variant (hrgym_lift.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                             float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
-                                                                            float* scratch_obs, hrg_box_state* boxes);
+                                                                            float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                              int64_t env_id0, hrg_box_state* boxes);
 #endif
 #if HRG_STACK
 extern "C" void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
-                                      int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_stack_state* stacks) {
-  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, stacks, n_envs);
+                                      int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_stack_state* stacks, StepOrder ord) {
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, stacks, n_envs, ord);
 }
 extern "C" void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_stack_state* stacks) {
   hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, stacks, n_envs);
@@ -2207,8 +2217,8 @@ extern "C" void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevMode
 #endif
 #if HRG_BOX
 extern "C" void hrg_box_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
-                                    int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes) {
-  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, boxes, n_envs);
+                                    int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_box_state* boxes, StepOrder ord) {
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, boxes, n_envs, ord);
 }
 extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_box_state* boxes) {
   hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, boxes, n_envs);
@@ -2273,6 +2283,8 @@ struct hrg_batch {
   float* d_scratch_obs = nullptr;
   hrg_box_state* d_boxes = nullptr;   // the manipulation object of each env (PickPlaceHumanCart)
   hrg_stack_state* d_stacks = nullptr; // the four cubes of each env (CollaborativeStackingCart)
+  int32_t* d_order = nullptr;          // launch order of the step kernel (StepOrder): two orders of n_envs + two pairs of counters
+  int32_t parity = 0;                  // which of the two orders the next step launch reads
   int32_t task = HRG_TASK_REACH;
   bool timing = false;
   bool taps = false;
@@ -2450,6 +2462,12 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     HIPCHK_C(hipMalloc(&b->d_stacks, sizeof(hrg_stack_state) * (size_t)n_envs));
     HIPCHK_C(hipMemset(b->d_stacks, 0, sizeof(hrg_stack_state) * (size_t)n_envs));
   }
+  {
+    std::vector<int32_t> ord(2 * (size_t)n_envs + 4, 0);
+    for (int32_t e = 0; e < n_envs; e++) ord[e] = ord[(size_t)n_envs + e] = e;
+    HIPCHK_C(hipMalloc(&b->d_order, sizeof(int32_t) * ord.size()));
+    HIPCHK_C(hipMemcpy(b->d_order, ord.data(), sizeof(int32_t) * ord.size(), hipMemcpyHostToDevice));
+  }
 #undef HIPCHK_C
   *out = b;
   return HRG_OK;
@@ -2461,7 +2479,7 @@ void hrg_batch_destroy(hrg_batch* b) {
   hipDeviceSynchronize();
   for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks);
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks); hipFree(b->d_order);
   delete b;
 }
 
@@ -2495,22 +2513,24 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
+  const StepOrder ord{b->d_order, b->n_envs, b->parity};
   if (b->task == HRG_TASK_STACKING)
     hrg_stack_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                          b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_stacks);
+                          b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_stacks, ord);
   else if (b->task == HRG_TASK_LIFTING)
     hrg_lift_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, ord);
   else if (HRG_IS_HANDOVER(b->task))
     hrg_ho_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, ord);
   else if (b->task != HRG_TASK_REACH)
     hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes);
+                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, ord);
   else
     hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
-                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, b->n_envs);
+                       b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, b->n_envs, ord);
   HIPCHK(hipGetLastError());
+  b->parity ^= 1;
   if (b->timing) { HIPCHK(hipEventRecord(ev.second, st)); b->events.push_back(ev); }
   return HRG_OK;
 }
