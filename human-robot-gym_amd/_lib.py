@@ -22,7 +22,7 @@ EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
     "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box", "hrg_batch_get_states", "hrg_batch_set_states",
-    "hrg_batch_check_actions", "hrg_stack_bytes", "hrg_batch_get_stack", "hrg_batch_set_stack",
+    "hrg_batch_check_actions", "hrg_stack_bytes", "hrg_batch_get_stack", "hrg_batch_set_stack", "hrg_batch_launch_order",
 ]
 
 
@@ -78,6 +78,7 @@ def load_library():
     lib.hrg_batch_reset.argtypes = [vp, vp, vp, vp]
     lib.hrg_batch_step.argtypes = [vp] * 8
     lib.hrg_batch_contacts.argtypes = [vp, vp, vp]
+    lib.hrg_batch_launch_order.argtypes = [vp, vp, vp]
     lib.hrg_batch_capsules.argtypes = [vp, vp, vp, vp]
     lib.hrg_batch_get_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_state.argtypes = [vp, i32, vp, ctypes.c_size_t]
@@ -255,6 +256,14 @@ class HipBatch:
         ncon = np.zeros(self.n, np.int32)
         _check(self.lib, self.lib.hrg_batch_contacts(self.h, pairs.ctypes.data_as(ctypes.c_void_p), ncon.ctypes.data_as(ctypes.c_void_p)))
         return pairs, ncon
+
+    def launch_order(self):
+        """(order, n_busy): the env each workgroup of the next step launch will step, and how many of them -- from the front -- were busy in the last step."""
+        import numpy as np
+        order = np.zeros(self.n, np.int32)
+        nb = ctypes.c_int32(0)
+        _check(self.lib, self.lib.hrg_batch_launch_order(self.h, order.ctypes.data_as(ctypes.c_void_p), ctypes.byref(nb)))
+        return order, int(nb.value)
 
     def enable_taps(self, on=True):
         _check(self.lib, self.lib.hrg_batch_enable_taps(self.h, int(bool(on))))

@@ -2535,6 +2535,16 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
   return HRG_OK;
 }
 
+int hrg_batch_launch_order(hrg_batch* b, int32_t* order_host, int32_t* n_busy_host) {
+  if (!b || !order_host || !n_busy_host) return fail(HRG_ERR_INVALID, "null argument");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  const size_t n = (size_t)b->n_envs;
+  HIPCHK(hipMemcpy(order_host, b->d_order + (size_t)b->parity * n, sizeof(int32_t) * n, hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(n_busy_host, b->d_order + 2 * n + 2 * (size_t)b->parity, sizeof(int32_t), hipMemcpyDeviceToHost));   // the front counter that filled this order
+  return HRG_OK;
+}
+
 int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));

@@ -360,6 +360,10 @@ int hrg_batch_contacts(hrg_batch* b, int32_t* pairs_host, int32_t* ncon_host);
 /* reach capsules of the last shield cycle: robot double[n_envs][HRG_NSHIELD_RCAP][7],
  * human double[n_envs][HRG_NHCAP_MAX][7] (p1,p2,r), n_human int32[n_envs] */
 int hrg_batch_capsules(hrg_batch* b, double* robot_host, double* human_host, int32_t* n_human_host);
+/* launch order of the NEXT step (diagnostic; no reference counterpart): order_host int32[n_envs] = the env each workgroup will step, n_busy_host = how many of
+ * them (from the front) were busy in the last step -- robot contacts or a fail-safe manoeuvre.  The order never changes what an env computes, only when its wave starts
+ * (busy envs first: the step kernel ends with its slowest wave). */
+int hrg_batch_launch_order(hrg_batch* b, int32_t* order_host, int32_t* n_busy_host);
 /* the capsule taps cost ~4 KB of HBM writes per env per shield cycle, so they are off unless enabled here */
 int hrg_batch_enable_taps(hrg_batch* b, int32_t on);
 int hrg_batch_get_state(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);

@@ -279,3 +279,32 @@ def test_bench_gather_branch_in_process():
             B.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_launch_order_stays_a_permutation_with_the_busy_envs_in_front():
+    """The step kernel files every env into the next launch's order (busy envs from the front).  Whatever the order, it has to be a permutation of the batch,
+    and an env under a fail-safe manoeuvre has to start among the first."""
+    import torch
+    n = 512
+    clips = hrg.synthetic_clips(5, seed=0)
+    d = hrg.build_model_desc(dict(shield_type="SSM", horizon=60, seed=9), n_clips=clips.n_clips)
+    G = hrg.HipBatch(d, clips, n)
+    G.reset()
+    order, nb = G.launch_order()
+    assert np.array_equal(order, np.arange(n)) and nb == 0
+    gen = torch.Generator(device="cuda"); gen.manual_seed(3)
+    seen_busy = 0
+    for k in range(45):
+        a = torch.rand((n, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1
+        obs, rew, done, info = G.step(a)
+        if k % 9 == 8:
+            order, nb = G.launch_order()
+            assert np.array_equal(np.sort(order), np.arange(n)), "the launch order lost or duplicated an env"
+            assert 0 <= nb <= n
+            st, _ = G.get_states(np.arange(n))
+            unsafe = np.array([not s.is_safe for s in st]) & ~done.cpu().numpy().astype(bool)
+            front = np.zeros(n, bool); front[order[:nb]] = True
+            assert np.all(front[unsafe]), "an env under a fail-safe manoeuvre is not among the first to start"
+            seen_busy = max(seen_busy, nb)
+    assert seen_busy > 0          # random actions next to a moving human: some env brakes within 45 steps
+    G.close()
