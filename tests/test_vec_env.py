@@ -204,3 +204,16 @@ def test_lazy_info_dicts_behave_like_dicts():
     d["x"] = 5
     assert d["x"] == 5 and d["timeout"] is False and "collision_type" in repr(mk(0))
     assert [k for k in mk(1)][:2] == INFO_KEYS[:2]
+
+
+def test_every_observation_key_of_the_reference_configs_is_served():
+    """`obs_keys` / `expert_obs_keys` of every yaml under human_robot_gym/training/config (enumerated once with a yaml walk over the reference tree; the list is
+    spelled out here because the reference does not travel): each key must map to columns of the observation superset."""
+    from human_robot_gym_amd.vec_env import OBS_COLUMNS
+    used = ["dist_eef_to_human_head", "vec_eef_to_object", "vec_eef_to_target", "object_gripped", "robot0_gripper_qpos", "gripper_aperture",
+            "dist_eef_to_human_rh", "dist_eef_to_human_lh", "goal_difference", "board_quat", "vec_eef_to_human_lh", "vec_eef_to_human_rh",
+            "board_gripped", "vec_eef_to_all_objects", "object-state"]
+    od = hrg._cstruct.CONST["HRG_OBS_DIM"]
+    for k in used:
+        cols = list(OBS_COLUMNS[k])
+        assert cols and all(0 <= c < od for c in cols) and len(set(cols)) == len(cols), k

@@ -10,9 +10,9 @@ from human_robot_gym_amd import mixed  # noqa: E402
 from human_robot_gym_amd._lib import HipBatch  # noqa: E402
 
 n, steps = 4096, 600
-for env_id, shield in (("PickPlaceHumanCart", "SSM"), ("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL"),
-                       ("CollaborativeLiftingCart", "SSM")):
-    clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600)
+for env_id, shield in (("ReachHuman", "SSM"), ("PickPlaceHumanCart", "SSM"), ("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL"),
+                       ("CollaborativeLiftingCart", "SSM"), ("CollaborativeStackingCart", "SSM")):
+    clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600) if env_id != "ReachHuman" else hrg.synthetic_clips(5, seed=0)
     d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31), n_clips=clips.n_clips, env_id=env_id)
     G = HipBatch(d, clips, n)
     G.reset()
@@ -28,9 +28,18 @@ for env_id, shield in (("PickPlaceHumanCart", "SSM"), ("HumanObjectInspectionCar
             bad += int((~np.isfinite(o)).sum())
             z = o[:, 49]
             print(f"  {env_id} step {k}: object z min {z.min():.3f} max {z.max():.3f}; below table-5mm {(z < 0.8 + 0.02 - 5e-3).mean():.3f}; gripped {o[:, 39].mean():.3f}", flush=True)
-    st, bx = G.get_states(np.arange(0, n, 8))
-    ph = np.bincount([b.task_phase for b in bx], minlength=6)
-    qn = max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx)
-    print(f"{env_id}: crashes {crashes} dones {dones} positive rewards {wins} non-finite {bad} phases {ph.tolist()} weld_active {np.mean([b.weld_active for b in bx]):.3f} "
-          f"handed over {sum(b.n_handed_over for b in bx)} |quat|-1 {qn:.2e}", flush=True)
+    order, nb = G.launch_order()
+    perm_ok = bool(np.array_equal(np.sort(order), np.arange(n)))
+    if env_id == "CollaborativeStackingCart":
+        sks = [G.get_stack(e) for e in range(0, n, 8)]
+        ph = np.bincount([s_.task_phase for s_ in sks], minlength=6)
+        qn = max(abs(np.linalg.norm(list(s_.quat[c])) - 1) for s_ in sks for c in range(4))
+        print(f"{env_id}: crashes {crashes} dones {dones} positive rewards {wins} non-finite {bad} phases {ph.tolist()} max stack height {max(s_.max_stack_height for s_ in sks)} "
+              f"|quat|-1 {qn:.2e} launch order a permutation {perm_ok} busy {nb}", flush=True)
+    else:
+        st, bx = G.get_states(np.arange(0, n, 8))
+        ph = np.bincount([b.task_phase for b in bx], minlength=6)
+        qn = max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx) if env_id != "ReachHuman" else 0.0
+        print(f"{env_id}: crashes {crashes} dones {dones} positive rewards {wins} non-finite {bad} phases {ph.tolist()} weld_active {np.mean([b.weld_active for b in bx]):.3f} "
+              f"handed over {sum(b.n_handed_over for b in bx)} |quat|-1 {qn:.2e} launch order a permutation {perm_ok} busy {nb}", flush=True)
     G.close()
