@@ -797,6 +797,14 @@ DI double chain_prefix(double x, int lane) {
   y += dpp_f64<0x114, 0xf>(y);  // row_shr:4
   return lane < NARM ? y : y + x;
 }
+// a value of lane K (compile-time) in every lane: two v_readlane into SGPRs instead of an LDS-crossbar shuffle
+template <int K>
+DI double lane_value(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), K);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), K);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 // two independent factorisations in one pass (M and M + h D of a substep): the two dependency chains (rsqrt, shuffles) interleave
 DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* lb) {
   const int i = lane >> 3, j = lane & 7;
@@ -819,20 +827,29 @@ DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* 
 // solve with these matrices (unconstrained acceleration, the Newton direction while no row has curvature, the implicit-damping step) into one product per
 // lane and a three-step row reduction, instead of a 16-step dependent substitution chain on 8 lanes.  Pivots are the same Schur complements as the
 // Cholesky pivots: positive definiteness is checked on them.
+#define HRG_PIVOT(v, K) lane_value<(K) * 9>(v)   // the pivot is one lane's value: scalar broadcast, and the reciprocal starts without waiting for a shuffle (-0.7 %)
+template <int K>
+DI void inv_pivot(double& a, int i, int j, bool& good) {
+  const double akk = HRG_PIVOT(a, K);
+  if (!(akk > 0)) good = false;
+  const double pa = 1.0 / akk;
+  const double aik = __shfl(a, i * 8 + K, 64);
+  const double akj = __shfl(a, K * 8 + j, 64);
+  if (i == K) a = j == K ? pa : akj * pa;
+  else if (j == K) a = -aik * pa;
+  else a -= aik * akj * pa;
+}
 DI void spd_inverse2(double a, double b, int lane, bool* ok, double* ia, double* ib) {
   const int i = lane >> 3, j = lane & 7;
   bool good = true;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const double akk = __shfl(a, k * 9, 64), bkk = __shfl(b, k * 9, 64);
-    if (!(akk > 0) || !(bkk > 0)) good = false;
-    const double pa = 1.0 / akk, pb = 1.0 / bkk;
-    const double aik = __shfl(a, i * 8 + k, 64), bik = __shfl(b, i * 8 + k, 64);
-    const double akj = __shfl(a, k * 8 + j, 64), bkj = __shfl(b, k * 8 + j, 64);
-    if (i == k) { a = j == k ? pa : akj * pa; b = j == k ? pb : bkj * pb; }
-    else if (j == k) { a = -aik * pa; b = -bik * pb; }
-    else { a -= aik * akj * pa; b -= bik * bkj * pb; }
-  }
+  inv_pivot<0>(a, i, j, good); inv_pivot<0>(b, i, j, good);
+  inv_pivot<1>(a, i, j, good); inv_pivot<1>(b, i, j, good);
+  inv_pivot<2>(a, i, j, good); inv_pivot<2>(b, i, j, good);
+  inv_pivot<3>(a, i, j, good); inv_pivot<3>(b, i, j, good);
+  inv_pivot<4>(a, i, j, good); inv_pivot<4>(b, i, j, good);
+  inv_pivot<5>(a, i, j, good); inv_pivot<5>(b, i, j, good);
+  inv_pivot<6>(a, i, j, good); inv_pivot<6>(b, i, j, good);
+  inv_pivot<7>(a, i, j, good); inv_pivot<7>(b, i, j, good);
   *ok = good;
   *ia = a; *ib = b;
 }
@@ -840,38 +857,22 @@ DI void spd_inverse2(double a, double b, int lane, bool* ok, double* ia, double*
 DI double spd_inverse1(double a, int lane, bool* ok) {
   const int i = lane >> 3, j = lane & 7;
   bool good = true;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const double akk = __shfl(a, k * 9, 64);
-    if (!(akk > 0)) good = false;
-    const double pa = 1.0 / akk;
-    const double aik = __shfl(a, i * 8 + k, 64);
-    const double akj = __shfl(a, k * 8 + j, 64);
-    if (i == k) a = j == k ? pa : akj * pa;
-    else if (j == k) a = -aik * pa;
-    else a -= aik * akj * pa;
-  }
+  inv_pivot<0>(a, i, j, good); inv_pivot<1>(a, i, j, good); inv_pivot<2>(a, i, j, good); inv_pivot<3>(a, i, j, good);
+  inv_pivot<4>(a, i, j, good); inv_pivot<5>(a, i, j, good); inv_pivot<6>(a, i, j, good); inv_pivot<7>(a, i, j, good);
   *ok = good;
   return a;
 }
 // ... and for four matrices at once (the four cube blocks of the stacking task's Newton system): the four dependency chains interleave
+template <int K>
+DI void inv_pivot4(double* a, int i, int j, bool& good) {
+#pragma unroll
+  for (int q = 0; q < 4; q++) inv_pivot<K>(a[q], i, j, good);
+}
 DI void spd_inverse4(double* a, int lane, bool* ok) {
   const int i = lane >> 3, j = lane & 7;
   bool good = true;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    double akk[4], aik[4], akj[4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) { akk[q] = __shfl(a[q], k * 9, 64); aik[q] = __shfl(a[q], i * 8 + k, 64); akj[q] = __shfl(a[q], k * 8 + j, 64); }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      if (!(akk[q] > 0)) good = false;
-      const double pa = 1.0 / akk[q];
-      if (i == k) a[q] = j == k ? pa : akj[q] * pa;
-      else if (j == k) a[q] = -aik[q] * pa;
-      else a[q] -= aik[q] * akj[q] * pa;
-    }
-  }
+  inv_pivot4<0>(a, i, j, good); inv_pivot4<1>(a, i, j, good); inv_pivot4<2>(a, i, j, good); inv_pivot4<3>(a, i, j, good);
+  inv_pivot4<4>(a, i, j, good); inv_pivot4<5>(a, i, j, good); inv_pivot4<6>(a, i, j, good); inv_pivot4<7>(a, i, j, good);
   *ok = good;
 }
 // sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it
