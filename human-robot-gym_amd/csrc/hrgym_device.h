@@ -220,10 +220,7 @@ struct Lds {
   hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)
   double cR[NCUBE][9];                   // cube rotation matrices at the current substep
   double rcen[HRG_NRCAP][3];
-  Contact con[NCON_DYN];
-  double hbp[NVS * (NVS + 1) / 2 + NVS]; // Newton Hessian / Cholesky factor of the 32-DoF system, packed lower triangle + reciprocal diagonal
-#define HB(i, j) g_L.hbp[(i) * ((i) + 1) / 2 + (j)]
-#define HBI(k) g_L.hbp[NVS * (NVS + 1) / 2 + (k)]
+  Contact con[NCON_DYN];                 // (the coupled Newton system lives in registers: Tiles, hrgym_hip.hip)
 #elif HRG_BOX
   union {
     struct {  // collide -> classify / constraint-row set-up
@@ -862,6 +859,15 @@ DI double spd_inverse1(double a, int lane, bool* ok) {
   *ok = good;
   return a;
 }
+// a 6 x 6 block padded to the 8 x 8 lane layout with a unit diagonal: the two padded pivots would change nothing (pivot 1, zero row and column), so six sweeps
+DI double spd_inverse1_6(double a, int lane, bool* ok) {
+  const int i = lane >> 3, j = lane & 7;
+  bool good = true;
+  inv_pivot<0>(a, i, j, good); inv_pivot<1>(a, i, j, good); inv_pivot<2>(a, i, j, good); inv_pivot<3>(a, i, j, good);
+  inv_pivot<4>(a, i, j, good); inv_pivot<5>(a, i, j, good);
+  *ok = good;
+  return a;
+}
 // ... and for four matrices at once (the four cube blocks of the stacking task's Newton system): the four dependency chains interleave
 template <int K>
 DI void inv_pivot4(double* a, int i, int j, bool& good) {
@@ -872,7 +878,7 @@ DI void spd_inverse4(double* a, int lane, bool* ok) {
   const int i = lane >> 3, j = lane & 7;
   bool good = true;
   inv_pivot4<0>(a, i, j, good); inv_pivot4<1>(a, i, j, good); inv_pivot4<2>(a, i, j, good); inv_pivot4<3>(a, i, j, good);
-  inv_pivot4<4>(a, i, j, good); inv_pivot4<5>(a, i, j, good); inv_pivot4<6>(a, i, j, good); inv_pivot4<7>(a, i, j, good);
+  inv_pivot4<4>(a, i, j, good); inv_pivot4<5>(a, i, j, good);   // 6 x 6 blocks padded with a unit diagonal: the padded pivots are no-ops
   *ok = good;
 }
 // sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it

@@ -74,43 +74,36 @@ static_assert(NVS == 32, "entry (i, j) of the packed Hessian is decoded as (e >>
 struct SRow { bool active; int type, kind, dof; double sgn, D, floss, flim, aref, y, p; };   // kind: 0 joint row, 1 weld row, 2 contact row
 DI double cube_mdiag(ModelPtr dm, int i) { return ((i - NV) % 6) < 3 ? dm->m.box_mass : dm->m.box_inertia[0]; }
 
-// in-place Cholesky of rows / columns k0..NVS-1 of the packed Hessian (k0 = NV: the cube block alone, valid when the robot-cube coupling block is zero)
-DI bool chol_stack(int lane, int k0) {
-  Lds& L = g_L;
-#pragma unroll 1
-  for (int k = k0; k < NVS; k++) {
-    const double dkk = HB(k, k);
-    if (!(dkk > 0)) return false;
-    const double piv = sqrt(dkk);
-    wave_sync();
-    if (lane == k) { HB(k, k) = piv; HBI(k) = 1.0 / piv; }
-    else if (lane > k && lane < NVS) HB(lane, k) = HB(lane, k) / piv;
-    wave_sync();
-#pragma unroll 1
-    for (int t = (k + 1) >> 1; t < NVS / 2; t++) {   // lanes 0..31 hold row 2t, lanes 32..63 row 2t + 1
-      const int i = 2 * t + (lane >> 5), j = lane & 31;
-      if (j > k && j <= i) HB(i, j) = HB(i, j) - HB(i, k) * HB(j, k);
-    }
-    wave_sync();
-  }
-  return true;
+// The coupled Newton system in registers: 5 x 5 tiles of 8 x 8 -- tile row / column 0 = the robot tree, 1 + c = cube c (6 x 6, padded to 8 x 8 with a unit
+// diagonal) -- and lane (i, j) owns entry (i, j) of every tile.  Gauss-Jordan sweeps over the real pivots turn the tiles into the inverse in place (the lane-parallel
+// sweep of spd_inverse1, tile by tile): per pivot one scalar broadcast, one shuffle per tile row and tile column, one multiply-add per tile.  A0 = first tile that takes
+// part (1: no robot-cube contact, the robot block is inverted on its own).
+struct Tiles { double t[5][5]; };
+DI double lane_value_dyn(double v, int k) {   // k wave-uniform
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), k);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-DI double chol_stack_solve(double b, int lane, int k0) {
-  Lds& L = g_L;
-  double x = b;
+template <int A, int A0>
+DI void tiles_pivots(Tiles& T, int i, int j, int np, bool& good) {
 #pragma unroll 1
-  for (int k = k0; k < NVS; k++) {
-    const double xk = __shfl(x, k, 64) * HBI(k);
-    if (lane == k) x = xk;
-    else if (lane > k && lane < NVS) x -= HB(lane, k) * xk;
+  for (int P = 0; P < np; P++) {
+    const double akk = lane_value_dyn(T.t[A][A], P * 9);
+    if (!(akk > 0)) good = false;
+    const double pa = 1.0 / akk;
+    double col[5], row[5];
+#pragma unroll
+    for (int a = A0; a < 5; a++) { col[a] = __shfl(T.t[a][A], i * 8 + P, 64); row[a] = __shfl(T.t[A][a], P * 8 + j, 64); }
+#pragma unroll
+    for (int a = A0; a < 5; a++)
+#pragma unroll
+      for (int b = A0; b < 5; b++) {
+        const bool prow = a == A && i == P, pcol = b == A && j == P;
+        const double x = T.t[a][b];
+        T.t[a][b] = prow ? (pcol ? pa : row[b] * pa) : (pcol ? -col[a] * pa : x - col[a] * row[b] * pa);
+      }
   }
-#pragma unroll 1
-  for (int k = NVS - 1; k >= k0; k--) {
-    const double xk = __shfl(x, k, 64) * HBI(k);
-    if (lane == k) x = xk;
-    else if (lane < k && lane >= k0) x -= HB(k, lane) * xk;
-  }
-  return x;
 }
 
 PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
@@ -322,6 +315,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       wave_sync();
     }
     STAMP(22);
+    bool h_is_m = true;
+    double Hrob = Minv;   // inverse of the robot block of the Newton Hessian
 #pragma unroll 1
     for (int it = 0; it < m.solver_iters; it++) {
       COUNT(16, 1);
@@ -369,13 +364,20 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       STAMP(27);
       // ---- Newton Hessian: M + sum_r h_r J_r' J_r ----
       if (!coupled) {   // robot block in registers (lanes = (mi, mj)), as in the ReachHuman solver
-        double hval = Mij;
-        if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
+        // ... whose Hessian is M until a row on the robot tree has curvature (a joint row in its quadratic zone, a contact of a robot body): M^-1 is already held
+        bool rc = false;
+#pragma unroll
+        for (int k = 0; k < 2; k++) rc |= hh[k] != 0 && (R[k].kind == 0 || (R[k].kind == 2 && L.con_rob[(lane + 64 * k - SROW_CON0) >> 2]));
+        if (__any(rc) || !h_is_m) {
+          double hval = Mij;
+          if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
 #pragma unroll 4
-        for (int q = 0; q < 4 * nc; q++) hval += L.rh[SROW_CON0 + q] * L.Jc[q][mi] * L.Jc[q][mj];   // (zeros where the row has no robot part or no curvature)
-        const double Hinv_ = spd_inverse1(hval, lane, &ok);
-        if (!ok) break;
-        const double x = -matvec_lanes(Hinv_, L.g, lane);
+          for (int q = 0; q < 4 * nc; q++) hval += L.rh[SROW_CON0 + q] * L.Jc[q][mi] * L.Jc[q][mj];   // (zeros where the row has no robot part or no curvature)
+          Hrob = spd_inverse1(hval, lane, &ok);
+          if (!ok) break;
+          h_is_m = false;
+        }
+        const double x = -matvec_lanes(Hrob, L.g, lane);
         if (mj == 0) L.d[mi] = x;
       }
       if (blocks) {   // four independent cube blocks: 6x6 padded to the 8x8 lane layout with a unit diagonal, inverted together
@@ -408,53 +410,77 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         COUNT(18, 1);
         if (!good) break;
         STAMP(24);
-      } else {
-#pragma unroll 1
-      for (int t = coupled ? 0 : NV / 2; t < NVS / 2; t++) {   // block-diagonal part of the packed Hessian
-        const int i = 2 * t + (lane >> 5), j = lane & 31;
-        if (j <= i) {
-          double hv = 0;
-          if (i < NV) { hv = L.M[i * NV + j]; if (i == j) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; } }
-          else if (i == j) { hv = cube_mdiag(dm, i); const int cu = (i - NV) / 6; if (cu >= HRG_CUBE_L) hv += L.rh[SROW_WELD0 + (i - NV) - 6 * HRG_CUBE_L]; }
-          HB(i, j) = hv;
+      } else {   // a cube-cube or robot-cube contact couples the blocks: the whole system as tiles in registers
+        Tiles T;
+#pragma unroll
+        for (int a = 0; a < 5; a++)
+#pragma unroll
+          for (int b_ = 0; b_ < 5; b_++) T.t[a][b_] = 0.0;
+        if (coupled) {
+          double hval = Mij;
+          if (mi == mj) { hval += L.rh[mi]; hval += L.rh[NV + 2 * mi]; hval += L.rh[NV + 2 * mi + 1]; }
+          T.t[0][0] = hval;
         }
-      }
-      wave_sync();
-#pragma unroll 1
-      for (int c = 0; c < nc; c++) {   // contact c adds h J' J on its 20 local columns [robot 8 | cube of geom 1 | cube of geom 2]
-        const int ca = L.con_ca[c], cb = L.con_cb[c], rob = L.con_rob[c] && coupled;
-        if (ca < 0 && cb < 0) continue;   // robot-only contact: in the robot block above (uncoupled) ...
-        const double h0 = L.rh[SROW_CON0 + 4 * c], h1 = L.rh[SROW_CON0 + 4 * c + 1], h2 = L.rh[SROW_CON0 + 4 * c + 2], h3 = L.rh[SROW_CON0 + 4 * c + 3];
-        if (h0 == 0 && h1 == 0 && h2 == 0 && h3 == 0) continue;
-#pragma unroll 1
-        for (int e = lane; e < 400; e += 64) {
-          const int li = e / 20, lj = e - 20 * li;
-          if (lj > li) continue;
-          if ((li < 8 && !rob) || (lj < 8 && !rob)) continue;
-          if ((li >= 8 && li < 14 && ca < 0) || (lj >= 8 && lj < 14 && ca < 0) || (li >= 14 && cb < 0) || (lj >= 14 && cb < 0)) continue;
-          const int gi = li < 8 ? li : (li < 14 ? NV + 6 * ca + li - 8 : NV + 6 * cb + li - 14), gj = lj < 8 ? lj : (lj < 14 ? NV + 6 * ca + lj - 8 : NV + 6 * cb + lj - 14);
-          const double v = h0 * L.Jc[4 * c][li] * L.Jc[4 * c][lj] + h1 * L.Jc[4 * c + 1][li] * L.Jc[4 * c + 1][lj] + h2 * L.Jc[4 * c + 2][li] * L.Jc[4 * c + 2][lj] +
-                           h3 * L.Jc[4 * c + 3][li] * L.Jc[4 * c + 3][lj];
-          HB(gi, gj) = HB(gi, gj) + v;
+#pragma unroll
+        for (int cu = 0; cu < NCUBE; cu++) {
+          double v = mi == mj ? (mi < 6 ? cube_mdiag(dm, NV + mi) : 1.0) : 0.0;
+          if (mi == mj && mi < 6 && cu >= HRG_CUBE_L) v += L.rh[SROW_WELD0 + 6 * (cu - HRG_CUBE_L) + mi];
+          T.t[1 + cu][1 + cu] = v;
         }
-        wave_sync();
-      }
-      if (coupled) {   // ... or here, when the robot block is part of the packed system
 #pragma unroll 1
-        for (int c = 0; c < nc; c++) {
-          if (!(L.con_rob[c] && L.con_ca[c] < 0 && L.con_cb[c] < 0)) continue;
-          for (int d = 0; d < 4; d++) { const double hq = L.rh[SROW_CON0 + 4 * c + d]; if (hq != 0 && mj <= mi) HB(mi, mj) = HB(mi, mj) + hq * L.Jc[4 * c + d][mi] * L.Jc[4 * c + d][mj]; }
+        for (int c = 0; c < nc; c++) {   // contact c: h J' J on its columns [robot 8 | cube of geom 1 | cube of geom 2] (absent parts are stored as zeros)
+          const int ca = __builtin_amdgcn_readfirstlane(L.con_ca[c]), cb = __builtin_amdgcn_readfirstlane(L.con_cb[c]);
+          double Srr = 0, Sra = 0, Sar = 0, Srb = 0, Sbr = 0, Saa = 0, Sab = 0, Sba = 0, Sbb = 0;
+#pragma unroll
+          for (int d = 0; d < 4; d++) {
+            const double* Jr = L.Jc[4 * c + d];
+            const double hq = L.rh[SROW_CON0 + 4 * c + d];
+            const double ri = Jr[mi], rj = Jr[mj];
+            const double ai = mi < 6 ? Jr[8 + mi] : 0.0, aj = mj < 6 ? Jr[8 + mj] : 0.0, bi = mi < 6 ? Jr[14 + mi] : 0.0, bj = mj < 6 ? Jr[14 + mj] : 0.0;
+            Srr += hq * ri * rj; Sra += hq * ri * aj; Sar += hq * ai * rj; Srb += hq * ri * bj; Sbr += hq * bi * rj;
+            Saa += hq * ai * aj; Sab += hq * ai * bj; Sba += hq * bi * aj; Sbb += hq * bi * bj;
+          }
+          if (coupled) T.t[0][0] += Srr;
+#pragma unroll
+          for (int a = 0; a < NCUBE; a++) {   // ca, cb are wave-uniform: scalar branches, the tile indices stay compile-time
+            if (ca == a) {
+              T.t[1 + a][1 + a] += Saa;
+              if (coupled) { T.t[0][1 + a] += Sra; T.t[1 + a][0] += Sar; }
+#pragma unroll
+              for (int b_ = 0; b_ < NCUBE; b_++) if (cb == b_) { T.t[1 + a][1 + b_] += Sab; T.t[1 + b_][1 + a] += Sba; }
+            }
+            if (cb == a) {
+              T.t[1 + a][1 + a] += Sbb;
+              if (coupled) { T.t[0][1 + a] += Srb; T.t[1 + a][0] += Sbr; }
+            }
+          }
         }
-        wave_sync();
-      }
-      STAMP(23);
-      COUNT(18, 1);
-      if (!chol_stack(lane, coupled ? 0 : NV)) break;
-      STAMP(24);
-      {
-        const double x = chol_stack_solve((coupled ? lane < NVS : (lane >= NV && lane < NVS)) ? -L.g[lane] : 0.0, lane, coupled ? 0 : NV);
-        if (coupled ? lane < NVS : (lane >= NV && lane < NVS)) L.d[lane] = x;
-      }
+        STAMP(23);
+        COUNT(18, 1);
+        bool good = true;
+        if (coupled) {
+          tiles_pivots<0, 0>(T, mi, mj, 8, good);
+          tiles_pivots<1, 0>(T, mi, mj, 6, good); tiles_pivots<2, 0>(T, mi, mj, 6, good); tiles_pivots<3, 0>(T, mi, mj, 6, good); tiles_pivots<4, 0>(T, mi, mj, 6, good);
+        } else {
+          tiles_pivots<1, 1>(T, mi, mj, 6, good); tiles_pivots<2, 1>(T, mi, mj, 6, good); tiles_pivots<3, 1>(T, mi, mj, 6, good); tiles_pivots<4, 1>(T, mi, mj, 6, good);
+        }
+        if (!good) break;
+        STAMP(24);
+        {   // direction d = -H^-1 g, one tile row at a time
+          double gb[5];
+          gb[0] = L.g[mj];
+#pragma unroll
+          for (int cu = 0; cu < NCUBE; cu++) gb[1 + cu] = mj < 6 ? L.g[NV + 6 * cu + mj] : 0.0;
+#pragma unroll
+          for (int a = 0; a < 5; a++) {
+            if (a == 0 && !coupled) continue;   // the robot block's direction was written above
+            double acc = 0;
+#pragma unroll
+            for (int b_ = 0; b_ < 5; b_++) if (b_ > 0 || coupled) acc += T.t[a][b_] * gb[b_];
+            const double x = -row8_sum(acc);
+            if (mj == 0 && (a == 0 || mi < 6)) L.d[a == 0 ? mi : NV + 6 * (a - 1) + mi] = x;
+          }
+        }
       }
       wave_sync();
 #pragma unroll
@@ -853,7 +879,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
           h_is_m = false;
         }
         // cube block: 6x6 padded to the 8x8 lane layout with a unit diagonal
-        const double Sinv = spd_inverse1(sval, lane, &ok);
+        const double Sinv = spd_inverse1_6(sval, lane, &ok);
         if (!ok) break;
         STAMP(24);
         wave_sync();
@@ -2253,7 +2279,20 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
   if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
   return 0;
 }
-#if !HRG_BOX && !HRG_STACK
+#if HRG_STACK
+#define hrg_debug_envacc hrg_debug_envacc_stack
+#define hrg_debug_envcyc hrg_debug_envcyc_stack
+#elif HRG_HANDOVER
+#define hrg_debug_envacc hrg_debug_envacc_ho
+#define hrg_debug_envcyc hrg_debug_envcyc_ho
+#elif HRG_LIFT
+#define hrg_debug_envacc hrg_debug_envacc_lift
+#define hrg_debug_envcyc hrg_debug_envcyc_lift
+#elif HRG_BOX
+#define hrg_debug_envacc hrg_debug_envacc_box
+#define hrg_debug_envcyc hrg_debug_envcyc_box
+#endif
+#if 1
 extern "C" int hrg_debug_envacc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envacc), sizeof(unsigned long long) * 32 * n) == hipSuccess ? 0 : -1; }
 extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envcyc), sizeof(unsigned long long) * 3 * n) == hipSuccess ? 0 : -1; }
 #endif
