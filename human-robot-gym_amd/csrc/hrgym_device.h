@@ -222,17 +222,8 @@ struct Lds {
   double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];                 // (the coupled Newton system lives in registers: Tiles, hrgym_hip.hip)
 #elif HRG_BOX
-  union {
-    struct {  // collide -> classify / constraint-row set-up
-      double rcen[HRG_NRCAP][3];
-      Contact con[NCON_DYN];
-    };
-    // after the row set-up: Newton Hessian / Cholesky factor of the coupled 14-DoF system, packed lower triangle + reciprocal
-    // diagonal (the uncoupled fast path keeps the 8x8-padded factor of the cube block in its first 72 doubles)
-    double hbp[NVT * (NVT + 1) / 2 + NVT];
-  };
-#define HB(i, j) g_L.hbp[(i) * ((i) + 1) / 2 + (j)]
-#define HBI(k) g_L.hbp[NVT * (NVT + 1) / 2 + (k)]
+  double rcen[HRG_NRCAP][3];             // collide -> classify / constraint-row set-up
+  Contact con[NCON_DYN];                 // (the coupled 14-DoF Newton system lives in registers: Tiles<2>)
 #else
   double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];
@@ -881,6 +872,37 @@ DI void spd_inverse4(double* a, int lane, bool* ok) {
   inv_pivot4<4>(a, i, j, good); inv_pivot4<5>(a, i, j, good);   // 6 x 6 blocks padded with a unit diagonal: the padded pivots are no-ops
   *ok = good;
 }
+// A coupled Newton system in registers: N x N tiles of 8 x 8 -- tile row / column 0 = the robot tree, the others = free bodies (6 x 6, padded to 8 x 8 with a unit
+// diagonal) -- and lane (i, j) owns entry (i, j) of every tile.  Gauss-Jordan sweeps over the real pivots turn the tiles into the inverse in place (the lane-parallel
+// sweep of spd_inverse1, tile by tile): per pivot one scalar broadcast, one shuffle per tile row and tile column, one multiply-add per tile.  A = the tile row the
+// pivots are in, np = how many (8 robot DoF, 6 of a free body), A0 = first tile that takes part (1: the robot block is inverted on its own).
+template <int N> struct Tiles { double t[N][N]; };
+DI double lane_value_dyn(double v, int k) {   // k wave-uniform
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), k);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+template <int N, int A, int A0>
+DI void tiles_pivots(Tiles<N>& T, int i, int j, int np, bool& good) {
+#pragma unroll 1
+  for (int P = 0; P < np; P++) {
+    const double akk = lane_value_dyn(T.t[A][A], P * 9);
+    if (!(akk > 0)) good = false;
+    const double pa = 1.0 / akk;
+    double col[N], row[N];
+#pragma unroll
+    for (int a = A0; a < N; a++) { col[a] = __shfl(T.t[a][A], i * 8 + P, 64); row[a] = __shfl(T.t[A][a], P * 8 + j, 64); }
+#pragma unroll
+    for (int a = A0; a < N; a++)
+#pragma unroll
+      for (int b = A0; b < N; b++) {
+        const bool prow = a == A && i == P, pcol = b == A && j == P;
+        const double x = T.t[a][b];
+        T.t[a][b] = prow ? (pcol ? pa : row[b] * pa) : (pcol ? -col[a] * pa : x - col[a] * row[b] * pa);
+      }
+  }
+}
 // sum over each group of 8 consecutive lanes (one matrix row in the (i,j) lane layout) on the DPP network; every lane of the group receives it
 DI double row8_sum(double v) {
   v += dpp_f64<0xB1, 0xf>(v);    // quad_perm [1,0,3,2]
@@ -895,57 +917,6 @@ DI void chol_store(double l, int lane, double* Lm, double* invd) {
   Lm[lane] = l;
   if ((lane >> 3) == (lane & 7)) invd[lane & 7] = 1.0 / l;
 }
-#if HRG_BOX
-// Cholesky of the 14x14 Newton Hessian held packed in g_L.hbp (lower triangle, in place; HBI(k) receives 1 / L_kk).
-// Right-looking: the pivot column is scaled by lanes = rows, the trailing update runs over lanes = (i, j) entries (4 per
-// lane).  Same subtraction order per entry as a left-looking scalar factorisation.
-DI bool chol_box(int lane) {
-  Lds& L = g_L;
-  int ei[4], ej[4];
-#pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int e = lane + 64 * t;
-    ei[t] = e < NVT * NVT ? e / NVT : -1;
-    ej[t] = e - (e / NVT) * NVT;
-  }
-#pragma unroll 1
-  for (int k = 0; k < NVT; k++) {
-    const double dkk = HB(k, k);
-    if (!(dkk > 0)) return false;
-    const double piv = sqrt(dkk);
-    wave_sync();
-    if (lane == k) { HB(k, k) = piv; HBI(k) = 1.0 / piv; }
-    else if (lane > k && lane < NVT) HB(lane, k) = HB(lane, k) / piv;
-    wave_sync();
-#pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int i = ei[t], j = ej[t];
-      if (i >= 0 && j > k && j <= i) HB(i, j) = HB(i, j) - HB(i, k) * HB(j, k);
-    }
-    wave_sync();
-  }
-  return true;
-}
-// solve with that factor; x_i lives in lane i (< 14)
-DI double chol_box_solve(double b, int lane) {
-  Lds& L = g_L;
-  double x = b;
-#pragma unroll 1
-  for (int k = 0; k < NVT; k++) {
-    const double xk = __shfl(x, k, 64) * HBI(k);
-    if (lane == k) x = xk;
-    else if (lane > k && lane < NVT) x -= HB(lane, k) * xk;
-  }
-#pragma unroll 1
-  for (int k = NVT - 1; k >= 0; k--) {
-    const double xk = __shfl(x, k, 64) * HBI(k);
-    if (lane == k) x = xk;
-    else if (lane < k) x -= HB(k, lane) * xk;
-  }
-  return x;
-}
-#endif
-
 // solve L L' x = b with x_i living in lane i (< 8): column-oriented substitution, the pivot value is broadcast
 // with a scalar readlane, the column of the factor comes from LDS.  Register footprint: one double.
 DI double chol_solve_lanes(const double* Lm, const double* invd, double b, int lane) {

@@ -74,38 +74,6 @@ static_assert(NVS == 32, "entry (i, j) of the packed Hessian is decoded as (e >>
 struct SRow { bool active; int type, kind, dof; double sgn, D, floss, flim, aref, y, p; };   // kind: 0 joint row, 1 weld row, 2 contact row
 DI double cube_mdiag(ModelPtr dm, int i) { return ((i - NV) % 6) < 3 ? dm->m.box_mass : dm->m.box_inertia[0]; }
 
-// The coupled Newton system in registers: 5 x 5 tiles of 8 x 8 -- tile row / column 0 = the robot tree, 1 + c = cube c (6 x 6, padded to 8 x 8 with a unit
-// diagonal) -- and lane (i, j) owns entry (i, j) of every tile.  Gauss-Jordan sweeps over the real pivots turn the tiles into the inverse in place (the lane-parallel
-// sweep of spd_inverse1, tile by tile): per pivot one scalar broadcast, one shuffle per tile row and tile column, one multiply-add per tile.  A0 = first tile that takes
-// part (1: no robot-cube contact, the robot block is inverted on its own).
-struct Tiles { double t[5][5]; };
-DI double lane_value_dyn(double v, int k) {   // k wave-uniform
-  const long long b = __double_as_longlong(v);
-  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), k);
-  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), k);
-  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
-}
-template <int A, int A0>
-DI void tiles_pivots(Tiles& T, int i, int j, int np, bool& good) {
-#pragma unroll 1
-  for (int P = 0; P < np; P++) {
-    const double akk = lane_value_dyn(T.t[A][A], P * 9);
-    if (!(akk > 0)) good = false;
-    const double pa = 1.0 / akk;
-    double col[5], row[5];
-#pragma unroll
-    for (int a = A0; a < 5; a++) { col[a] = __shfl(T.t[a][A], i * 8 + P, 64); row[a] = __shfl(T.t[A][a], P * 8 + j, 64); }
-#pragma unroll
-    for (int a = A0; a < 5; a++)
-#pragma unroll
-      for (int b = A0; b < 5; b++) {
-        const bool prow = a == A && i == P, pcol = b == A && j == P;
-        const double x = T.t[a][b];
-        T.t[a][b] = prow ? (pcol ? pa : row[b] * pa) : (pcol ? -col[a] * pa : x - col[a] * row[b] * pa);
-      }
-  }
-}
-
 PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -411,7 +379,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         if (!good) break;
         STAMP(24);
       } else {   // a cube-cube or robot-cube contact couples the blocks: the whole system as tiles in registers
-        Tiles T;
+        Tiles<5> T;
 #pragma unroll
         for (int a = 0; a < 5; a++)
 #pragma unroll
@@ -459,10 +427,10 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         COUNT(18, 1);
         bool good = true;
         if (coupled) {
-          tiles_pivots<0, 0>(T, mi, mj, 8, good);
-          tiles_pivots<1, 0>(T, mi, mj, 6, good); tiles_pivots<2, 0>(T, mi, mj, 6, good); tiles_pivots<3, 0>(T, mi, mj, 6, good); tiles_pivots<4, 0>(T, mi, mj, 6, good);
+          tiles_pivots<5, 0, 0>(T, mi, mj, 8, good);
+          tiles_pivots<5, 1, 0>(T, mi, mj, 6, good); tiles_pivots<5, 2, 0>(T, mi, mj, 6, good); tiles_pivots<5, 3, 0>(T, mi, mj, 6, good); tiles_pivots<5, 4, 0>(T, mi, mj, 6, good);
         } else {
-          tiles_pivots<1, 1>(T, mi, mj, 6, good); tiles_pivots<2, 1>(T, mi, mj, 6, good); tiles_pivots<3, 1>(T, mi, mj, 6, good); tiles_pivots<4, 1>(T, mi, mj, 6, good);
+          tiles_pivots<5, 1, 1>(T, mi, mj, 6, good); tiles_pivots<5, 2, 1>(T, mi, mj, 6, good); tiles_pivots<5, 3, 1>(T, mi, mj, 6, good); tiles_pivots<5, 4, 1>(T, mi, mj, 6, good);
         }
         if (!good) break;
         STAMP(24);
@@ -887,30 +855,46 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         const double x2 = -row8_sum(Sinv * (mj < HRG_NBOXV ? L.g[NV + mj] : 0.0));
         if (mj == 0) { L.d[mi] = x1; if (mi < HRG_NBOXV) L.d[NV + mi] = x2; }
       } else {
-      // Hessian of the coupled 14-DoF system into LDS: lanes = (i, j) entries, 4 per lane
-#pragma unroll 1
-      for (int e = lane; e < NVT * NVT; e += 64) {
-        const int i = e / NVT, j = e - i * NVT;
-        double hv = (i < NV && j < NV) ? L.M[i * NV + j] : (i == j && i < NV + 3 ? m.box_mass : 0.0);
-        if (i >= NV + 3 && j >= NV + 3) hv = L.bMr[3 * (i - NV - 3) + (j - NV - 3)];
-        if (i == j && i < NV) { hv += L.rh[i]; hv += L.rh[NV + 2 * i]; hv += L.rh[NV + 2 * i + 1]; }
+      // a robot-cube contact (lifting: the grip) couples the blocks: the 14-DoF Newton system as 2 x 2 register tiles (robot tree | cube, 6 x 6 padded with a unit
+      // diagonal), lane (mi, mj) owns entry (mi, mj) of each; inverted in place by Gauss-Jordan sweeps over the 14 real pivots
+      Tiles<2> T;
+      {
+        double t00 = Mij;
+        if (mi == mj) { t00 += L.rh[mi]; t00 += L.rh[NV + 2 * mi]; t00 += L.rh[NV + 2 * mi + 1]; }
+        double t11 = mi == mj ? (mi < 3 ? m.box_mass : 1.0) : 0.0;
+        if (mi >= 3 && mi < HRG_NBOXV && mj >= 3 && mj < HRG_NBOXV) t11 = L.bMr[3 * (mi - 3) + (mj - 3)];
 #if HRG_HANDOVER
-        if (i == j && i >= NV) hv += L.rh[ROW_WELD0 + i - NV];
+        if (mi == mj && mi < HRG_NBOXV) t11 += L.rh[ROW_WELD0 + mi];
 #endif
-        for (uint64_t mm = cmask; mm;) {
-          const int q = __ffsll((long long)mm) - 1; mm &= mm - 1;
-          const double hq = L.rh[ROW_CON0 + q];
-          if (hq != 0) hv += hq * L.Jc[q][i] * L.Jc[q][j];
+        double t01 = 0, t10 = 0;
+        const bool ci = mi < HRG_NBOXV, cj = mj < HRG_NBOXV;
+        const int bi_ = NV + (ci ? mi : 0), bj_ = NV + (cj ? mj : 0);
+#pragma unroll 4
+        for (int q = 0; q < nq; q++) {
+          const double hq = L.rh[ROW_CON0 + q], ri = L.Jc[q][mi], rj = L.Jc[q][mj], bi = ci ? L.Jc[q][bi_] : 0.0, bj = cj ? L.Jc[q][bj_] : 0.0;
+          t00 += hq * ri * rj; t01 += hq * ri * bj; t10 += hq * bi * rj; t11 += hq * bi * bj;
         }
-        if (j <= i) HB(i, j) = hv;
+#if HRG_LIFT
+        for (uint64_t mm = wmask; mm;) {   // the connect rows (cube part only)
+          const int q = __ffsll((long long)mm) - 1 + ROW_WELD0 - ROW_CON0; mm &= mm - 1;
+          const double hq = L.rh[ROW_CON0 + q], bi = ci ? L.Jc[q][bi_] : 0.0, bj = cj ? L.Jc[q][bj_] : 0.0;
+          t11 += hq * bi * bj;
+        }
+#endif
+        T.t[0][0] = t00; T.t[0][1] = t01; T.t[1][0] = t10; T.t[1][1] = t11;
       }
-      wave_sync();
       STAMP(23);
-      if (!chol_box(lane)) break;
+      {
+        bool good = true;
+        tiles_pivots<2, 0, 0>(T, mi, mj, NV, good);
+        tiles_pivots<2, 1, 0>(T, mi, mj, HRG_NBOXV, good);
+        if (!good) break;
+      }
       STAMP(24);
       {
-        const double x = chol_box_solve(lane < NVT ? -L.g[lane] : 0.0, lane);
-        if (lane < NVT) L.d[lane] = x;
+        const double g0 = L.g[mj], g1 = mj < HRG_NBOXV ? L.g[NV + mj] : 0.0;
+        const double x0 = -row8_sum(T.t[0][0] * g0 + T.t[0][1] * g1), x1 = -row8_sum(T.t[1][0] * g0 + T.t[1][1] * g1);
+        if (mj == 0) { L.d[mi] = x0; if (mi < HRG_NBOXV) L.d[NV + mi] = x1; }
       }
       }
       wave_sync();
