@@ -77,6 +77,7 @@ Path = _STRUCTS["hrg_path"]
 EnvState = _STRUCTS["hrg_env_state"]
 BoxState = _STRUCTS["hrg_box_state"]
 StackState = _STRUCTS["hrg_stack_state"]
+HammerState = _STRUCTS["hrg_hammer_state"]
 
 
 def struct_to_dict(s):

@@ -124,7 +124,7 @@ def _quat_xyzw_to_mat(q):
     return R
 
 
-def hand_sites(frames, info):
+def hand_sites(frames, info, with_rot=False):
     """World positions of the L_Hand / R_Hand sites for every frame [n, FRAME_DIM] of a clip placed by `info` (no per-episode offsets):
     the pose chain of HumanEnv._control_human (human_env.py:1736-1763) and the tree of human.xml, vectorised over frames.  Host-side
     helper for shaping synthetic clips; the steppers have their own kinematics."""
@@ -143,16 +143,19 @@ def hand_sites(frames, info):
         R[b] = R[par] @ _rot(2, q[:, 0]) @ _rot(1, q[:, 1]) @ _rot(0, q[:, 2])      # z, y, x
         p[b] = p[par] + R[par] @ anc - R[b] @ anc
     names = [b["name"] for b in bodies]
-    out = []
+    out, rot = [], []
     for nm in ("L_Hand", "R_Hand"):
         b = names.index(nm)
-        out.append(p[b] + R[b] @ np.asarray(bodies[b]["anchor"], float))
+        out.append(p[b] + np.einsum("nij,j->ni", R[b], np.asarray(bodies[b]["anchor"], float)))
+        rot.append(R[b])
     assert out[0].shape == (n, 3)
+    if with_rot:
+        return out[0], out[1], rot[0], rot[1]
     return out[0], out[1]
 
 
 def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=120.0, stand_off=1.2, inspection=False, handover=False, lifting=None, lift_height=0.7,
-                    choreographed=False, stacking=False):
+                    choreographed=False, stacking=False, hammering=None):
     """Band-limited random joint motion (sigma 0.3 rad, 2 Hz cut-off, clipped to +-1.56) and a slow pelvis
     random walk within +-0.3 m around a standing pose, in the BVH (Y-up) frame the reference clips use."""
     rng = np.random.RandomState(seed)
@@ -169,6 +172,7 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
             a *= sigma / np.sqrt(0.5 * np.sum(a * a) + 1e-12)
             return (a[:, None] * np.sin(2 * np.pi * f[:, None] * t[None, :] + ph[:, None])).sum(0)
 
+        rigid = lifting is not None or hammering is not None
         anim = {}
         anim["Pelvis_pos_x"] = np.clip(band(0.15, 0.3), -0.3, 0.3)
         anim["Pelvis_pos_y"] = 1.0 + np.clip(band(0.01, 1.0), -0.03, 0.03)
@@ -176,11 +180,11 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
         yaw = band(0.4, 0.2)
         anim["Pelvis_quat"] = np.stack([np.zeros(n), np.sin(yaw / 2), np.zeros(n), np.cos(yaw / 2)], 1)  # about Y (up)
         for name in order:
-            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else (0.0 if lifting is not None else 0.3)  # convert_bvh.py:55-72 None joints (lifting: a rigid posture, the motion is the pelvis track)
+            sigma = 0.0 if name.split("_")[-2] in ("Spine", "Toe", "Hand") else (0.0 if rigid else 0.3)  # convert_bvh.py:55-72 None joints (lifting / hammering: a rigid posture, the motion is the pelvis track)
             mean = {"L_Shoulder_z": -1.1, "R_Shoulder_z": 1.1}.get(name, 0.0)  # arms hang down instead of the T-pose
-            if lifting is not None:  # ... and a little closer: the hands half a metre apart, like the board's grips
+            if rigid:  # ... and a little closer: the hands half a metre apart, like the board's grips
                 mean = {"L_Shoulder_z": -1.43, "R_Shoulder_z": 1.43}.get(name, 0.0)
-            anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.full(n, mean if lifting is not None else 0.0)
+            anim[name] = np.clip(mean + band(sigma, 2.0), -1.56, 1.56) if sigma > 0 else np.full(n, mean if rigid else 0.0)
         # the clip's info file places the human at the table edge in front of the robot: BVH +z maps to world +x
         # under human_base_quat (human_env.py:373), so 1.2 m along z = 1.2 m in front of the robot base
         info = {"position_offset": [0.0, 0.0, stand_off], "orientation_quat": [0.0, 0.0, 0.0, 1.0], "scale": 1.0}
@@ -194,6 +198,32 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
             info.update(keyframes=[int(0.3 * n), int(0.6 * n)], object_holding_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(present=[15.0, 5.0], wait=[12.0]), loop_speeds=dict(present=[1.0, 0.5], wait=[0.8]),
                         loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+        if hammering is not None:
+            # stand-in for the CollaborativeHammering/* recordings and info files: the board is presented from 30 % on, idle loop around the middle of the
+            # keyframes.  `hammering` = world position of the middle between the hands while the board is presented; a rigid posture turned HAMMERING_YAW
+            # about the vertical, so that the line between the hands matches the line between the board's two grips (the left one 0.4 m closer to
+            # the robot); the human comes 0.4 m closer during the approach and steps back after the second keyframe
+            info.update(keyframes=[int(0.3 * n), int(0.6 * n)], loop_amplitudes=[15.0, 5.0], loop_speeds=[1.0, 0.5], loop_amplitude_std_factor=1.1, loop_speed_std_factor=1.1)
+            anim["Pelvis_quat"] = np.tile(np.array([0.0, np.sin(HAMMERING_YAW / 2), 0.0, np.cos(HAMMERING_YAW / 2)]), (n, 1))
+            F = np.zeros((n, FRAME_DIM))
+            F[:, 0], F[:, 1], F[:, 2] = anim["Pelvis_pos_x"], anim["Pelvis_pos_y"], anim["Pelvis_pos_z"]
+            F[:, 3:7] = anim["Pelvis_quat"]
+            for k, name in enumerate(order):
+                F[:, 7 + k] = anim[name]
+            lh, rh = hand_sites(F, info)
+            k0, k1 = info["keyframes"]
+            f = np.arange(n, dtype=float)
+            up = np.clip(f / max(k0, 1.0), 0.0, 1.0)
+            down = np.clip((f - k1) / max(0.5 * (n - k1), 1.0), 0.0, 1.0)
+            w = (up * up * (3 - 2 * up)) * (1 - down * down * (3 - 2 * down))
+            u = t / t[-1]
+            sway = 0.02 * np.sin(2 * np.pi * u * rng.uniform(0.5, 1.5))
+            want = np.asarray(hammering, float)[None, :] + np.stack([0.4 * (1 - w), sway, 0.0 * u], 1)
+            Rb = _quat_xyzw_to_mat(np.array([0.5, 0.5, 0.5, 0.5])) @ _quat_xyzw_to_mat(np.asarray(info["orientation_quat"], float))
+            shift = (want - 0.5 * (lh + rh)) @ Rb
+            anim["Pelvis_pos_x"] = anim["Pelvis_pos_x"] + shift[:, 0]
+            anim["Pelvis_pos_y"] = anim["Pelvis_pos_y"] + shift[:, 1]
+            anim["Pelvis_pos_z"] = anim["Pelvis_pos_z"] + shift[:, 2]
         if stacking:   # stand-in for the CollaborativeStacking/* info files: keyframes at 15 / 25 / 35 / 55 / 65 % of the clip, alternating first hand, two waiting loops
             info.update(keyframes=[int(f * n) for f in (0.15, 0.25, 0.35, 0.55, 0.65)], first_placing_hand="left" if len(clips) % 2 else "right",
                         loop_amplitudes=dict(wait_for_second=[15.0, 5.0], wait_for_fourth=[12.0]), loop_speeds=dict(wait_for_second=[1.0, 0.5], wait_for_fourth=[0.8]),
@@ -240,6 +270,34 @@ def synthetic_clips(n_clips=13, seed=0, min_frames=1200, max_frames=3000, fps=12
             anim["Pelvis_pos_z"] = anim["Pelvis_pos_z"] + shift[:, 2]
         clips.append((anim, info))
     return ClipSet(clips)
+
+
+HAMMERING_YAW = np.pi * 0.75        # turn of the synthetic hammering human about the vertical (BVH y axis)
+HAMMERING_HANDS = (1.05, 0.0, 1.05)  # middle between the hands while the board is presented: the nail area lies 0.3 - 0.7 m in front of the robot base, 0.25 m above the table
+
+
+def hammering_relquat(anchors=((-0.1, 0.2, 0.0), (-0.5, -0.2, 0.0))):
+    """Relative pose quaternion (w, x, y, z) of the right-hand weld of CollaborativeHammeringCart for which the SYNTHETIC human of
+    `synthetic_clips(hammering=...)` holds the board level: q_mocap = q_board o q_rel with the mocap frame = right-hand body turned +90 deg about y
+    (collaborative_hammering_cartesian_env.py:688-715) and the board yawed so that its two grips lie on the line between the hands.  The reference's
+    value (0, 0, 0, 1) belongs to the recorded clips' hand orientations, which are absent."""
+    order = _qpos_joint_order()
+    F = np.zeros((1, FRAME_DIM))
+    F[0, 1] = 1.0
+    F[0, 3:7] = [0.0, np.sin(HAMMERING_YAW / 2), 0.0, np.cos(HAMMERING_YAW / 2)]
+    for k, name in enumerate(order):
+        F[0, 7 + k] = {"L_Shoulder_z": -1.43, "R_Shoulder_z": 1.43}.get(name, 0.0)
+    info = {"position_offset": [0.0, 0.0, 1.2], "orientation_quat": [0.0, 0.0, 0.0, 1.0]}
+    lh, rh, _, Rr = hand_sites(F, info, with_rot=True)
+    v = (lh - rh)[0]
+    a = np.asarray(anchors[0], float) - np.asarray(anchors[1], float)
+    th = np.arctan2(v[1], v[0]) - np.arctan2(a[1], a[0])
+    Rboard = np.array([[np.cos(th), -np.sin(th), 0.0], [np.sin(th), np.cos(th), 0.0], [0.0, 0.0, 1.0]])
+    Ry = np.array([[0.0, 0.0, 1.0], [0.0, 1.0, 0.0], [-1.0, 0.0, 0.0]])       # +90 deg about y
+    Rrel = Rboard.T @ (Rr[0] @ Ry)
+    w = 0.5 * np.sqrt(max(1.0 + np.trace(Rrel), 1e-12))
+    q = np.array([w, (Rrel[2, 1] - Rrel[1, 2]) / (4 * w), (Rrel[0, 2] - Rrel[2, 0]) / (4 * w), (Rrel[1, 0] - Rrel[0, 1]) / (4 * w)])
+    return (q / np.linalg.norm(q)).tolist()
 
 
 def lifting_hands_nominal(desc):

@@ -29,11 +29,23 @@ _STEP_MS = {"CollaborativeStackingCart": 10.65, "RobotHumanHandoverCart": 6.13, 
 def task_clips(env_id, n_clips=13, seed=0, **kw):
     """Synthetic clip set carrying the animation info `env_id` reads."""
     extra = {"HumanObjectInspectionCart": dict(inspection=True), "HumanRobotHandoverCart": dict(handover=True),
-             "RobotHumanHandoverCart": dict(handover="r2h"), "CollaborativeStackingCart": dict(stacking=True)}.get(env_id, {})
+             "RobotHumanHandoverCart": dict(handover="r2h"), "CollaborativeStackingCart": dict(stacking=True),
+             }.get(env_id, {})
+    if env_id == "CollaborativeHammeringCart":
+        from .animation import HAMMERING_HANDS
+        extra = dict(hammering=HAMMERING_HANDS)
     if env_id == "CollaborativeLiftingCart":
         from .animation import lifting_hands_nominal
         extra = dict(lifting=lifting_hands_nominal(build_model_desc(None, env_id=env_id)), fps=20.0)
     return synthetic_clips(n_clips, seed=seed, **extra, **kw)
+
+
+def task_env_kwargs(env_id):
+    """Environment keyword arguments that go with the synthetic clips of `task_clips` (the reference's defaults belong to its recorded clips)."""
+    if env_id == "CollaborativeHammeringCart":
+        from .animation import hammering_relquat
+        return dict(hammer_weld_relquat=hammering_relquat())
+    return {}
 
 
 def split_evenly(n_envs, n_tasks):

@@ -153,7 +153,34 @@ STACKING_ENV_KWARGS = dict(
     done_at_success=True,
     stack_weld_relpos=[0.0, 0.045, 0.0],   # relpose of lh_weld_eq / rh_weld_eq (1263-1281)
 )
-ENV_DEFAULTS = {"CollaborativeStackingCart": STACKING_ENV_KWARGS, "CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
+# CollaborativeHammeringCart constructor defaults (collaborative_hammering_cartesian_env.py:291-367) overlaid with
+# training/config/environment/default/collaborative_hammering_cart.yaml
+HAMMERING_ENV_KWARGS = dict(
+    PICK_PLACE_ENV_KWARGS,
+    horizon=1000,
+    table_full_size=[1.5, 2.0, 0.05],
+    board_full_size=[1.0, 0.4, 0.03],
+    n_nail_placements_sampled_per_100_steps=1,
+    goal_tolerance=0.05,
+    collision_reward=-10.0,
+    hammer_gripped_reward_bonus=0.0,
+    nail_hammered_in_reward=-1.0,
+    task_reward=1.0,
+    human_animation_freq=100,
+    human_rand=[0.0, 0.0, 0.0],
+    n_animations_sampled_per_100_steps=1,
+    gripper_controllable=False,
+    hammer_anchors=[[-0.1, 0.2, 0.0], [-0.5, -0.2, 0.0]],   # l_anchor / r_anchor of _postprocess_model (1001-1002)
+    hammer_weld_relquat=[0.0, 0.0, 0.0, 1.0],               # relpose of rh_eq: "0 0 0 0 0 0 1" (1123-1131)
+)
+# Stand-in for robosuite 1.3.2's composite HammerObject (absent; its dimensions are drawn at random per instance): a box handle at the middle of the
+# reference's ranges (handle_radius 0.015-0.02, handle_length 0.1-0.25, handle_density 100-250) and ONE box for head + neck + face
+# (head_halfsize between 1 and 1.2 handle radii, head_density_ratio 2); no claw.  Body frame: origin = middle of the handle, handle along z, head along x.
+HAMMER = dict(handle_half=[0.0175, 0.0175, 0.0875], handle_density=175.0, head_half=[0.0616, 0.01925, 0.01925], head_density=350.0)
+# models/assets/objects/nail.xml: nail_head body 0.06 above nail_base, collision cylinder r 0.02 / half height 0.002 at +0.001 (stand-in: a box of the same
+# extents), slide joint along -z, range [0, 0.06], frictionloss 10000, solreffriction (-100, -100)
+NAIL = dict(head_half=[0.02, 0.02, 0.002], head_dz=0.001, stem=0.06, range=0.06, frictionloss=10000.0, fric_damping=100.0, dummy_half=0.01)
+ENV_DEFAULTS = {"CollaborativeHammeringCart": HAMMERING_ENV_KWARGS, "CollaborativeStackingCart": STACKING_ENV_KWARGS, "CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
                 "RobotHumanHandoverCart": HANDOVER_R2H_ENV_KWARGS,
                 "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
                 "HumanObjectInspectionCart": INSPECTION_ENV_KWARGS}
@@ -646,6 +673,8 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)
         d.n_targets = max(int(kw["horizon"] * kw["n_targets_sampled_per_100_steps"] / 100), 1)
         d.object_gripped_reward = float(kw["object_gripped_reward"])
+    if env_id == "CollaborativeHammeringCart":
+        _fill_hammering(d, kw)
     # ---- Cartesian action front-end (wrappers/ik_position_delta_wrapper.py)
     d.ik_enabled = int(ik_position_delta is not None)
     ik = dict(IK_DEFAULTS)
@@ -667,6 +696,70 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     d.ik_target_rot[:] = R_init[NARM - 1].reshape(-1).tolist()      # orientation at init_qpos, ik_position_delta_wrapper.py:74-82
     d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
     return d
+
+
+def _fill_hammering(d, kw):
+    """CollaborativeHammeringCart (collaborative_hammering_cartesian_env.py): board, hammer stand-in, nail, the two hand equalities, task parameters."""
+    NARM, NF = CONST["HRG_NARM"], CONST["HRG_NFINGER"]
+    d.task = CONST["HRG_TASK_HAMMERING"]
+    d.init_qpos[:] = [0.0, 0.0, -math.pi / 2, 0.0, -math.pi / 2, math.pi / 4]   # _reset_internal, 720
+    tx, ty = kw["table_full_size"][0], kw["table_full_size"][1]
+    d.table_half[:] = [0.5 * tx, 0.5 * ty]
+    size = [float(x) for x in kw["board_full_size"]]
+    half = [0.5 * x for x in size]
+    d.hm_board_half[:] = half
+    d.hm_board_mass = 1000.0 * size[0] * size[1] * size[2]                       # BoxObject(name="board") without a density: robosuite's default 1000 (934-938)
+    bi = [d.hm_board_mass * (half[(a + 1) % 3] ** 2 + half[(a + 2) % 3] ** 2) / 3.0 for a in range(3)]
+    d.hm_board_inertia[:] = bi
+    d.hm_board_invweight_rot = sum(1.0 / x for x in bi) / 3.0
+    for hd in range(2):
+        d.hm_anchor[hd][:] = [float(x) for x in kw["hammer_anchors"][hd]]
+    q = np.asarray(kw["hammer_weld_relquat"], float)
+    d.hm_weld_relquat[:] = (q / np.linalg.norm(q)).tolist()
+    # the hammer: two boxes, inertia about the common COM in the body axes (both boxes are centred on the handle axis: no products of inertia)
+    hh, hd_ = np.asarray(HAMMER["handle_half"]), np.asarray(HAMMER["head_half"])
+    m1, m2 = HAMMER["handle_density"] * 8 * hh.prod(), HAMMER["head_density"] * 8 * hd_.prod()
+    c1, c2 = np.zeros(3), np.array([0.0, 0.0, hh[2] + hd_[2]])
+    com = (m1 * c1 + m2 * c2) / (m1 + m2)
+    I = np.zeros(3)
+    for mm, hb, c in ((m1, hh, c1), (m2, hd_, c2)):
+        off = c - com
+        for a in range(3):
+            I[a] += mm * (hb[(a + 1) % 3] ** 2 + hb[(a + 2) % 3] ** 2) / 3.0 + mm * (off[(a + 1) % 3] ** 2 + off[(a + 2) % 3] ** 2)
+    d.hm_hammer_mass = float(m1 + m2)
+    d.hm_hammer_inertia[:] = I.tolist()
+    d.hm_hammer_invweight_rot = float(np.mean(1.0 / I))
+    d.hm_hammer_com[:] = com.tolist()
+    G = CONST
+    d.hm_geom_pos[G["HRG_HG_BOARD"]][:] = [0.0, 0.0, 0.0]
+    d.hm_geom_pos[G["HRG_HG_HANDLE"]][:] = (c1 - com).tolist()
+    d.hm_geom_pos[G["HRG_HG_HEAD"]][:] = (c2 - com).tolist()
+    d.hm_geom_pos[G["HRG_HG_NAIL"]][:] = [0.0, 0.0, NAIL["head_dz"]]
+    d.hm_geom_half[G["HRG_HG_BOARD"]][:] = half
+    d.hm_geom_half[G["HRG_HG_HANDLE"]][:] = hh.tolist()
+    d.hm_geom_half[G["HRG_HG_HEAD"]][:] = hd_.tolist()
+    d.hm_geom_half[G["HRG_HG_NAIL"]][:] = NAIL["head_half"]
+    d.hm_hammer_grip_quat[:] = [math.cos(math.pi / 4), 0.0, math.sin(math.pi / 4), 0.0]      # Rotation.from_euler("y", pi / 2), 792
+    # finger positions at which the pads' inner surfaces (finger origin +- 0.01, bar axis 0.019 outboard, radius 0.008) touch the handle's faces
+    pad = GRIPPER["finger_capsule"][0][1] - GRIPPER["finger_capsule"][2]
+    for f in range(NF):
+        sg = 1.0 if f == 0 else -1.0
+        d.hm_finger_grip_qpos[f] = sg * (hh[0] - abs(GRIPPER["finger_pos"][f][1]) - pad)
+    nh = NAIL["head_half"]
+    d.hm_nail_mass = 1000.0 * math.pi * nh[0] ** 2 * 2 * nh[2]
+    # NailSampler (946-960): z_offset = half board thickness + 0.001, on top of that the dummy's half height [UPSTREAM UniformRandomSampler]; nail_head 0.06 above
+    d.hm_nail_z0 = half[2] + 0.001 + NAIL["dummy_half"] + NAIL["stem"]
+    d.hm_nail_range = NAIL["range"]
+    d.hm_nail_frictionloss = NAIL["frictionloss"]
+    d.hm_nail_fric_damping = NAIL["fric_damping"]
+    d.hm_nail_invweight = 1.0 / d.hm_nail_mass + 1.0 / d.hm_board_mass
+    d.hm_nail_bin[:] = [half[0] * 0.1, half[0] * 0.9, -half[1] * 0.9, half[1] * 0.9]         # _get_default_nail_sample_space_boundaries (838-853)
+    d.hm_goal_tolerance = float(kw["goal_tolerance"])
+    d.hammer_gripped_reward_bonus = float(kw["hammer_gripped_reward_bonus"])
+    d.nail_hammered_in_reward = float(kw["nail_hammered_in_reward"])
+    d.gripper_controllable = int(bool(kw["gripper_controllable"]))
+    d.n_obj_placements = max(int(kw["horizon"] * kw["n_nail_placements_sampled_per_100_steps"] / 100), 1)   # 370-373
+    d.n_targets = 1
 
 
 def robot_fk_numpy(d, q):

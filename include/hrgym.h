@@ -57,7 +57,8 @@ extern "C" {
 #define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
 #define HRG_NHCAP_MAX 64  /* human reach capsules over all three models (fits one wavefront) */
 #define HRG_LTT_NSEG 12   /* constant-jerk segments per joint of a long-term trajectory */
-#define HRG_OBS_DIM 57    /* superset of the flat observation; the host selects columns by obs_keys:
+#define HRG_OBS_DIM 64    /* superset of the flat observation (64 floats = one 256-byte row per env: a wavefront stores a row with one coalesced
+                          *  instruction); the host selects columns by obs_keys:
                           *  [0:12] object-state  [12:18] goal_difference  [18:24] robot0_joint_pos  [24:30] robot0_joint_vel
                           *  [30:33] robot0_eef_pos  [33:39] desired_goal   (human_env.py:1483-1602, reach_human_env.py:608-666)
                           *  the cube tasks serve object_quat (x, y, z, w) in [12:16] (those columns are joint-space entries of ReachHuman only)
@@ -65,7 +66,10 @@ extern "C" {
                           *  [39] object_gripped  [40:43] vec_eef_to_object  [43:46] vec_eef_to_target  [46] gripper_aperture
                           *  [47:50] object_pos  [50:53] target_pos
                           *  both tasks: [53:55] robot0_gripper_qpos  [55:57] robot0_gripper_qvel (the scripted experts' inputs,
-                          *  demonstrations/experts/pick_place_human_cart_expert.py:24-41) */
+                          *  demonstrations/experts/pick_place_human_cart_expert.py:24-41)
+                          *  [57:61] quat_eef_to_object of the handover tasks / quat_eef_to_board of CollaborativeLiftingCart (x, y, z, w;
+                          *  human_robot_handover_cartesian_env.py:860-875, collaborative_lifting_cartesian_env.py:1010-1031), board_quat of
+                          *  CollaborativeHammeringCart; [61] its nail_hammering_progress; [62:64] unused (zero) */
 #define HRG_ACT_DIM 7     /* 6 joint deltas + 1 gripper (reach_human_expert.py:82-83) */
 #define HRG_INFO_DIM 14
 #define HRG_NCON_MAX 24   /* contacts reported per env per substep */
@@ -78,6 +82,8 @@ extern "C" {
 #define HRG_NV_STACK (HRG_NV + HRG_NCUBE * HRG_NBOXV) /* DoF of the stacking task's constrained system: robot tree + four free joints */
 #define HRG_NCON_DYN_STACK 23 /* contacts that enter its solve: 8 + 16 + 12 + 4 x 23 = 128 constraint rows = two per lane of a wavefront */
 #define HRG_NROW_STACK 128
+#define HRG_NV_HAMMER 24   /* CollaborativeHammeringCart: three 8-wide blocks -- robot tree 0..7 | board 8..13, nail slide joint 14, pad | hammer 16..21, pad, pad */
+#define HRG_NCON_DYN_HAMMER 20 /* contacts that enter its solve: 9 + 18 + 9 + 4 x 20 = 116 constraint rows (two per lane of a wavefront) */
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
 #define HRG_MAX_LOOP 4     /* layered sines of an animation loop (utils/animation_utils.py:91-119) */
@@ -116,7 +122,9 @@ enum { HRG_TASK_REACH = 0, HRG_TASK_PICK_PLACE = 1, HRG_TASK_INSPECTION = 2 /* H
        HRG_TASK_LIFTING = 6 /* CollaborativeLiftingCart (collaborative_lifting_cartesian_env.py): robot and human carry a board together */,
        HRG_TASK_STACKING = 7 /* CollaborativeStackingCart (collaborative_stacking_cartesian_env.py): human and robot build a stack of four cubes in turns */,
        HRG_TASK_REACH_BOX = 8 /* ReachHuman with its free `smallBox` object (reach_human_env.py:573-579, 5 cm cube placed anywhere on the table; not whitelisted: a
-                               * robot contact with it is a static collision); task logic of ReachHuman, stepped by the cube kernel */ };
+                               * robot contact with it is a static collision); task logic of ReachHuman, stepped by the cube kernel */,
+       HRG_TASK_HAMMERING = 9 /* CollaborativeHammeringCart (collaborative_hammering_cartesian_env.py): the robot holds a hammer and drives a nail into a board the
+                               * human presents -- two free bodies (board, hammer), the nail on a slide joint of the board, a weld + a connect to the hands */ };
 #define HRG_IS_HANDOVER(task) ((task) == HRG_TASK_HANDOVER_H2R || (task) == HRG_TASK_HANDOVER_R2H)
 /* ObjectInspectionPhase, human_object_inspection_cartesian_env.py:43-49 */
 enum { HRG_PHASE_APPROACH = 0, HRG_PHASE_READY = 1, HRG_PHASE_INSPECTION = 2, HRG_PHASE_RETREAT = 3, HRG_PHASE_COMPLETE = 4 };
@@ -127,6 +135,11 @@ enum { HRG_R2H_APPROACH = 0, HRG_R2H_REACH_OUT = 1, HRG_R2H_RETREAT = 2, HRG_R2H
 /* CollaborativeStackingPhase, collaborative_stacking_cartesian_env.py:52-60 */
 enum { HRG_STK_APPROACH = 0, HRG_STK_PLACE_FIRST = 1, HRG_STK_WAIT_FOR_SECOND = 2, HRG_STK_PLACE_THIRD = 3, HRG_STK_WAIT_FOR_FOURTH = 4, HRG_STK_RETREAT = 5,
        HRG_STK_COMPLETE = 6 };
+/* CollaborativeHammeringPhase, collaborative_hammering_cartesian_env.py:48-53 */
+enum { HRG_HM_APPROACH = 0, HRG_HM_PRESENT = 1, HRG_HM_RETREAT = 3, HRG_HM_COMPLETE = 4 };
+/* free bodies / collision geoms of the hammering task: geom GEOM_BOX + g, body BODY_BOX + b (the nail's contacts act on the board's DoF and the slide joint) */
+enum { HRG_HM_BOARD = 0, HRG_HM_HAMMER = 1, HRG_HM_NAIL = 2 };
+enum { HRG_HG_BOARD = 0, HRG_HG_HANDLE = 1, HRG_HG_HEAD = 2, HRG_HG_NAIL = 3, HRG_HM_NGEOM = 4 };
 /* cube indices of the stacking task (order of `self.objects`, 1176-1180): the robot's two cubes, then the cubes in the human's hands */
 enum { HRG_CUBE_A = 0, HRG_CUBE_B = 1, HRG_CUBE_L = 2, HRG_CUBE_R = 3 };
 
@@ -287,6 +300,28 @@ typedef struct hrg_model_desc {
   double pfl_v_safe;            /* Cartesian speed [m/s] the arm may keep while the reachable sets intersect */
   double pfl_reach[HRG_NARM];   /* largest distance of a point of the arm downstream of joint j from that joint (lever arm of its velocity) */
   double stack_weld_relpos[3];  /* relpose of the cube <-> hand mocap welds: mocap body origin in the cube frame, "0 0.045 0" (1263-1281) */
+  /* ---- CollaborativeHammeringCart (collaborative_hammering_cartesian_env.py:291-381, 889-960, 1100-1145; models/assets/objects/nail.xml) ---- */
+  double hm_board_half[3], hm_board_mass, hm_board_inertia[3]; /* BoxObject "board" (934-938): board_full_size / 2, default density 1000 */
+  double hm_board_invweight_rot;  /* body_invweight0 (rotation) of the board: mean of 1 / inertia */
+  double hm_anchor[2][3];         /* l_anchor / r_anchor: board-frame positions of lh_grip (connect) and rh_grip (weld), 1001-1002 */
+  double hm_weld_relquat[4];      /* relpose quaternion of rh_eq (w, x, y, z), 1123-1131 */
+  double hm_hammer_mass, hm_hammer_inertia[3]; /* HammerObject [UPSTREAM robosuite]: stand-in of two boxes (handle, head); inertia about the COM, body axes */
+  double hm_hammer_invweight_rot;
+  double hm_hammer_com[3];        /* COM in the hammer's body frame (origin = middle of the handle) */
+  double hm_geom_pos[HRG_HM_NGEOM][3];  /* geom centres in their body frame: board (0), handle and head relative to the hammer's COM, nail head relative to the nail_head body */
+  double hm_geom_half[HRG_HM_NGEOM][3];
+  double hm_hammer_grip_quat[4];  /* world orientation the hammer is put into the gripper with: Ry(90 deg), _put_hammer_into_gripper (790-812) */
+  double hm_finger_grip_qpos[HRG_NFINGER]; /* finger positions at a reset: pads touching the handle (the reference closes the gripper over 100 sim steps, 795-809) */
+  double hm_nail_mass;            /* nail_head_g0, cylinder r 0.02 h 0.004 at density 1000 (nail.xml:5) */
+  double hm_nail_z0;              /* nail_head body origin above the board's centre at joint position 0: placement z + 0.06 (nail.xml:3, 946-960) */
+  double hm_nail_range;           /* slide joint range [0, 0.06], axis (0, 0, -1) of the board (nail.xml:7) */
+  double hm_nail_frictionloss, hm_nail_fric_damping; /* frictionloss 10000, solreffriction (-100, -100): reference acceleration -damping / dmax * velocity */
+  double hm_nail_invweight;       /* dof_invweight0 of the slide joint */
+  double hm_nail_bin[4];          /* xmin xmax ymin ymax of the nail placements on the board (838-853) */
+  double hm_goal_tolerance;       /* nail counts as hammered in when 1 - progress < goal_tolerance (505-520) */
+  double hammer_gripped_reward_bonus, nail_hammered_in_reward; /* _sparse_reward (522-556) */
+  int32_t gripper_controllable;   /* False: the gripper action is replaced by 'close' (486-487) */
+  int32_t hm_pad;
   uint64_t seed;
 } hrg_model_desc;
 
@@ -382,6 +417,11 @@ int hrg_batch_set_box(hrg_batch* b, int32_t env, const void* buf_host, size_t by
 size_t hrg_stack_bytes(void);
 int hrg_batch_get_stack(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_stack(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
+/* board, hammer, nail + task bookkeeping of CollaborativeHammeringCart (hrg_hammer_state, include/hrgym_state.h):
+ * CollaborativeHammeringCart.get/set_environment_state, collaborative_hammering_cartesian_env.py:1339-1377 */
+size_t hrg_hammer_bytes(void);
+int hrg_batch_get_hammer(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
+int hrg_batch_set_hammer(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
 
 /* HumanEnv.check_collision_action (human_env.py:588-627; called by CollisionPreventionWrapper, wrappers/collision_prevention_wrapper.py:38-51, and
  * utils/training_utils.py:362-366): would the joint-space action drive the robot into the static scene or itself?  The goal configuration the

@@ -120,6 +120,23 @@ typedef struct hrg_stack_state {
   int32_t pad;
 } hrg_stack_state;
 
+/* CollaborativeHammeringCart: the board the human holds (free joint; the nail rides on it on a slide joint), the hammer in the robot's gripper (free
+ * joint), the two hand mocap bodies, and the task's bookkeeping (CollaborativeHammeringEnvState, collaborative_hammering_cartesian_env.py:56-89).  Its own
+ * HBM array, streamed only by that task's kernel; get/set through hrg_batch_get_hammer / hrg_batch_set_hammer. */
+typedef struct hrg_hammer_state {
+  double pos[2][3], quat[2][4];      /* HRG_HM_BOARD, HRG_HM_HAMMER: centre of mass, orientation (w,x,y,z) */
+  double vel[2][6];                  /* linear, angular velocity (world frame) */
+  double acc_warmstart[2][6];
+  double nail_q, nail_v, nail_acc_warmstart; /* nail_head_joint0: how far the nail is driven in [m], 0 .. hm_nail_range */
+  double nail_xy[2];                 /* current nail placement on the board (board frame): nail_placements[nail_placements_index] */
+  double obs_pos[3][3];              /* body_xpos of the last forward pass: board_main, hammer root body (middle of the handle), nail_head */
+  double mocap_pos[2][3], mocap_quat[2][4]; /* lh_mocap, rh_mocap (688-715), set once per cycle */
+  int32_t nail_index;                /* _nail_placements_index */
+  int32_t gripped;                   /* hammer_gripped sensor (1283-1289) at the last substep */
+  int32_t task_phase;                /* HRG_HM_* */
+  int32_t n_delayed;                 /* _n_delayed_timesteps */
+} hrg_hammer_state;
+
 #ifdef __cplusplus
 }
 #endif

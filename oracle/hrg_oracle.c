@@ -122,6 +122,7 @@ typedef struct hrgo_batch {
   hrg_env_state* st;
   hrg_box_state* box; /* manipulation object per env (unused by ReachHuman) */
   hrg_stack_state* stk; /* the four cubes + bookkeeping of CollaborativeStackingCart */
+  hrg_hammer_state* hmr; /* board, hammer, nail + bookkeeping of CollaborativeHammeringCart */
   /* parity taps of the last shield cycle */
   double (*rcaps)[HRG_NSHIELD_RCAP][7];
   double (*hcaps)[HRG_NHCAP_MAX][7];
@@ -382,7 +383,8 @@ static double layered_sines(const hrgo_batch* b, int64_t gid, const hrg_env_stat
 }
 
 static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, int clip, int* at_io);
-static void human_control_sk(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, hrg_stack_state* sk, double* mocap_pos, double* mocap_quat, const double** qh) {
+static void hammer_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, hrg_hammer_state* hm, int clip, int* at_io);
+static void human_control_all(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, hrg_stack_state* sk, hrg_hammer_state* hm, double* mocap_pos, double* mocap_quat, const double** qh) {
   const hrg_model_desc* m = &b->m;
   /* human_env.py:1719-1731 */
   int control_time = (int)floor((double)s->low_level_time / m->anim_step_length);
@@ -437,6 +439,7 @@ static void human_control_sk(const hrgo_batch* b, int64_t gid, hrg_env_state* s,
     if (at < 0) at = 0;
   }
   if (m->task == HRG_TASK_STACKING) stack_animation_time(b, gid, s, sk, clip, &at);
+  if (m->task == HRG_TASK_HAMMERING) hammer_animation_time(b, gid, s, hm, clip, &at);
   s->animation_time = at;
   if (at > b->clips.clip_len[clip] - 1) {
     s->anim_index = (s->anim_index + 1) % m->n_anim_ids; /* human_env.py:1704-1708 */
@@ -459,8 +462,11 @@ static void human_control_sk(const hrgo_batch* b, int64_t gid, hrg_env_state* s,
   *qh = fr + 7;
 }
 
+static void human_control_sk(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, hrg_stack_state* sk, double* mocap_pos, double* mocap_quat, const double** qh) {
+  human_control_all(b, gid, s, bx, sk, NULL, mocap_pos, mocap_quat, qh);
+}
 static void human_control(const hrgo_batch* b, int64_t gid, hrg_env_state* s, hrg_box_state* bx, double* mocap_pos, double* mocap_quat, const double** qh) {
-  human_control_sk(b, gid, s, bx, NULL, mocap_pos, mocap_quat, qh);
+  human_control_all(b, gid, s, bx, NULL, NULL, mocap_pos, mocap_quat, qh);
 }
 
 static void human_fk(const hrg_model_desc* m, const double* mocap_pos, const double* mocap_quat, const double* qh, human_kin* h, double site[HRG_NHJ][3]) {
@@ -1054,7 +1060,15 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
 }
 
 /* the manipulation object is whitelisted: COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717) */
-static int geom_class_t(int g, int task) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX && task != HRG_TASK_REACH_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); } /* GEOM_BOX + c: cube c of the stacking task (1526-1549) */
+/* GEOM_BOX + c: cube c of the stacking task (1526-1549); the hammering task white-lists the hammer's geoms only, "the board is not white-listed"
+ * (collaborative_hammering_cartesian_env.py:1325-1337) */
+static int geom_class_t(int g, int task) {
+  if (g < HRG_NRCAP) return HRG_GEOM_ROBOT;
+  if (g < GEOM_TABLE) return HRG_GEOM_HUMAN;
+  if (g < GEOM_BOX || task == HRG_TASK_REACH_BOX) return HRG_GEOM_STATIC;
+  if (task == HRG_TASK_HAMMERING) return g == GEOM_BOX + HRG_HG_HANDLE || g == GEOM_BOX + HRG_HG_HEAD ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC;
+  return HRG_GEOM_ALLOWED;
+}
 static int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; } /* utils/pairing.py:4-16 */
 
 /* HumanEnv._collision_detection + _on_*_detected, human_env.py:966-1123 */
@@ -1120,7 +1134,12 @@ static void impedance(const hrg_model_desc* m, double pos_minus_margin, double* 
   *Bd = 2.0 / (dmax * tc);
 }
 
+static void efc_add_b(const hrg_model_desc* m, efc_t* E, const double* J, const double* qd, int type, double pos, double margin, double floss, double diag, double Bd_own);
 static void efc_add(const hrg_model_desc* m, efc_t* E, const double* J, const double* qd, int type, double pos, double margin, double floss, double diag) {
+  efc_add_b(m, E, J, qd, type, pos, margin, floss, diag, -1.0);
+}
+/* Bd_own >= 0: the row's own damping of its reference acceleration (a joint's solreffriction in the direct format), else the model's solref */
+static void efc_add_b(const hrg_model_desc* m, efc_t* E, const double* J, const double* qd, int type, double pos, double margin, double floss, double diag, double Bd_own) {
   /* R = (1-imp)/imp * diagApprox with MuJoCo's constant approximations (dof_invweight0 for joint rows, sum of
    * the two bodies' translational body_invweight0 for contact rows), not the exact J M^-1 J' */
   if (E->n >= NEFC_MAX) return;
@@ -1129,6 +1148,7 @@ static void efc_add(const hrg_model_desc* m, efc_t* E, const double* J, const do
   if (!(nz > 0) || !(diag > 0)) return; /* row does not act on the robot tree */
   double imp, K, Bd;
   impedance(m, pos - margin, &imp, &K, &Bd);
+  if (Bd_own >= 0) Bd = Bd_own;
   int r = E->n++;
   memcpy(E->J[r], J, sizeof(double) * E->nv);
   E->type[r] = type;
@@ -1552,6 +1572,9 @@ static void eef_of(const hrg_model_desc* m, const robot_kin* k, double* eef) {
 static void env_reset_stack(hrgo_batch* B, int e, const robot_kin* k);
 static void compute_obs_stack(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, hrg_stack_state* sk, float* obs);
 static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info);
+static void env_reset_hammer(hrgo_batch* B, int e, const robot_kin* k);
+static void compute_obs_hammer(const hrgo_batch* B, const hrg_env_state* s, const hrg_hammer_state* hm, float* obs);
+static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info);
 static void env_reset(hrgo_batch* B, int e, float* obs) {
   const hrg_model_desc* m = &B->m;
   hrg_env_state* s = &B->st[e];
@@ -1563,6 +1586,10 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   /* robot.reset: init_qpos + N(0, 0.02^2) (robosuite "default" initialization_noise) */
   for (int j = 0; j < NARM; j++) s->qpos[j] = m->init_qpos[j] + m->init_noise * rng_gauss(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)j);
   for (int j = 0; j < HRG_NFINGER; j++) s->qpos[NARM + j] = m->finger_init_qpos[j];
+  if (m->task == HRG_TASK_HAMMERING) { /* _put_hammer_into_gripper (790-812) closes the gripper on the handle: the fingers start where their pads touch it, commanded shut */
+    for (int j = 0; j < HRG_NFINGER; j++) s->qpos[NARM + j] = m->hm_finger_grip_qpos[j];
+    s->grip_action = -1.0;
+  }
   /* human placement: x, y, yaw uniform in +-human_rand (human_env.py:1376-1387, 1650-1656) */
   double ux = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 0), uy = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 1),
          uz = rng_u01(m->seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 2);
@@ -1587,6 +1614,11 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
   if (m->task == HRG_TASK_STACKING) {
     env_reset_stack(B, e, &k);
     if (obs) compute_obs_stack(B, gid, s, &B->stk[e], obs);
+    return;
+  }
+  if (m->task == HRG_TASK_HAMMERING) {
+    env_reset_hammer(B, e, &k);
+    if (obs) compute_obs_hammer(B, s, &B->hmr[e], obs);
     return;
   }
   hrg_box_state* bx = m->task != HRG_TASK_REACH ? &B->box[e] : NULL;
@@ -1639,6 +1671,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
 static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
   const hrg_model_desc* m = &B->m;
   if (m->task == HRG_TASK_STACKING) { env_step_stack(B, e, action, obs, term_obs, reward, done, info); return; }
+  if (m->task == HRG_TASK_HAMMERING) { env_step_hammer(B, e, action, obs, term_obs, reward, done, info); return; }
   hrg_env_state* s = &B->st[e];
   int64_t gid = s->stream_id; /* in-episode draws follow the state's streams (= the env's own id unless the state was copied in) */
   const double h = m->timestep;
@@ -2075,7 +2108,7 @@ static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env
   *at_io = at;
 }
 
-/* Contacts of two boxes with the same half extents h (centres pa / pb, rotations Ra / Rb row-major): separating-axis test over the 15 axes; the axis of
+/* Contacts of two boxes with half extents ha / hb (centres pa / pb, rotations Ra / Rb row-major; the stacking task's cubes share one h): separating-axis test over the 15 axes; the axis of
  * least penetration decides.  A face axis: the face of the other box most anti-parallel to it is clipped against the reference face's rectangle --
  * candidates = incident vertices inside the rectangle (0..3), rectangle corners under the incident face (4..7), crossings of the incident edges with the
  * rectangle's sides (8..23); of those that penetrate, at most four are kept: the deepest, the one farthest from it, and the farthest from their line on
@@ -2085,7 +2118,7 @@ static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env
  * parallel cubes keep their reference face while rounding-level differences come and go */
 #define BB_TIE 1e-9
 typedef struct { double pos[3], n[3], dist; } bb_contact;
-static int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, bb_contact out[4]) {
+static int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, bb_contact out[4]) {
   double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
   v3sub(t, pb, pa);
   for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = Ra[3 * k + i]; B[i][k] = Rb[3 * k + i]; }
@@ -2093,12 +2126,12 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
   double sf = -1e300, se = -1e300;
   int bf = 0, be = -1;
   for (int i = 0; i < 3; i++) {
-    const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
+    const double s_ = fabs(ta[i]) - (ha[i] + hb[0] * AC[i][0] + hb[1] * AC[i][1] + hb[2] * AC[i][2]);
     if (s_ > 0) return 0;
     if (s_ > sf + BB_TIE) { sf = s_; bf = i; }
   }
   for (int j = 0; j < 3; j++) {
-    const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
+    const double s_ = fabs(tb[j]) - (hb[j] + ha[0] * AC[0][j] + ha[1] * AC[1][j] + ha[2] * AC[2][j]);
     if (s_ > 0) return 0;
     if (s_ > sf + BB_TIE) { sf = s_; bf = 3 + j; }
   }
@@ -2108,7 +2141,7 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     if (l2 < 1e-12) continue; /* parallel edges: the face axes cover it */
     const double l = sqrt(l2);
     const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j]; /* t . (A_i x B_j) */
-    const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
+    const double s_ = (fabs(tl) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1])) / l;
     if (s_ > 0) return 0;
     if (s_ > se + BB_TIE) { se = s_; be = 3 * i + j; }
   }
@@ -2120,8 +2153,8 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     if (v3dot(n, t) < 0) v3scl(n, n, -1.0);
     v3cpy(pA, pa); v3cpy(pB, pb);
     for (int k = 0; k < 3; k++) {
-      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * h[k]);
-      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * h[k]);
+      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * ha[k]);
+      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * hb[k]);
     }
     v3sub(d, pB, pA);
     const double uaub = C[i][j], q1 = v3dot(A[i], d), q2 = -v3dot(B[j], d), den = 1.0 - uaub * uaub;
@@ -2140,23 +2173,25 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
   const double (*In)[3] = refA ? B : A;
   const double* pr = refA ? pa : pb;
   const double* pi = refA ? pb : pa;
+  const double* hr = refA ? ha : hb;   /* half extents of the reference / the incident box */
+  const double* hi = refA ? hb : ha;
   const double sg = refA ? (ta[r] >= 0 ? 1.0 : -1.0) : (tb[r] >= 0 ? -1.0 : 1.0); /* reference normal points at the incident box */
   double nr[3], cr[3], ci[3];
   v3scl(nr, Rf[r], sg);
-  v3madd(cr, pr, nr, h[r]);
+  v3madd(cr, pr, nr, hr[r]);
   int k = 0;
   double best = -1;
   for (int q = 0; q < 3; q++) { const double c_ = fabs(v3dot(In[q], nr)); if (c_ > best) { best = c_; k = q; } }
   const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
   const double si = v3dot(In[k], nr) > 0 ? -1.0 : 1.0; /* incident face normal opposes the reference normal */
-  v3madd(ci, pi, In[k], si * h[k]);
-  const double hu = h[r1], hv = h[r2];
+  v3madd(ci, pi, In[k], si * hi[k]);
+  const double hu = hr[r1], hv = hr[r2];
   static const double S1[4] = {1, -1, -1, 1}, S2[4] = {1, 1, -1, -1};
   double vu[4], vv[4], vd[4];
   for (int q = 0; q < 4; q++) {
     double x[3], d[3];
-    v3madd(x, ci, In[k1], S1[q] * h[k1]);
-    v3madd(x, x, In[k2], S2[q] * h[k2]);
+    v3madd(x, ci, In[k1], S1[q] * hi[k1]);
+    v3madd(x, x, In[k2], S2[q] * hi[k2]);
     v3sub(d, x, cr);
     vu[q] = v3dot(d, Rf[r1]); vv[q] = v3dot(d, Rf[r2]); vd[q] = v3dot(d, nr);
   }
@@ -2169,8 +2204,8 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
     double d0[3];
     v3sub(d0, ci, cr);
     const double c0u = v3dot(d0, Rf[r1]), c0v = v3dot(d0, Rf[r2]), c0d = v3dot(d0, nr);
-    const double e1u = h[k1] * v3dot(In[k1], Rf[r1]), e1v = h[k1] * v3dot(In[k1], Rf[r2]), e1d = h[k1] * v3dot(In[k1], nr);
-    const double e2u = h[k2] * v3dot(In[k2], Rf[r1]), e2v = h[k2] * v3dot(In[k2], Rf[r2]), e2d = h[k2] * v3dot(In[k2], nr);
+    const double e1u = hi[k1] * v3dot(In[k1], Rf[r1]), e1v = hi[k1] * v3dot(In[k1], Rf[r2]), e1d = hi[k1] * v3dot(In[k1], nr);
+    const double e2u = hi[k2] * v3dot(In[k2], Rf[r1]), e2v = hi[k2] * v3dot(In[k2], Rf[r2]), e2d = hi[k2] * v3dot(In[k2], nr);
     const double det = e1u * e2v - e1v * e2u;
     if (fabs(det) > 1e-12 * hu * hv)
       for (int q = 0; q < 4; q++) {
@@ -2239,6 +2274,8 @@ static int box_box(const double* pa, const double* Ra, const double* pb, const d
   }
   return np_;
 }
+
+static int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, bb_contact out[4]) { return box_box2(pa, Ra, h, pb, Rb, h, out); }
 
 /* contact list of the stacking task: the robot's own contacts (collide), then per cube c the robot capsules' first points, table corners, floor corners,
  * then the cube pairs (a < b), then the second points of capsules lying along a face.  object_gripped (1467-1481): a finger pair holds cube A or B --
@@ -2749,6 +2786,555 @@ static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, flo
   else memcpy(obs, term_obs, sizeof(float) * HRG_OBS_DIM);
 }
 
+/* =============================================================================================== CollaborativeHammeringCart
+ * collaborative_hammering_cartesian_env.py: the human carries a board (free joint; held by a weld at the right and a connect at the left hand mocap body),
+ * a nail rides on the board on a slide joint (models/assets/objects/nail.xml), the robot holds a hammer (free joint) in its closed gripper and has to drive
+ * the nail in while the human presents the board; three-phase animation machine.  Constrained system: 24 DoF in three blocks of eight --
+ * robot tree 0..7 | board 8..13 + the nail's slide joint 14 (+ pad) | hammer 16..21 (+ 2 pads); a pad DoF has unit mass, no force and no constraint row.
+ * Stand-ins: the hammer is two boxes (robosuite's composite HammerObject is absent), the nail head a box, box-box contacts by box_box2 (D13),
+ * capsule-box contacts as for the single cube (D8); MuJoCo's noslip post-pass (noslip_iterations = 20, 1149) is not restated. */
+#define NVH HRG_NV_HAMMER
+#define HM_OB NV        /* board DoF */
+#define HM_ON (NV + 6)  /* nail slide joint */
+#define HM_OH (NV + 8)  /* hammer DoF */
+#define GEOM_HM(g) (GEOM_BOX + (g))
+#define BODY_HM(b) (BODY_BOX + (b))
+
+/* CollaborativeHammeringCart._compute_animation_time (636-680), applied to the classic animation time *at_io */
+static void hammer_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env_state* s, hrg_hammer_state* hm, int clip, int* at_io) {
+  const int classic = *at_io, len = b->clips.clip_len[clip];
+  const double k0 = (double)b->clips.clip_keyframes[clip][0], mid = 0.5 * (k0 + (double)b->clips.clip_keyframes[clip][1]);
+  int at = classic;
+  if (hm->task_phase == HRG_HM_APPROACH && (double)at > k0) hm->task_phase = HRG_HM_PRESENT;
+  else if (hm->task_phase == HRG_HM_PRESENT && (double)at > mid) { /* idle loop until the nail is hammered in */
+    at = (int)layered_sines(b, gid, s, clip, 0, b->clips.clip_n_loop[clip], (double)classic, mid);
+    hm->n_delayed = classic - at;
+  } else if (hm->task_phase == HRG_HM_RETREAT) at -= hm->n_delayed;
+  if (at >= len - 1) { hm->task_phase = HRG_HM_COMPLETE; at = len - 1; }
+  if (at < 0) at = 0;
+  *at_io = at;
+}
+
+/* world poses of the four collision geoms, the nail_head body origin and the slide axis */
+typedef struct { double c[HRG_HM_NGEOM][3], R[2][9], nail_org[3], axis[3]; } hammer_geo;
+static const int HM_GEOM_BODY[HRG_HM_NGEOM] = {HRG_HM_BOARD, HRG_HM_HAMMER, HRG_HM_HAMMER, HRG_HM_NAIL};
+static void hammer_geometry(const hrg_model_desc* m, const hrg_hammer_state* hm, hammer_geo* G) {
+  double t[3];
+  quat2mat(G->R[0], hm->quat[0]);
+  quat2mat(G->R[1], hm->quat[1]);
+  v3cpy(G->c[HRG_HG_BOARD], hm->pos[0]);
+  for (int g = HRG_HG_HANDLE; g <= HRG_HG_HEAD; g++) { m3mulv(t, G->R[1], m->hm_geom_pos[g]); v3add(G->c[g], hm->pos[1], t); }
+  const double loc[3] = {hm->nail_xy[0], hm->nail_xy[1], m->hm_nail_z0 - hm->nail_q};
+  m3mulv(t, G->R[0], loc); v3add(G->nail_org, hm->pos[0], t);
+  m3mulv(t, G->R[0], m->hm_geom_pos[HRG_HG_NAIL]); v3add(G->c[HRG_HG_NAIL], G->nail_org, t);
+  for (int a = 0; a < 3; a++) G->axis[a] = -G->R[0][3 * a + 2]; /* joint axis (0, 0, -1) of the board */
+}
+
+/* contact list of the hammering task: the robot's own contacts (collide), then per geom g (board, handle, head) the robot capsules' first points, the
+ * corners on the table and on the floor, then the box pairs (head - nail, handle - nail, head - board, handle - board), then the second points of capsules
+ * lying along a face.  The handle meets the two finger bars only (the stand-in hand capsule envelops the real gripper's palm, through which the handle
+ * passes); robot - nail contacts are not generated.  hammer_gripped (1283-1289): _check_grasp = both fingers touch a geom of the hammer. */
+static int collide_hammer(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, hrg_hammer_state* hm, const hammer_geo* G, contact_t* con) {
+  int n = collide(m, k, h, NULL, con);
+  double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3], Rb[9];
+  quat2mat(Rb, m->base_quat);
+  for (int c = 0; c < HRG_NRCAP; c++) {
+    int b = m->rcap_body[c];
+    const double* R = b < 0 ? Rb : k->R[b];
+    const double* p = b < 0 ? m->base_pos : k->p[b];
+    double t[3];
+    m3mulv(t, R, m->rcap_p1[c]); v3add(rp1[c], p, t);
+    m3mulv(t, R, m->rcap_p2[c]); v3add(rp2[c], p, t);
+  }
+#define EMIT(G1, G2, B1, B2, DIST, NRM, POS) \
+  do { if (n < HRG_NCON_MAX) { con[n].g1 = G1; con[n].g2 = G2; con[n].b1 = B1; con[n].b2 = B2; con[n].dist = DIST; v3cpy(con[n].n, NRM); v3cpy(con[n].pos, POS); n++; } } while (0)
+  int n_second = 0, second_i[3 * HRG_NRCAP], second_g[3 * HRG_NRCAP];
+  double second_s[3 * HRG_NRCAP][3], second_b[3 * HRG_NRCAP][3];
+  int f0 = 0, f1 = 0;
+  for (int g = HRG_HG_BOARD; g <= HRG_HG_HEAD; g++) {
+    const double* Rx = G->R[HM_GEOM_BODY[g]];
+    const double* hb = m->hm_geom_half[g];
+    const int body = BODY_HM(HM_GEOM_BODY[g]);
+    for (int i = 0; i < HRG_NRCAP; i++) {
+      if (m->rcap_body[i] < 0) continue;
+      if (g == HRG_HG_HANDLE && i < HRG_NRCAP - 2) continue;
+      double t, cs[3], cb[3], nn[3], pos[3], s2[2][3], b2[2][3];
+      double e2 = seg_box(rp1[i], rp2[i], G->c[g], Rx, hb, &t, cs, cb), dd = sqrt(e2), dist = dd - m->rcap_r[i];
+      if (!(dist < 0)) continue;
+      if (dd > 1e-9 && cap_box_two(rp1[i], rp2[i], G->c[g], Rx, hb, m->rcap_r[i], cs, cb, s2, b2)) {
+        v3cpy(cs, s2[0]); v3cpy(cb, b2[0]);
+        v3sub(nn, cb, cs); dd = v3norm(nn); dist = dd - m->rcap_r[i];
+        second_i[n_second] = i; second_g[n_second] = g; v3cpy(second_s[n_second], s2[1]); v3cpy(second_b[n_second], b2[1]); n_second++;
+      }
+      if (dd > 1e-9) { v3sub(nn, cb, cs); v3scl(nn, nn, 1.0 / dd); }
+      else { /* capsule axis inside the box: push out through the nearest face */
+        double loc[3], best = 1e300; int ax = 0;
+        v3sub(pos, cs, G->c[g]);
+        for (int a = 0; a < 3; a++) { loc[a] = Rx[a] * pos[0] + Rx[3 + a] * pos[1] + Rx[6 + a] * pos[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
+        double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) nn[a] = sg * Rx[3 * a + ax];
+        dist = -best - m->rcap_r[i];
+      }
+      v3madd(pos, cs, nn, m->rcap_r[i] + 0.5 * dist);
+      if (n < HRG_NCON_MAX && g != HRG_HG_BOARD) { f0 |= i == HRG_NRCAP - 2; f1 |= i == HRG_NRCAP - 1; }
+      EMIT(i, GEOM_HM(g), m->rcap_body[i], body, dist, nn, pos);
+    }
+  }
+  for (int pl = 0; pl < 2; pl++)
+    for (int g = HRG_HG_BOARD; g <= HRG_HG_HEAD; g++) {
+      const double* Rx = G->R[HM_GEOM_BODY[g]];
+      const double* hb = m->hm_geom_half[g];
+      for (int cn = 0; cn < 8; cn++) {
+        double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]}, p[3];
+        m3mulv(p, Rx, loc);
+        v3add(p, p, G->c[g]);
+        double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
+        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (dist < 0) {
+          double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
+          EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_HM(g), -1, BODY_HM(HM_GEOM_BODY[g]), dist, nn, pos);
+        }
+      }
+    }
+  static const int PA[4] = {HRG_HG_HEAD, HRG_HG_HANDLE, HRG_HG_HEAD, HRG_HG_HANDLE}, PB[4] = {HRG_HG_NAIL, HRG_HG_NAIL, HRG_HG_BOARD, HRG_HG_BOARD};
+  for (int q = 0; q < 4; q++) {
+    const int ga = PA[q], gb = PB[q];
+    const double *ha = m->hm_geom_half[ga], *hb = m->hm_geom_half[gb];
+    double d[3];
+    v3sub(d, G->c[gb], G->c[ga]);
+    const double ra = sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]), rb = sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]);
+    if (v3dot(d, d) > (ra + rb) * (ra + rb)) continue; /* circumspheres apart */
+    bb_contact bc[4];
+    const int nc = box_box2(G->c[ga], G->R[1], ha, G->c[gb], G->R[0], hb, bc);
+    for (int z = 0; z < nc; z++) EMIT(GEOM_HM(ga), GEOM_HM(gb), BODY_HM(HRG_HM_HAMMER), BODY_HM(HM_GEOM_BODY[gb]), bc[z].dist, bc[z].n, bc[z].pos);
+  }
+  for (int q = 0; q < n_second; q++) {
+    const int i = second_i[q], g = second_g[q];
+    double nn[3], pos[3];
+    v3sub(nn, second_b[q], second_s[q]);
+    const double dd = v3norm(nn), dist = dd - m->rcap_r[i];
+    v3scl(nn, nn, 1.0 / dd);
+    v3madd(pos, second_s[q], nn, m->rcap_r[i] + 0.5 * dist);
+    EMIT(i, GEOM_HM(g), m->rcap_body[i], BODY_HM(HM_GEOM_BODY[g]), dist, nn, pos);
+  }
+#undef EMIT
+  hm->gripped = f0 && f1;
+  return n;
+}
+
+/* _update_mocap_body_transforms (688-715): each mocap body sits at its hand site, rotated like the hand body turned by -90 deg (left) / +90 deg (right)
+ * about its y axis */
+static void hammer_mocap(const hrg_model_desc* m, const hrg_env_state* s, hrg_hammer_state* hm, const human_kin* hk) {
+  for (int hd = 0; hd < 2; hd++) {
+    const int site = hd == 0 ? m->site_lhand : m->site_rhand, body = m->meas_body[site];
+    const double ang = hd == 0 ? -0.5 * PI : 0.5 * PI, c = cos(ang), sn = sin(ang);
+    const double Ry[9] = {c, 0, sn, 0, 1, 0, -sn, 0, c};
+    double R[9];
+    v3cpy(hm->mocap_pos[hd], s->human_site[site]);
+    m3mul(R, hk->R[body], Ry);
+    mat2quat(hm->mocap_quat[hd], R);
+  }
+}
+/* orientation the weld rh_eq wants for the board: mocap = board o relpose  =>  q_board = q_mocap o relquat^-1 (1123-1131) */
+static void hammer_weld_quat(const hrg_model_desc* m, const hrg_hammer_state* hm, double* qt) {
+  const double qi[4] = {m->hm_weld_relquat[0], -m->hm_weld_relquat[1], -m->hm_weld_relquat[2], -m->hm_weld_relquat[3]};
+  quatmul(qt, hm->mocap_quat[1], qi);
+}
+/* _reset_board (769-779) + _human_take_board_from_table (831-835).  The reference puts the board on the table and lets the soft weld / connect drag it into
+ * the hands over the next substeps; here it is put where the weld holds it, at rest (DESIGN.md D14's choice).  _reset_nail (781-788): pulled out. */
+static void hammer_take_board(const hrgo_batch* B, int64_t gid, const hrg_env_state* s, hrg_hammer_state* hm) {
+  const hrg_model_desc* m = &B->m;
+  double Rt[9], t[3];
+  hammer_weld_quat(m, hm, hm->quat[0]);
+  quat2mat(Rt, hm->quat[0]);
+  m3mulv(t, Rt, m->hm_anchor[1]);
+  v3sub(hm->pos[0], hm->mocap_pos[1], t);
+  for (int a = 0; a < 6; a++) { hm->vel[0][a] = 0; hm->acc_warmstart[0][a] = 0; }
+  hm->nail_q = 0; hm->nail_v = 0; hm->nail_acc_warmstart = 0;
+  /* nail_placements[index]: UniformRandomSampler over the board (889-960), drawn counter-based on demand (D6) */
+  hm->nail_xy[0] = m->hm_nail_bin[0] + (m->hm_nail_bin[1] - m->hm_nail_bin[0]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_OBJECT, (uint64_t)(2 * hm->nail_index));
+  hm->nail_xy[1] = m->hm_nail_bin[2] + (m->hm_nail_bin[3] - m->hm_nail_bin[2]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_OBJECT, (uint64_t)(2 * hm->nail_index + 1));
+}
+static void hammer_obs_pos(const hrg_model_desc* m, hrg_hammer_state* hm) { /* body_xpos of board_main, the hammer's root body, nail_head */
+  hammer_geo G;
+  hammer_geometry(m, hm, &G);
+  double t[3];
+  v3cpy(hm->obs_pos[0], hm->pos[0]);
+  m3mulv(t, G.R[1], m->hm_hammer_com); v3sub(hm->obs_pos[1], hm->pos[1], t);
+  v3cpy(hm->obs_pos[2], G.nail_org);
+}
+
+/* _setup_observables (1151-1323) in the columns of the observation superset: hammer_quat (w, x, y, z as body_xquat gives it) 12:16, board_pos 33:36,
+ * vec_eef_to_board 36:39, hammer_gripped 39, vec_eef_to_hammer 40:43, vec_eef_to_nail 43:46, gripper_aperture 46, hammer_pos 47:50, nail_pos 50:53,
+ * board_quat (x, y, z, w) 57:61, nail_hammering_progress 61.  quat_eef_to_hammer / quat_eef_to_board look "object_quat" up in the observation cache,
+ * which this env never fills: constant zeros (1217-1225, 1259-1267), served by the host. */
+static void compute_obs_hammer(const hrgo_batch* B, const hrg_env_state* s, const hrg_hammer_state* hm, float* obs) {
+  const hrg_model_desc* m = &B->m;
+  double goal[NARM] = {0};
+  compute_obs(m, s, NULL, goal, obs);
+  for (int j = 0; j < NARM; j++) { obs[12 + j] = 0.0f; obs[33 + j] = 0.0f; }
+  for (int a = 0; a < 4; a++) obs[12 + a] = (float)hm->quat[1][a];
+  obs[39] = (float)hm->gripped;
+  double ap = 0;
+  for (int f = 0; f < HRG_NFINGER; f++) ap += (s->qpos[NARM + f] - m->finger_qpos_range[0][f]) / (m->finger_qpos_range[1][f] - m->finger_qpos_range[0][f]);
+  obs[46] = (float)(ap / HRG_NFINGER);
+  for (int a = 0; a < 3; a++) {
+    obs[33 + a] = (float)hm->obs_pos[0][a];
+    obs[36 + a] = (float)(hm->obs_pos[0][a] - s->eef_pos[a]);
+    obs[40 + a] = (float)(hm->obs_pos[1][a] - s->eef_pos[a]);
+    obs[43 + a] = (float)(hm->obs_pos[2][a] - s->eef_pos[a]);
+    obs[47 + a] = (float)hm->obs_pos[1][a];
+    obs[50 + a] = (float)hm->obs_pos[2][a];
+    obs[57 + a] = (float)hm->quat[0][1 + a];
+  }
+  obs[60] = (float)hm->quat[0][0];
+  obs[61] = (float)clampd(hm->nail_q / m->hm_nail_range, 0.0, 1.0);
+}
+
+/* CollaborativeHammeringCart._reset_internal (717-747) after the common part of env_reset */
+static void env_reset_hammer(hrgo_batch* B, int e, const robot_kin* k) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  hrg_hammer_state* hm = &B->hmr[e];
+  const int64_t gid = B->env_id0 + e;
+  (void)k;
+  memset(hm, 0, sizeof *hm);
+  hm->quat[0][0] = 1;
+  human_kin hk;
+  double mp[3], mq[4], Rg[9], t[3];
+  const double* qh;
+  human_control_all(B, gid, s, NULL, NULL, hm, mp, mq, &qh); /* _control_human + _reset_animation: phase APPROACH (memset), the human holds the board */
+  human_fk(m, mp, mq, qh, &hk, s->human_site);
+  hammer_mocap(m, s, hm, &hk);
+  hammer_take_board(B, gid, s, hm);
+  /* _put_hammer_into_gripper (790-812): the hammer's root body at the grip site, turned 90 deg about y; at rest */
+  for (int a = 0; a < 4; a++) hm->quat[1][a] = m->hm_hammer_grip_quat[a];
+  quat2mat(Rg, hm->quat[1]);
+  m3mulv(t, Rg, m->hm_hammer_com);
+  v3add(hm->pos[1], s->eef_pos, t);
+  hammer_obs_pos(m, hm);
+}
+
+/* mass matrix (row-major 8 x 8, the pad DoF with a unit diagonal) and applied force of the board + nail subtree: the board as a free body with world-frame
+ * angular velocity, the nail head as a point mass at r = R rho(q) that slides along a = -R e_z:  v_nail = v + w x r + a qd */
+static void hammer_board_block(const hrg_model_desc* m, const hrg_hammer_state* hm, const hammer_geo* G, double* M8, double* f8) {
+  const double mb = m->hm_board_mass, mn = m->hm_nail_mass;
+  const double* R = G->R[0];
+  double r[3], Iw[9], w[3] = {hm->vel[0][3], hm->vel[0][4], hm->vel[0][5]}, Lw[3], gy[3], c[3], t1[3], t2[3], rxa[3], rxg[3], rxc[3];
+  v3sub(r, G->c[HRG_HG_NAIL], hm->pos[0]);
+  for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int kk = 0; kk < 3; kk++) t += R[3 * i + kk] * m->hm_board_inertia[kk] * R[3 * j + kk]; Iw[3 * i + j] = t; }
+  m3mulv(Lw, Iw, w);
+  v3cross(gy, Lw, w); /* -(w x I w) */
+  v3cross(t1, w, r); v3cross(t1, w, t1); /* w x (w x r) */
+  v3cross(t2, w, G->axis); /* w x a */
+  for (int a = 0; a < 3; a++) c[a] = t1[a] + 2.0 * hm->nail_v * t2[a];
+  v3cross(rxa, r, G->axis); v3cross(rxg, r, m->gravity); v3cross(rxc, r, c);
+  memset(M8, 0, sizeof(double) * 64);
+  const double rr = v3dot(r, r);
+  const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0}; /* [r]x */
+  for (int i = 0; i < 3; i++) {
+    M8[i * 8 + i] = mb + mn;
+    for (int j = 0; j < 3; j++) {
+      M8[i * 8 + 3 + j] = -mn * rx[3 * i + j];
+      M8[(3 + i) * 8 + j] = mn * rx[3 * i + j];
+      M8[(3 + i) * 8 + 3 + j] = Iw[3 * i + j] + mn * ((i == j ? rr : 0.0) - r[i] * r[j]);
+    }
+    M8[i * 8 + 6] = M8[6 * 8 + i] = mn * G->axis[i];
+    M8[(3 + i) * 8 + 6] = M8[6 * 8 + 3 + i] = mn * rxa[i];
+    f8[i] = (mb + mn) * m->gravity[i] - mn * c[i];
+    f8[3 + i] = gy[i] + mn * rxg[i] - mn * rxc[i];
+  }
+  M8[6 * 8 + 6] = mn;
+  M8[7 * 8 + 7] = 1.0;
+  f8[6] = mn * v3dot(G->axis, m->gravity) - mn * v3dot(G->axis, c);
+  f8[7] = 0.0;
+}
+
+static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+  const hrg_model_desc* m = &B->m;
+  hrg_env_state* s = &B->st[e];
+  hrg_hammer_state* hm = &B->hmr[e];
+  int64_t gid = s->stream_id;
+  const double h = m->timestep;
+  if (m->ik_enabled) ik_action(m, s, action);
+  screen_action(B, gid, s, action);
+  if (!m->gripper_controllable) action[NARM] = 1; /* CollaborativeHammeringCart.step (486-487): always close the gripper */
+  s->timestep += 1;
+  int has_collision = 0, collision_type = HRG_COL_NULL, failsafe_intervention = 0, crash = 0;
+  robot_kin k;
+  human_kin hk;
+  double M[NV * NV], bias[NV];
+  for (int cyc = 0; cyc < m->n_cycles && !crash; cyc++) {
+    robot_fk(m, s->qpos, &k);
+    robot_crba(m, &k, M);
+    robot_bias(m, &k, s->qvel, bias);
+    if (cyc == 0) { /* failsafe_controller.py:252-300 */
+      for (int i = 0; i < NARM; i++) for (int j = 0; j < NARM; j++) s->mass_matrix[i * NARM + j] = M[i * NV + j];
+      double scale = fabs(m->act_out_max - m->act_out_min) / fabs(m->act_in_max - m->act_in_min);
+      double otr = 0.5 * (m->act_out_max + m->act_out_min), itr = 0.5 * (m->act_in_max + m->act_in_min);
+      for (int j = 0; j < NARM; j++) {
+        double a = clampd(action[j], m->act_in_min, m->act_in_max);
+        double g = s->qpos[j] + ((a - itr) * scale + otr);
+        s->goal_qpos[j] = clampd(g, m->qpos_limits[0][j], m->qpos_limits[1][j]);
+        s->new_goal_q[j] = s->goal_qpos[j];
+      }
+      s->new_goal = 1;
+    }
+    shield_step(B, e, s->time);
+    double ctrl[NV];
+    for (int i = 0; i < NARM; i++) {
+      double t = 0;
+      for (int j = 0; j < NARM; j++) t += s->mass_matrix[i * NARM + j] * (m->kp * (s->des_q[j] - s->qpos[j]) + m->kd * (s->des_v[j] - s->qvel[j]) + s->des_a[j]);
+      ctrl[i] = clampd(t + bias[i], m->arm_ctrlrange[i][0], m->arm_ctrlrange[i][1]);
+    }
+    {
+      double a = action[NARM], sg = a > 0 ? 1.0 : (a < 0 ? -1.0 : 0.0);
+      s->grip_action = clampd(s->grip_action - m->gripper_speed * sg, -1.0, 1.0);
+      for (int f = 0; f < HRG_NFINGER; f++) {
+        double lo = m->finger_ctrlrange[f][0], hi = m->finger_ctrlrange[f][1];
+        ctrl[NARM + f] = 0.5 * (hi + lo) + 0.5 * (hi - lo) * (f == 0 ? s->grip_action : -s->grip_action);
+      }
+    }
+    if (!failsafe_intervention && !s->is_safe) { failsafe_intervention = 1; s->failsafe_interventions++; }
+    /* _control_human (682-686): super + sim.forward() + the two hand mocap bodies */
+    double mp[3], mq[4];
+    const double* qh;
+    human_control_all(B, gid, s, NULL, NULL, hm, mp, mq, &qh);
+    human_fk(m, mp, mq, qh, &hk, s->human_site);
+    hammer_mocap(m, s, hm, &hk);
+    hammer_geo G;
+    hammer_geometry(m, hm, &G);
+    contact_t con[HRG_NCON_MAX];
+    int ncon = collide_hammer(m, &k, &hk, hm, &G, con);
+    double rc[HRG_NRCAP][3], Rb[9];
+    quat2mat(Rb, m->base_quat);
+    for (int c = 0; c < HRG_NRCAP; c++) {
+      int b = m->rcap_body[c];
+      double t[3], mid[3];
+      for (int a = 0; a < 3; a++) mid[a] = 0.5 * (m->rcap_p1[c][a] + m->rcap_p2[c][a]);
+      m3mulv(t, b < 0 ? Rb : k.R[b], mid);
+      v3add(rc[c], b < 0 ? m->base_pos : k.p[b], t);
+    }
+    classify(m, &k, s, con, ncon, rc, &has_collision, &collision_type);
+    s->ncon = ncon;
+    for (int c = 0; c < HRG_NCON_MAX; c++) { s->con_pairs[c][0] = c < ncon ? con[c].g1 : -1; s->con_pairs[c][1] = c < ncon ? con[c].g2 : -1; }
+    /* ---- sim.step(): robot tree | board + nail | hammer ---- */
+    double LM[NV * NV], a0[NVH], qd[NVH], frc[NV], Mt[NVH * NVH], M8[64], f8[8];
+    memcpy(LM, M, sizeof LM);
+    if (!chol(LM, NV)) { crash = 1; break; }
+    memset(Mt, 0, sizeof Mt);
+    memset(a0, 0, sizeof a0);
+    memset(qd, 0, sizeof qd);
+    for (int i = 0; i < NV; i++) {
+      double act = ctrl[i];
+      if (i >= NARM) act = clampd(m->finger_kp * (ctrl[i] - s->qpos[i]), m->finger_forcerange[0], m->finger_forcerange[1]);
+      frc[i] = act - m->jnt_damping[i] * s->qvel[i] - bias[i];
+      a0[i] = frc[i];
+      qd[i] = s->qvel[i];
+    }
+    chol_solve(LM, NV, a0);
+    for (int i = 0; i < NV; i++) for (int j = 0; j < NV; j++) Mt[i * NVH + j] = M[i * NV + j];
+    hammer_board_block(m, hm, &G, M8, f8);
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) Mt[(HM_OB + i) * NVH + HM_OB + j] = M8[8 * i + j];
+    {
+      double L8[64], x8[8];
+      memcpy(L8, M8, sizeof L8); memcpy(x8, f8, sizeof x8);
+      if (!chol(L8, 8)) { crash = 1; break; }
+      chol_solve(L8, 8, x8);
+      for (int i = 0; i < 8; i++) a0[HM_OB + i] = x8[i];
+    }
+    { /* the hammer: free body, M = blockdiag(m 1, R diag(I) R'), gyroscopic torque -(w x I w), gravity */
+      const double* R = G.R[1];
+      double Iw[9], w[3] = {hm->vel[1][3], hm->vel[1][4], hm->vel[1][5]}, Lw[3], tau[3], tl[3];
+      for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { double t = 0; for (int kk = 0; kk < 3; kk++) t += R[3 * i + kk] * m->hm_hammer_inertia[kk] * R[3 * j + kk]; Iw[3 * i + j] = t; }
+      m3mulv(Lw, Iw, w);
+      v3cross(tau, Lw, w);
+      for (int kk = 0; kk < 3; kk++) tl[kk] = (R[kk] * tau[0] + R[3 + kk] * tau[1] + R[6 + kk] * tau[2]) / m->hm_hammer_inertia[kk];
+      for (int a = 0; a < 3; a++) {
+        Mt[(HM_OH + a) * NVH + HM_OH + a] = m->hm_hammer_mass;
+        for (int b_ = 0; b_ < 3; b_++) Mt[(HM_OH + 3 + a) * NVH + HM_OH + 3 + b_] = Iw[3 * a + b_];
+        a0[HM_OH + a] = m->gravity[a];
+        a0[HM_OH + 3 + a] = R[3 * a] * tl[0] + R[3 * a + 1] * tl[1] + R[3 * a + 2] * tl[2];
+      }
+      Mt[(HM_OH + 6) * NVH + HM_OH + 6] = 1.0; Mt[(HM_OH + 7) * NVH + HM_OH + 7] = 1.0;
+    }
+    for (int a = 0; a < 6; a++) { qd[HM_OB + a] = hm->vel[0][a]; qd[HM_OH + a] = hm->vel[1][a]; }
+    qd[HM_ON] = hm->nail_v;
+    efc_t* E = (efc_t*)malloc(sizeof(efc_t));
+    E->n = 0;
+    E->nv = NVH;
+    for (int i = 0; i < NV; i++)
+      if (m->jnt_frictionloss[i] > 0) { double J[NVMAX] = {0}; J[i] = 1; efc_add(m, E, J, qd, ROW_FRICTION, 0, 0, m->jnt_frictionloss[i], m->dof_invweight0[i]); }
+    if (m->hm_nail_frictionloss > 0) { /* nail_head_joint0: frictionloss with its own solreffriction (nail.xml:7) */
+      double J[NVMAX] = {0}; J[HM_ON] = 1;
+      efc_add_b(m, E, J, qd, ROW_FRICTION, 0, 0, m->hm_nail_frictionloss, m->hm_nail_invweight, m->hm_nail_fric_damping / m->solimp[1]);
+    }
+    for (int i = 0; i < NV; i++) {
+      double dlo = s->qpos[i] - m->jnt_range[i][0], dhi = m->jnt_range[i][1] - s->qpos[i];
+      if (dlo < 0) { double J[NVMAX] = {0}; J[i] = 1; efc_add(m, E, J, qd, ROW_UNILATERAL, dlo, 0, 0, m->dof_invweight0[i]); }
+      if (dhi < 0) { double J[NVMAX] = {0}; J[i] = -1; efc_add(m, E, J, qd, ROW_UNILATERAL, dhi, 0, 0, m->dof_invweight0[i]); }
+    }
+    { /* the slide joint's range [0, hm_nail_range] */
+      double dlo = hm->nail_q, dhi = m->hm_nail_range - hm->nail_q;
+      if (dlo < 0) { double J[NVMAX] = {0}; J[HM_ON] = 1; efc_add(m, E, J, qd, ROW_UNILATERAL, dlo, 0, 0, m->hm_nail_invweight); }
+      if (dhi < 0) { double J[NVMAX] = {0}; J[HM_ON] = -1; efc_add(m, E, J, qd, ROW_UNILATERAL, dhi, 0, 0, m->hm_nail_invweight); }
+    }
+    for (int c = 0; c < ncon && c < HRG_NCON_DYN_HAMMER; c++) {
+      const double* n = con[c].n;
+      double t1[3], t2[3], e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+      v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+      v3scl(t1, t1, 1.0 / v3norm(t1));
+      v3cross(t2, n, t1);
+      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      for (int d = 0; d < 4; d++) {
+        double dir[3], J[NVMAX] = {0};
+        const double* tt = d < 2 ? t1 : t2;
+        double sg = (d & 1) ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m->friction_static * tt[a];
+        if (con[c].b1 >= 0 && con[c].b1 < NV) robot_point_jac(m, &k, con[c].b1, con[c].pos, dir, -1.0, J);
+        if (con[c].b2 >= 0 && con[c].b2 < NV) robot_point_jac(m, &k, con[c].b2, con[c].pos, dir, +1.0, J);
+        double diag = (con[c].b1 >= 0 && con[c].b1 < NV ? m->body_invweight0[con[c].b1] : 0.0) + (con[c].b2 >= 0 && con[c].b2 < NV ? m->body_invweight0[con[c].b2] : 0.0);
+        for (int side = 0; side < 2; side++) { /* free bodies: J = +-dir . (v + w x r); the nail's point moves with the board and along the slide axis */
+          const int body = side ? con[c].b2 : con[c].b1;
+          if (body < BODY_BOX) continue;
+          const int fb = body - BODY_BOX, o = fb == HRG_HM_HAMMER ? HM_OH : HM_OB;
+          const double sgn = side ? 1.0 : -1.0;
+          double r[3], rxd[3];
+          v3sub(r, con[c].pos, hm->pos[fb == HRG_HM_HAMMER ? 1 : 0]);
+          v3cross(rxd, r, dir);
+          for (int a = 0; a < 3; a++) { J[o + a] = sgn * dir[a]; J[o + 3 + a] = sgn * rxd[a]; }
+          if (fb == HRG_HM_NAIL) { J[HM_ON] = sgn * v3dot(dir, G.axis); diag += m->hm_nail_invweight; }
+          else diag += 1.0 / (fb == HRG_HM_HAMMER ? m->hm_hammer_mass : m->hm_board_mass);
+        }
+        efc_add(m, E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
+      }
+    }
+    { /* lh_eq: connect(lh_grip, lh_mocap); rh_eq: weld(rh_grip, rh_mocap) (1100-1145); both stay active (the switch to rh_backup_eq is commented out, 650) */
+      const double* R = G.R[0];
+      for (int hd = 0; hd < 2; hd++) {
+        double rr[3], pt[3];
+        m3mulv(rr, R, m->hm_anchor[hd]);
+        v3add(pt, hm->pos[0], rr);
+        for (int a = 0; a < 3; a++) {
+          double J[NVMAX] = {0}, ea[3] = {a == 0, a == 1, a == 2}, rxe[3];
+          v3cross(rxe, rr, ea);
+          J[HM_OB + a] = 1;
+          for (int b_ = 0; b_ < 3; b_++) J[HM_OB + 3 + b_] = rxe[b_];
+          efc_add(m, E, J, qd, ROW_EQUALITY, pt[a] - hm->mocap_pos[hd][a], 0, 0, 1.0 / m->hm_board_mass);
+        }
+      }
+      double qt[4], qe[4], erot[3];
+      hammer_weld_quat(m, hm, qt);
+      const double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
+      quatmul(qe, hm->quat[0], qc);
+      if (qe[0] < 0) for (int a = 0; a < 4; a++) qe[a] = -qe[a];
+      const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+      for (int a = 0; a < 3; a++) erot[a] = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
+      for (int a = 0; a < 3; a++) { double J[NVMAX] = {0}; J[HM_OB + 3 + a] = 1; efc_add(m, E, J, qd, ROW_EQUALITY, erot[a], 0, 0, m->hm_board_invweight_rot); }
+    }
+    double qacc[NVH];
+    memset(qacc, 0, sizeof qacc);
+    memcpy(qacc, s->qacc_warmstart, sizeof(double) * NV);
+    for (int a = 0; a < 6; a++) { qacc[HM_OB + a] = hm->acc_warmstart[0][a]; qacc[HM_OH + a] = hm->acc_warmstart[1][a]; }
+    qacc[HM_ON] = hm->nail_acc_warmstart;
+    solve(m, Mt, a0, E, qacc);
+    if (g_debug && (ncon > 0 || g_debug > 1)) {
+      double mx = 0; for (int i = 0; i < NVH; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
+      fprintf(stderr, "[oracle hammer] env %d cyc %d ncon %d nefc %d max|qacc| %.3e", e, cyc, ncon, E->n, mx);
+      for (int c = 0; c < ncon; c++) fprintf(stderr, " (%d,%d d=%.5f)", con[c].g1, con[c].g2, con[c].dist);
+      fprintf(stderr, "\n");
+    }
+    free(E);
+    for (int i = 0; i < NVH; i++) if (!(fabs(qacc[i]) < 1e10)) crash = 1;
+    if (crash) break;
+    memcpy(s->qacc_warmstart, qacc, sizeof(double) * NV);
+    double Mh[NV * NV], rhs[NV];
+    memcpy(Mh, M, sizeof Mh);
+    for (int i = 0; i < NV; i++) { Mh[i * NV + i] += h * m->jnt_damping[i]; double t = 0; for (int j = 0; j < NV; j++) t += M[i * NV + j] * qacc[j]; rhs[i] = t; }
+    if (!chol(Mh, NV)) { crash = 1; break; }
+    chol_solve(Mh, NV, rhs);
+    for (int i = 0; i < NV; i++) { s->qvel[i] += h * rhs[i]; s->qpos[i] += h * s->qvel[i]; }
+    hammer_obs_pos(m, hm); /* body_xpos of the forward pass inside mj_step (pre-integration) */
+    for (int fb = 0; fb < 2; fb++) {
+      const int o = fb ? HM_OH : HM_OB;
+      for (int a = 0; a < 6; a++) { hm->acc_warmstart[fb][a] = qacc[o + a]; hm->vel[fb][a] += h * qacc[o + a]; }
+      for (int a = 0; a < 3; a++) hm->pos[fb][a] += h * hm->vel[fb][a];
+      double w[3] = {hm->vel[fb][3], hm->vel[fb][4], hm->vel[fb][5]}, wn = v3norm(w), ang = h * wn;
+      if (wn > 1e-12) {
+        double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w[0] * sh, w[1] * sh, w[2] * sh}, qn[4];
+        quatmul(qn, dq, hm->quat[fb]);
+        double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (int a = 0; a < 4; a++) hm->quat[fb][a] = qn[a] / nn;
+      }
+    }
+    hm->nail_acc_warmstart = qacc[HM_ON];
+    hm->nail_v += h * qacc[HM_ON];
+    hm->nail_q += h * hm->nail_v;
+    s->time += h;
+    eef_of(m, &k, s->eef_pos);
+    s->low_level_time += 1;
+  }
+  /* ---- observation, success, info, reward, done ---- */
+  compute_obs_hammer(B, s, hm, term_obs);
+  const double progress = clampd(hm->nail_q / m->hm_nail_range, 0.0, 1.0); /* nail_hammering_progress (1291-1303) */
+  const int hammered_in = 1.0 - progress < m->hm_goal_tolerance; /* _check_nail_hammered_in (505-520) */
+  const int goal_reached = !crash && hm->task_phase == HRG_HM_COMPLETE; /* _check_success (576-587) */
+  double r;
+  if (goal_reached) r = m->task_reward; /* _sparse_reward (522-556) */
+  else {
+    r = hammered_in ? m->nail_hammered_in_reward : -1.0;
+    if (hm->gripped) r += m->hammer_gripped_reward_bonus;
+  }
+  if (goal_reached) s->n_goal_reached++;
+  int illegal = (collision_type & (HRG_COL_STATIC | HRG_COL_ROBOT | HRG_COL_HUMAN_CRIT)) != 0;
+  if (m->reward_shaping) r += 1.0 + 0.0; /* _dense_reward is a TODO returning 0 (558-574) */
+  if (illegal) r += m->collision_reward;
+  r *= m->reward_scale;
+  int d = 0;
+  if (crash) { r += m->sim_crash_reward; d = 1; }
+  else {
+    if (m->done_at_collision && illegal) d = 1;
+    if (m->done_at_success && goal_reached) d = 1;
+  }
+  int ncoll = s->n_collisions_static + s->n_collisions_robot + s->n_collisions_human + s->n_collisions_critical;
+  info[HRG_INFO_COLLISION] = has_collision;
+  info[HRG_INFO_COLLISION_TYPE] = collision_type;
+  info[HRG_INFO_N_COLLISIONS] = ncoll;
+  info[HRG_INFO_N_COLLISIONS_STATIC] = s->n_collisions_static;
+  info[HRG_INFO_N_COLLISIONS_ROBOT] = s->n_collisions_robot;
+  info[HRG_INFO_N_COLLISIONS_HUMAN] = s->n_collisions_human;
+  info[HRG_INFO_N_COLLISIONS_CRITICAL] = s->n_collisions_critical;
+  info[HRG_INFO_TIMEOUT] = s->timestep >= m->horizon;
+  info[HRG_INFO_FAILSAFE_INTERVENTIONS] = s->failsafe_interventions;
+  info[HRG_INFO_N_GOAL_REACHED] = s->n_goal_reached;
+  info[HRG_INFO_SIM_CRASH] = crash;
+  info[HRG_INFO_TRUNCATED] = 0;
+  info[HRG_INFO_ACTION_RESAMPLES] = s->action_resamples;
+  info[HRG_INFO_N_OBJECT_HANDED_OVER] = 0;
+  /* ---- CollaborativeHammeringCart.step tail (490-503) ---- */
+  if (goal_reached && !m->done_at_success && !d) { /* _on_goal_reached (749-767): next nail placement, board and nail reset, next animation */
+    hm->nail_index = (hm->nail_index + 1) % m->n_obj_placements;
+    s->anim_index = (s->anim_index + 1) % m->n_anim_ids;
+    s->animation_time = 0;
+    s->anim_start_time = (int)((double)s->low_level_time / m->anim_step_length);
+    hm->task_phase = HRG_HM_APPROACH; hm->n_delayed = 0;
+    human_kin hk2;
+    double mp[3], mq[4];
+    const double* qh;
+    human_control_all(B, gid, s, NULL, NULL, hm, mp, mq, &qh);
+    human_fk(m, mp, mq, qh, &hk2, s->human_site);
+    hammer_mocap(m, s, hm, &hk2);
+    hm->task_phase = HRG_HM_APPROACH; hm->n_delayed = 0; /* _reset_animation (764-767, 770-774) */
+    hammer_take_board(B, gid, s, hm);
+  }
+  if (!d && hm->task_phase == HRG_HM_PRESENT && hammered_in) hm->task_phase = HRG_HM_RETREAT; /* 496-501 */
+  if (s->timestep >= m->horizon) { info[HRG_INFO_TRUNCATED] = !d; d = 1; }
+  *reward = (float)r;
+  *done = (uint8_t)d;
+  if (d) env_reset(B, e, obs);
+  else memcpy(obs, term_obs, sizeof(float) * HRG_OBS_DIM);
+}
+
 /* =============================================================================================== API */
 int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, hrgo_batch** out) {
   hrgo_batch* B = (hrgo_batch*)calloc(1, sizeof *B);
@@ -2762,6 +3348,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
   B->st = (hrg_env_state*)calloc((size_t)n_envs, sizeof(hrg_env_state));
   B->box = (hrg_box_state*)calloc((size_t)n_envs, sizeof(hrg_box_state));
   B->stk = (hrg_stack_state*)calloc((size_t)n_envs, sizeof(hrg_stack_state));
+  B->hmr = (hrg_hammer_state*)calloc((size_t)n_envs, sizeof(hrg_hammer_state));
   B->rcaps = calloc((size_t)n_envs, sizeof *B->rcaps);
   B->hcaps = calloc((size_t)n_envs, sizeof *B->hcaps);
   B->n_hcaps = calloc((size_t)n_envs, sizeof(int32_t));
@@ -2771,7 +3358,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
 }
 void hrgo_destroy(hrgo_batch* B) {
   if (!B) return;
-  free(B->frames); free(B->st); free(B->box); free(B->stk); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
+  free(B->frames); free(B->st); free(B->box); free(B->stk); free(B->hmr); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
 }
 int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
   for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
@@ -2854,6 +3441,16 @@ int hrgo_get_stack(hrgo_batch* B, int e, void* buf, size_t bytes) {
   memcpy(buf, &B->stk[e], bytes);
   return 0;
 }
+int hrgo_get_hammer(hrgo_batch* B, int e, void* buf, size_t bytes) {
+  if (e < 0 || e >= B->n_envs || bytes != sizeof(hrg_hammer_state)) return -1;
+  memcpy(buf, &B->hmr[e], bytes);
+  return 0;
+}
+int hrgo_set_hammer(hrgo_batch* B, int e, const void* buf, size_t bytes) {
+  if (e < 0 || e >= B->n_envs || bytes != sizeof(hrg_hammer_state)) return -1;
+  memcpy(&B->hmr[e], buf, bytes);
+  return 0;
+}
 int hrgo_set_stack(hrgo_batch* B, int e, const void* buf, size_t bytes) {
   if (bytes != sizeof(hrg_stack_state)) return -1;
   memcpy(&B->stk[e], buf, bytes);
@@ -2873,6 +3470,15 @@ size_t hrgo_state_bytes(void) { return sizeof(hrg_env_state); }
 size_t hrgo_box_bytes(void) { return sizeof(hrg_box_state); }
 size_t hrgo_desc_bytes(void) { return sizeof(hrg_model_desc); }
 /* HumanEnv.check_collision_action for every env (human_env.py:588-627): goal configuration of the action at the current joint angles -> pre-check model */
+/* two boxes with different half extents: out = n x [pos 3 | normal 3 | dist] */
+int hrgo_test_boxbox2(const double* pa, const double* qa, const double* ha, const double* pb, const double* qb, const double* hb, double* out) {
+  double Ra[9], Rb[9];
+  bb_contact bc[4];
+  quat2mat(Ra, qa); quat2mat(Rb, qb);
+  const int n = box_box2(pa, Ra, ha, pb, Rb, hb, bc);
+  for (int z = 0; z < n; z++) { for (int a = 0; a < 3; a++) { out[7 * z + a] = bc[z].pos[a]; out[7 * z + 3 + a] = bc[z].n[a]; } out[7 * z + 6] = bc[z].dist; }
+  return n;
+}
 int hrgo_check_actions(hrgo_batch* B, const double* actions, uint8_t* collides) {
   for (int e = 0; e < B->n_envs; e++) collides[e] = (uint8_t)(action_collides(&B->m, &B->st[e], actions + (size_t)e * HRG_ACT_DIM) != 0);
   return 0;

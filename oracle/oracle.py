@@ -102,6 +102,15 @@ class OracleBatch:
     def set_box(self, e, s):
         assert self.lib.hrgo_set_box(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
 
+    def get_hammer(self, e):
+        from human_robot_gym_amd._cstruct import HammerState
+        s = HammerState()
+        assert self.lib.hrgo_get_hammer(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+        return s
+
+    def set_hammer(self, e, s):
+        assert self.lib.hrgo_set_hammer(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0
+
     def get_stack(self, e):
         from human_robot_gym_amd._cstruct import StackState
         s = StackState()

@@ -19,6 +19,8 @@ from make_golden import clips_for as _clips, object_rows  # noqa: E402
 def _desc(name, clips):
     kw = dict(CASES[name])
     env_id = kw.pop("env_id", "ReachHuman")
+    from human_robot_gym_amd.mixed import task_env_kwargs
+    kw.update(task_env_kwargs(env_id))
     return hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=env_id), env_id
 
 

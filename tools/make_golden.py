@@ -29,6 +29,8 @@ CASES = {
     "lifting_ssm": dict(env_id="CollaborativeLiftingCart", shield_type="SSM", horizon=60),
     # four free cubes: two resting on the table, two welded to the hands; the human drops its first cube at its keyframe (it falls to the table / floor)
     "stacking_ssm": dict(env_id="CollaborativeStackingCart", shield_type="SSM", horizon=60),
+    # board (weld + connect to the hands) with the nail on its slide joint, hammer in the closed gripper; the nail creeps in under its own weight
+    "hammering_ssm": dict(env_id="CollaborativeHammeringCart", shield_type="SSM", horizon=60),
 }
 # cases whose free-running GPU rollout is compared against the fixture (tests/test_golden.py): all of them
 GPU_CASES = list(CASES)
@@ -40,6 +42,11 @@ def object_rows(B, env_id, n):
         sks = [B.get_stack(e) for e in range(n)]
         fl = [[x for c in range(4) for x in list(s.pos[c]) + list(s.quat[c]) + list(s.vel[c])] + list(s.target) for s in sks]
         it = [[s.task_phase, s.weld_active[0], s.weld_active[1], s.gripped, s.n_stack, s.max_stack_height, s.has_target] + list(s.stack_ids) for s in sks]
+        return np.array(fl), np.array(it, np.int32)
+    if env_id == "CollaborativeHammeringCart":
+        hms = [B.get_hammer(e) for e in range(n)]
+        fl = [[x for b in range(2) for x in list(h.pos[b]) + list(h.quat[b]) + list(h.vel[b])] + [h.nail_q, h.nail_v] + list(h.nail_xy) for h in hms]
+        it = [[h.task_phase, h.gripped, h.nail_index, h.n_delayed] for h in hms]
         return np.array(fl), np.array(it, np.int32)
     bxs = [B.get_box(e) for e in range(n)]
     return (np.array([list(b.pos) + list(b.quat) + list(b.vel) + list(b.target) for b in bxs]),
@@ -62,6 +69,8 @@ def run(name, kw, n_envs=8, n_steps=40, seed=11):
     clips = clips_for(name)
     kw = dict(kw)
     env_id = kw.pop("env_id", "ReachHuman")
+    from human_robot_gym_amd.mixed import task_env_kwargs
+    kw.update(task_env_kwargs(env_id))
     d = hrg.build_model_desc(kw, n_clips=clips.n_clips, env_id=env_id)
     B = OracleBatch(d, clips, n_envs)
     out = dict(obs0=B.reset())
