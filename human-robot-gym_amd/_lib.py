@@ -7,7 +7,7 @@ import ctypes
 import os
 import subprocess
 
-from ._cstruct import CONST, EnvState, BoxState, StackState, ModelDesc, ClipTable
+from ._cstruct import CONST, EnvState, BoxState, StackState, HammerState, ModelDesc, ClipTable
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libhrgym_hip.so")   # the one shipping library; no environment variable redirects it
@@ -17,22 +17,24 @@ SRC_BOX = os.path.join(_HERE, "csrc", "hrgym_box.hip")   # the same sources comp
 SRC_HO = os.path.join(_HERE, "csrc", "hrgym_handover.hip")   # ... and once more with the object <-> hand weld of the handover tasks
 SRC_LIFT = os.path.join(_HERE, "csrc", "hrgym_lift.hip")     # ... and with the connect equalities / task logic of CollaborativeLiftingCart
 SRC_STACK = os.path.join(_HERE, "csrc", "hrgym_stack.hip")   # ... and the four-cube system of CollaborativeStackingCart
+SRC_HAMMER = os.path.join(_HERE, "csrc", "hrgym_hammer.hip")  # ... and board + nail + hammer of CollaborativeHammeringCart
 
 EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
     "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box", "hrg_batch_get_states", "hrg_batch_set_states",
     "hrg_batch_check_actions", "hrg_stack_bytes", "hrg_batch_get_stack", "hrg_batch_set_stack", "hrg_batch_launch_order",
+    "hrg_hammer_bytes", "hrg_batch_get_hammer", "hrg_batch_set_hammer",
 ]
 
 
 def build_library(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
+    deps = [SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
         os.path.join(os.path.dirname(_HERE), "include", f) for f in ("hrgym.h", "hrgym_state.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH, SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK]
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-o", LIB_PATH, SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -87,6 +89,9 @@ def load_library():
     lib.hrg_box_bytes.restype = ctypes.c_size_t
     lib.hrg_batch_get_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_box.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_hammer_bytes.restype = ctypes.c_size_t
+    lib.hrg_batch_get_hammer.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_batch_set_hammer.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_stack_bytes.restype = ctypes.c_size_t
     lib.hrg_batch_get_stack.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_stack.argtypes = [vp, i32, vp, ctypes.c_size_t]
@@ -240,6 +245,15 @@ class HipBatch:
 
     def set_box(self, e, s):
         _check(self.lib, self.lib.hrg_batch_set_box(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
+
+    def get_hammer(self, e):
+        """Board, hammer, nail + task bookkeeping of env e (CollaborativeHammeringCart)."""
+        s = HammerState()
+        _check(self.lib, self.lib.hrg_batch_get_hammer(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
+        return s
+
+    def set_hammer(self, e, s):
+        _check(self.lib, self.lib.hrg_batch_set_hammer(self.h, int(e), ctypes.byref(s), ctypes.sizeof(s)))
 
     def get_stack(self, e):
         """The four cubes + task bookkeeping of env e (CollaborativeStackingCart)."""

@@ -37,8 +37,17 @@
 #ifndef HRG_STACK
 #define HRG_STACK 0   // HRG_STACK=1 (hrgym_stack.hip, HRG_BOX=0): CollaborativeStackingCart -- four free cubes, box-box contacts, two welds; its own collision tail and solver
 #endif
+#ifndef HRG_HAMMER
+#define HRG_HAMMER 0  // HRG_HAMMER=1 (hrgym_hammer.hip, HRG_BOX=0): CollaborativeHammeringCart -- board + nail + hammer, a 24-DoF system in three 8-wide blocks; its own collision tail and solver
+#endif
 #define NVT HRG_NVT
-#if HRG_STACK
+#if HRG_HAMMER
+#define NVS HRG_NV_HAMMER       // robot tree | board + nail (+ pad) | hammer (+ 2 pads)
+#define NCON_DYN HRG_NCON_DYN_HAMMER
+#define HM_OB NV                // board DoF
+#define HM_ON (NV + 6)          // nail slide joint
+#define HM_OH (NV + 8)          // hammer DoF
+#elif HRG_STACK
 #define NVS HRG_NV_STACK        // robot tree + four free joints
 #define NCON_DYN HRG_NCON_DYN_STACK
 #define NCUBE HRG_NCUBE
@@ -185,7 +194,17 @@ struct Contact {
 // constraint-row slots (lanes): 0..7 friction loss | 8..23 joint limits (dof, lo/hi) | 24.. contacts x 4 pyramid edges
 #define ROW_CON0 24
 #define ROW_WELD0 (ROW_CON0 + 4 * NCON_DYN)   // 6 equality rows of the object <-> hand weld (cube variant: lanes 56..61)
-#if HRG_STACK
+#if HRG_HAMMER
+// hammering: two rows per lane -- 0..7 friction loss of the robot tree | 8 of the nail's slide joint | 9..24 robot joint limits | 25, 26 the nail's range |
+// 27..29 connect at the left hand, 30..35 weld at the right hand | 36..115 contacts x 4 pyramid edges
+#define HROW_NFRIC 8
+#define HROW_LIM0 9
+#define HROW_NLIM 25
+#define HROW_EQ0 27
+#define HROW_CON0 36
+#define HROW_NEQ 9
+#define NROW 128
+#elif HRG_STACK
 // stacking: two rows per lane -- 0..7 friction loss | 8..23 joint limits | 24..35 the two welds (hand, component) | 36..127 contacts x 4 pyramid edges
 #define SROW_WELD0 24
 #define SROW_CON0 36
@@ -216,7 +235,16 @@ struct Lds {
 #endif
   double act[NV];                        // this step's action (7 used)
   int acc_has_collision, acc_collision_type, acc_failsafe, acc_pad;  // per-policy-step accumulators
-#if HRG_STACK
+#if HRG_HAMMER
+  hrg_hammer_state hm;                   // board, hammer, nail + task bookkeeping (streamed from its own HBM array)
+  double gR[2][9];                       // rotation matrices of the board and the hammer at the current substep
+  double gc[HRG_HM_NGEOM][3];            // world centres of the four collision geoms (board, handle, head, nail head)
+  double nail_org[3], nail_axis[3];      // nail_head body origin and the slide axis, world
+  double Mb[64], fb[8];                  // mass matrix (8 x 8, pad DoF with a unit diagonal) and applied force of the board + nail subtree
+  double Ihw[9], tauh[3];                // the hammer's world-frame rotational inertia and gyroscopic torque
+  double rcen[HRG_NRCAP][3];
+  Contact con[NCON_DYN];
+#elif HRG_STACK
   hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)
   double cR[NCUBE][9];                   // cube rotation matrices at the current substep
   double rcen[HRG_NRCAP][3];
@@ -242,7 +270,11 @@ struct Lds {
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
       int cur[HRG_NPREV_MAX];
     };
-#if HRG_STACK
+#if HRG_HAMMER
+    struct {  // dynamics_step (hammering): dense rows of J over the 24 DoF (+1 pad: odd stride) -- 4 per contact, then the 9 equality rows; per-row gradient / curvature
+      double Jc[4 * NCON_DYN + HROW_NEQ][NVS + 1], rg[NROW], rh[NROW];
+    };
+#elif HRG_STACK
     struct {  // dynamics_step_stack: contact rows of J, compact: [robot 8 | first cube 6 | second cube 6] (+1 pad: odd stride), per-row gradient / curvature
       double Jc[4 * NCON_DYN][21], rg[NROW], rh[NROW];
       int con_ca[NCON_DYN], con_cb[NCON_DYN], con_rob[NCON_DYN + 1];   // cube index of geom 1 / geom 2 (-1: none), contact has a robot part
@@ -468,7 +500,7 @@ DI double seg_seg(PA p1, PB q1, PC p2, PD q2, double* c1, double* c2) {
   return v3dot(d, d);
 }
 
-#if HRG_BOX || HRG_STACK
+#if HRG_BOX || HRG_STACK || HRG_HAMMER
 // closest points of a segment and a box (centre c, rotation R row-major, half extents hb[3]): the squared distance along the
 // segment is a convex piecewise quadratic in t; safeguarded Newton on its derivative (exact inside one piece).
 template <class PA, class PB, class PC, class PR>

@@ -533,6 +533,452 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   wave_sync();
   return busy_rows ? 2 : 0;   // bit 0: diverged; bit 1: the robot tree carries contact rows or cubes are stacked (the caller's measure of how busy this env is)
 }
+#elif HRG_HAMMER
+// ================================================================================================ solver (hammering)
+// mj_step for the robot tree + the board with the nail on its slide joint + the hammer of CollaborativeHammeringCart (oracle: env_step_hammer): the same primal
+// Newton method with exact line search on 24 DoF in three blocks of eight and up to 128 constraint rows -- TWO rows per lane (r = lane, lane + 64; slots in
+// hrgym_device.h).  Contact and equality rows of J are stored dense (24 wide); the Newton system lives in registers as 3 x 3 tiles of 8 x 8 (lane (i, j) owns
+// entry (i, j) of every tile) and is inverted in place by Gauss-Jordan sweeps over its 21 real pivots.  The two equalities at the hands always carry curvature,
+// so every iteration inverts the full system.
+struct HRow { bool active; int type, kind, dof; double sgn, D, floss, flim, aref, y, p; };   // kind 0: a row on one DoF (sgn e_dof), 1: dense row `dof` of L.Jc
+
+PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  hrg_hammer_state& hm = L.hm;
+  const double h = m.timestep;
+  const int mi = lane >> 3, mj = lane & 7;
+  const int nc = ncon < NCON_DYN ? ncon : NCON_DYN;
+  bool ok;
+  const double Mij = L.M[lane];
+  double Minv, MDinv;   // entries (mi, mj) of M^-1 and (M + h D)^-1 of the robot tree
+  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  if (!ok) return 1;
+  // ---- board + nail subtree: the board as a free body with world-frame angular velocity, the nail head a point mass at r that slides along the axis a ----
+  double Mb;
+  {
+    const double mb = m.hm_board_mass, mn = m.hm_nail_mass;
+    double r[3], ax[3], rxa[3];
+    for (int a = 0; a < 3; a++) { r[a] = L.gc[HRG_HG_NAIL][a] - hm.pos[0][a]; ax[a] = L.nail_axis[a]; }
+    v3cross(rxa, r, ax);
+    const double rr = v3dot(r, r);
+    const double rx[9] = {0, -r[2], r[1], r[2], 0, -r[0], -r[1], r[0], 0};
+    double v = 0;
+    if (mi < 3 && mj < 3) v = mi == mj ? mb + mn : 0.0;
+    else if (mi < 3 && mj < 6) v = -mn * rx[3 * mi + (mj - 3)];
+    else if (mi < 6 && mj < 3) v = mn * rx[3 * (mi - 3) + mj];
+    else if (mi < 6 && mj < 6) {
+      const int a = mi - 3, b = mj - 3;
+      double iw = 0;
+      for (int k = 0; k < 3; k++) iw += L.gR[0][3 * a + k] * m.hm_board_inertia[k] * L.gR[0][3 * b + k];
+      v = iw + mn * ((a == b ? rr : 0.0) - r[a] * r[b]);
+    } else if (mi == 6 && mj == 6) v = mn;
+    else if (mi == 7 && mj == 7) v = 1.0;
+    else if (mi == 6 && mj < 3) v = mn * ax[mj];
+    else if (mj == 6 && mi < 3) v = mn * ax[mi];
+    else if (mi == 6 && mj < 6) v = mn * rxa[mj - 3];
+    else if (mj == 6 && mi < 6) v = mn * rxa[mi - 3];
+    Mb = v;
+    L.Mb[lane] = v;
+    if (lane < 8) {   // applied force: gravity, the board's gyroscopic torque, the nail's velocity-product acceleration c = w x (w x r) + 2 qd w x a
+      const double w[3] = {hm.vel[0][3], hm.vel[0][4], hm.vel[0][5]};
+      double Lw[3], gy[3], c[3], t1[3], t2[3], rxg[3], rxc[3];
+      for (int a = 0; a < 3; a++) {
+        double t = 0;
+        for (int b = 0; b < 3; b++) { double iw = 0; for (int k = 0; k < 3; k++) iw += L.gR[0][3 * a + k] * m.hm_board_inertia[k] * L.gR[0][3 * b + k]; t += iw * w[b]; }
+        Lw[a] = t;
+      }
+      v3cross(gy, Lw, w);
+      v3cross(t1, w, r); v3cross(t1, w, t1);
+      v3cross(t2, w, ax);
+      for (int a = 0; a < 3; a++) c[a] = t1[a] + 2.0 * hm.nail_v * t2[a];
+      v3cross(rxg, r, m.gravity); v3cross(rxc, r, c);
+      double f;
+      if (lane < 3) f = (mb + mn) * m.gravity[lane] - mn * c[lane];
+      else if (lane < 6) f = gy[lane - 3] + mn * rxg[lane - 3] - mn * rxc[lane - 3];
+      else if (lane == 6) f = mn * v3dot(ax, m.gravity) - mn * v3dot(ax, c);
+      else f = 0.0;
+      L.fb[lane] = f;
+    }
+    if (lane < 9) {   // the hammer's world-frame rotational inertia R diag(I) R'
+      const int a = lane / 3, b = lane - 3 * a;
+      double iw = 0;
+      for (int k = 0; k < 3; k++) iw += L.gR[1][3 * a + k] * m.hm_hammer_inertia[k] * L.gR[1][3 * b + k];
+      L.Ihw[lane] = iw;
+    }
+  }
+  wave_sync();
+  const double Mbinv = spd_inverse1(Mb, lane, &ok);
+  if (!ok) return 1;
+  if (lane < NV) {
+    double act = L.ctrl[lane];
+    if (lane >= NARM) act = clampd(m.finger_kp * (act - s.qpos[lane]), m.finger_forcerange[0], m.finger_forcerange[1]);
+    L.Ma0[lane] = act - m.jnt_damping[lane] * s.qvel[lane] - L.bias[lane];
+    L.qacc[lane] = s.qacc_warmstart[lane];
+  } else if (lane < HM_OH) {
+    const int k = lane - HM_OB;
+    L.Ma0[lane] = L.fb[k];
+    L.qacc[lane] = k < 6 ? hm.acc_warmstart[0][k] : (k == 6 ? hm.nail_acc_warmstart : 0.0);
+  } else if (lane < NVS) {   // the hammer: gravity, gyroscopic torque -(w x I w); a0 = M^-1 of that in closed form
+    const int k = lane - HM_OH;
+    const double w[3] = {hm.vel[1][3], hm.vel[1][4], hm.vel[1][5]};
+    double Lw[3], tau[3], tl[3];
+    for (int a = 0; a < 3; a++) Lw[a] = L.Ihw[3 * a] * w[0] + L.Ihw[3 * a + 1] * w[1] + L.Ihw[3 * a + 2] * w[2];
+    v3cross(tau, Lw, w);
+    for (int kk = 0; kk < 3; kk++) tl[kk] = (L.gR[1][kk] * tau[0] + L.gR[1][3 + kk] * tau[1] + L.gR[1][6 + kk] * tau[2]) / m.hm_hammer_inertia[kk];
+    double a0v = 0, f = 0;
+    if (k < 3) { a0v = m.gravity[k]; f = m.hm_hammer_mass * a0v; }
+    else if (k < 6) { const int a = k - 3; a0v = L.gR[1][3 * a] * tl[0] + L.gR[1][3 * a + 1] * tl[1] + L.gR[1][3 * a + 2] * tl[2]; f = tau[a]; }
+    L.a0[lane] = a0v;
+    L.Ma0[lane] = f;
+    L.qacc[lane] = k < 6 ? hm.acc_warmstart[1][k] : 0.0;
+  }
+  wave_sync();
+  {
+    const double x = matvec_lanes(Minv, L.Ma0, lane), xb = row8_sum(Mbinv * L.fb[mj]);
+    if (mj == 0) { L.a0[mi] = x; L.a0[HM_OB + mi] = xb; }
+  }
+  STAMP(20);
+  // ---- this lane's two constraint rows ----
+  HRow R[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int r = lane + 64 * k;
+    HRow& w = R[k];
+    w.active = false; w.type = 1; w.kind = 0; w.dof = 0; w.sgn = 0; w.D = 0; w.floss = 0; w.flim = 0; w.aref = 0; w.y = 0; w.p = 0;
+    bool cand = false;
+    double pos = 0, margin = 0, diag = 0, vel = 0, Bd_own = -1.0;
+    if (r < NV) {
+      if (m.jnt_frictionloss[r] > 0) { cand = true; w.type = 0; w.floss = m.jnt_frictionloss[r]; diag = m.dof_invweight0[r]; w.dof = r; w.sgn = 1.0; vel = s.qvel[r]; }
+    } else if (r == HROW_NFRIC) {   // nail_head_joint0: frictionloss with its own solreffriction (nail.xml:7)
+      if (m.hm_nail_frictionloss > 0) { cand = true; w.type = 0; w.floss = m.hm_nail_frictionloss; diag = m.hm_nail_invweight; w.dof = HM_ON; w.sgn = 1.0; vel = hm.nail_v; Bd_own = m.hm_nail_fric_damping / m.solimp[1]; }
+    } else if (r < HROW_NLIM) {
+      const int q = r - HROW_LIM0, dof = q >> 1, side = q & 1;
+      const double dist = side ? m.jnt_range[dof][1] - s.qpos[dof] : s.qpos[dof] - m.jnt_range[dof][0];
+      if (dist < 0) { cand = true; pos = dist; diag = m.dof_invweight0[dof]; w.dof = dof; w.sgn = side ? -1.0 : 1.0; vel = w.sgn * s.qvel[dof]; }
+    } else if (r < HROW_EQ0) {   // the slide joint's range [0, hm_nail_range]
+      const int side = r - HROW_NLIM;
+      const double dist = side ? m.hm_nail_range - hm.nail_q : hm.nail_q;
+      if (dist < 0) { cand = true; pos = dist; diag = m.hm_nail_invweight; w.dof = HM_ON; w.sgn = side ? -1.0 : 1.0; vel = w.sgn * hm.nail_v; }
+    } else if (r < HROW_CON0) {   // lh_eq: connect(lh_grip, lh_mocap) rows 0..2; rh_eq: weld(rh_grip, rh_mocap) position rows 3..5, rotation rows 6..8 (1100-1145)
+      const int e = r - HROW_EQ0;
+      double* Jr = L.Jc[4 * NCON_DYN + e];
+      for (int i = 0; i < NVS; i++) Jr[i] = 0.0;
+      w.type = 2; w.kind = 1; w.dof = 4 * NCON_DYN + e;
+      cand = true;
+      if (e < 6) {
+        const int hd = e < 3 ? 0 : 1, a = e - 3 * hd;
+        double rr[3], rxe[3];
+        m3mulv(rr, L.gR[0], m.hm_anchor[hd]);
+        const double ea[3] = {a == 0 ? 1.0 : 0.0, a == 1 ? 1.0 : 0.0, a == 2 ? 1.0 : 0.0};
+        v3cross(rxe, rr, ea);
+        pos = hm.pos[0][a] + rr[a] - hm.mocap_pos[hd][a];
+        Jr[HM_OB + a] = 1.0;
+        vel = hm.vel[0][a];
+        for (int b = 0; b < 3; b++) { Jr[HM_OB + 3 + b] = rxe[b]; vel += rxe[b] * hm.vel[0][3 + b]; }
+        diag = 1.0 / m.hm_board_mass;
+      } else {
+        const int a = e - 6;
+        const double qm[4] = {hm.mocap_quat[1][0], hm.mocap_quat[1][1], hm.mocap_quat[1][2], hm.mocap_quat[1][3]};
+        const double qi[4] = {m.hm_weld_relquat[0], -m.hm_weld_relquat[1], -m.hm_weld_relquat[2], -m.hm_weld_relquat[3]};
+        const double qo[4] = {hm.quat[0][0], hm.quat[0][1], hm.quat[0][2], hm.quat[0][3]};
+        double qt[4], qe[4];
+        quatmul(qt, qm, qi);
+        const double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
+        quatmul(qe, qo, qc);
+        if (qe[0] < 0) for (int z = 0; z < 4; z++) qe[z] = -qe[z];
+        const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+        pos = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
+        Jr[HM_OB + 3 + a] = 1.0;
+        vel = hm.vel[0][3 + a];
+        diag = m.hm_board_invweight_rot;
+      }
+    } else if (r < HROW_CON0 + 4 * NCON_DYN) {
+      const int q = r - HROW_CON0, c = q >> 2, d = q & 3;
+      w.kind = 1; w.dof = q;
+      if (c < nc) {
+        const Contact& cc = L.con[c];
+        const double n[3] = {cc.n[0], cc.n[1], cc.n[2]}, cp[3] = {cc.pos[0], cc.pos[1], cc.pos[2]};
+        double t1[3], t2[3], dir[3];
+        const double e1[3] = {1, 0, 0}, e2[3] = {0, 1, 0};
+        v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
+        v3scl(t1, t1, 1.0 / v3norm(t1));
+        v3cross(t2, n, t1);
+        const double sg = (d & 1) ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
+        pos = cc.dist;
+        margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+        const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
+        diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
+        const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
+        double nz = 0;
+        double* Jr = L.Jc[q];
+        for (int i = NV; i < NVS; i++) Jr[i] = 0.0;
+        if (!(rb1 || rb2)) { for (int i = 0; i < NV; i++) Jr[i] = 0.0; }
+        else {
+#pragma unroll 1
+          for (int i = 0; i < NV; i++) {
+            double t[3], v[3];
+            v3cross(t, L.Sw[i], cp);
+            v3add(v, L.Sv[i], t);
+            const double jv = v3dot(dir, v);
+            double acc = 0;
+            if ((am1 >> i) & 1) acc += -1.0 * jv;
+            if ((am2 >> i) & 1) acc += jv;
+            Jr[i] = acc;
+            vel += acc * s.qvel[i];
+            nz += fabs(acc);
+          }
+        }
+#pragma unroll
+        for (int side = 0; side < 2; side++) {   // free bodies: J = -+dir . (v + w x r); the nail's point moves with the board and along the slide axis
+          const int body = side ? cc.b2 : cc.b1;
+          if (body >= BODY_BOX) {
+            const int fb = body - BODY_BOX, bi = fb == HRG_HM_HAMMER ? 1 : 0, o = fb == HRG_HM_HAMMER ? HM_OH : HM_OB;
+            const double sgn = side ? 1.0 : -1.0;
+            double rr[3], rxd[3];
+            for (int a = 0; a < 3; a++) rr[a] = cp[a] - hm.pos[bi][a];
+            v3cross(rxd, rr, dir);
+            for (int a = 0; a < 3; a++) { Jr[o + a] = sgn * dir[a]; Jr[o + 3 + a] = sgn * rxd[a]; vel += sgn * (dir[a] * hm.vel[bi][a] + rxd[a] * hm.vel[bi][3 + a]); nz += fabs(dir[a]) + fabs(rxd[a]); }
+            if (fb == HRG_HM_NAIL) {
+              const double ja = sgn * (dir[0] * L.nail_axis[0] + dir[1] * L.nail_axis[1] + dir[2] * L.nail_axis[2]);
+              Jr[HM_ON] = ja; vel += ja * hm.nail_v; nz += fabs(ja);
+              diag += m.hm_nail_invweight;
+            } else diag += 1.0 / (fb == HRG_HM_HAMMER ? m.hm_hammer_mass : m.hm_board_mass);
+          }
+        }
+        diag *= 1.0 + m.friction_static * m.friction_static;
+        cand = nz > 0;
+      }
+    }
+    w.active = cand && diag > 0;
+    if (w.active) {
+      double imp;
+      const double K = dm->sol_K, Bd = Bd_own >= 0 ? Bd_own : dm->sol_Bd;
+      impedance(m, pos - margin, &imp);
+      w.aref = -Bd * vel - K * imp * (pos - margin);
+      w.D = 1.0 / ((1 - imp) / imp * diag);
+      if (w.type == 0) w.flim = w.floss / w.D;
+    }
+  }
+  STAMP(21);
+  COUNT(19, __popcll(__ballot(R[0].active)) + __popcll(__ballot(R[1].active)));
+  wave_sync();
+  auto rowdot = [&](const HRow& w, const double* x) -> double {
+    if (!w.active) return 0.0;
+    if (w.kind == 0) return w.sgn * x[w.dof];
+    const double* Jr = L.Jc[w.dof];
+    double t = 0;
+#pragma unroll
+    for (int i = 0; i < NVS; i++) t += Jr[i] * x[i];
+    return t;
+  };
+  // M x for the DoF of this lane: robot rows dense, the board + nail block dense, the hammer m 1 / R diag(I) R', pad DoF 1
+  auto Mrow = [&](const double* x) -> double {
+    double t = 0;
+    if (lane < NV) {
+#pragma unroll
+      for (int j = 0; j < NV; j++) t += L.M[lane * NV + j] * x[j];
+    } else if (lane < HM_OH) {
+#pragma unroll
+      for (int j = 0; j < 8; j++) t += L.Mb[(lane - HM_OB) * 8 + j] * x[HM_OB + j];
+    } else if (lane < NVS) {
+      const int k = lane - HM_OH;
+      if (k < 3) t = m.hm_hammer_mass * x[lane];
+      else if (k < 6) t = L.Ihw[3 * (k - 3)] * x[HM_OH + 3] + L.Ihw[3 * (k - 3) + 1] * x[HM_OH + 4] + L.Ihw[3 * (k - 3) + 2] * x[HM_OH + 5];
+      else t = x[lane];
+    }
+    return t;
+  };
+  { // warm start vs unconstrained acceleration: keep the cheaper point
+    double c0 = 0, c1 = 0, g_, h_;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (R[k].active) {
+        double t0, t1;
+        row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, rowdot(R[k], L.qacc) - R[k].aref, &t0, &g_, &h_);
+        row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, rowdot(R[k], L.a0) - R[k].aref, &t1, &g_, &h_);
+        c0 += t0; c1 += t1;
+      }
+    if (lane < NVS) L.d[lane] = L.qacc[lane] - L.a0[lane];
+    wave_sync();
+    double quad = 0;
+    if (lane < NVS) quad = 0.5 * L.d[lane] * Mrow(L.d);
+    const double cost_ws = wave_sum(quad + c0), cost_a0 = wave_sum(c1);
+    wave_sync();
+    if (!(cost_ws < cost_a0)) { if (lane < NVS) L.qacc[lane] = L.a0[lane]; }
+    wave_sync();
+  }
+  STAMP(22);
+#pragma unroll 1
+  for (int it = 0; it < m.solver_iters; it++) {
+    COUNT(16, 1);
+    double gg[2], hh[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+      double cc_ = 0;
+      gg[k] = 0; hh[k] = 0;
+      R[k].y = rowdot(R[k], L.qacc) - R[k].aref;
+      if (R[k].active) row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, R[k].y, &cc_, &gg[k], &hh[k]);
+      L.rg[lane + 64 * k] = gg[k]; L.rh[lane + 64 * k] = hh[k];
+    }
+    wave_sync();
+    double gm = 0;
+    if (lane < NVS) {   // gradient of the DoF of this lane
+      double t = Mrow(L.qacc) - L.Ma0[lane];
+      gm = t;
+      if (lane < NV) { t += L.rg[lane]; t += L.rg[HROW_LIM0 + 2 * lane]; t -= L.rg[HROW_LIM0 + 2 * lane + 1]; }
+      else if (lane == HM_ON) { t += L.rg[HROW_NFRIC]; t += L.rg[HROW_NLIM]; t -= L.rg[HROW_NLIM + 1]; }
+#pragma unroll 4
+      for (int q = 0; q < 4 * nc; q++) t += L.Jc[q][lane] * L.rg[HROW_CON0 + q];
+#pragma unroll
+      for (int e = 0; e < HROW_NEQ; e++) t += L.Jc[4 * NCON_DYN + e][lane] * L.rg[HROW_EQ0 + e];
+      L.g[lane] = t;
+    }
+    wave_sync();
+    {
+      const double gl = lane < NVS ? L.g[lane] : 0.0, ml = lane < NVS ? L.Ma0[lane] : 0.0;
+      const double gn = wave_sum(gl * gl), sc = wave_sum(ml * ml);
+      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+    }
+    STAMP(27);
+    // ---- Newton Hessian M + sum_r h_r J_r' J_r as 3 x 3 tiles in registers ----
+    Tiles<3> T;
+#pragma unroll
+    for (int a = 0; a < 3; a++)
+#pragma unroll
+      for (int b_ = 0; b_ < 3; b_++) T.t[a][b_] = 0.0;
+    {
+      double t00 = Mij, t11 = Mb, t22 = 0.0;
+      if (mi == mj) { t00 += L.rh[mi]; t00 += L.rh[HROW_LIM0 + 2 * mi]; t00 += L.rh[HROW_LIM0 + 2 * mi + 1]; }
+      if (mi == 6 && mj == 6) { t11 += L.rh[HROW_NFRIC]; t11 += L.rh[HROW_NLIM]; t11 += L.rh[HROW_NLIM + 1]; }
+      if (mi < 3 && mj < 3) t22 = mi == mj ? m.hm_hammer_mass : 0.0;
+      else if (mi >= 3 && mi < 6 && mj >= 3 && mj < 6) t22 = L.Ihw[3 * (mi - 3) + (mj - 3)];
+      else if (mi == mj && mi >= 6) t22 = 1.0;
+      T.t[0][0] = t00; T.t[1][1] = t11; T.t[2][2] = t22;
+    }
+#pragma unroll 1
+    for (int q = 0; q < 4 * nc + HROW_NEQ; q++) {
+      const int row = q < 4 * nc ? q : 4 * NCON_DYN + (q - 4 * nc);
+      const double hq = L.rh[q < 4 * nc ? HROW_CON0 + q : HROW_EQ0 + (q - 4 * nc)];
+      if (__builtin_amdgcn_readfirstlane(hq != 0.0 ? 1 : 0)) {
+        const double* Jr = L.Jc[row];
+        const double ji[3] = {Jr[mi], Jr[8 + mi], Jr[16 + mi]}, jj[3] = {Jr[mj], Jr[8 + mj], Jr[16 + mj]};
+#pragma unroll
+        for (int a = 0; a < 3; a++)
+#pragma unroll
+          for (int b_ = 0; b_ < 3; b_++) T.t[a][b_] += hq * ji[a] * jj[b_];
+      }
+    }
+    STAMP(23);
+    COUNT(18, 1);
+    {
+      bool good = true;
+      tiles_pivots<3, 0, 0>(T, mi, mj, 8, good);
+      tiles_pivots<3, 1, 0>(T, mi, mj, 7, good);
+      tiles_pivots<3, 2, 0>(T, mi, mj, 6, good);
+      if (!good) break;
+    }
+    STAMP(24);
+    {   // direction d = -H^-1 g, one tile row at a time
+      const double gb[3] = {L.g[mj], L.g[8 + mj], L.g[16 + mj]};
+#pragma unroll
+      for (int a = 0; a < 3; a++) {
+        const double x = -row8_sum(T.t[a][0] * gb[0] + T.t[a][1] * gb[1] + T.t[a][2] * gb[2]);
+        if (mj == 0) L.d[8 * a + mi] = x;
+      }
+    }
+    wave_sync();
+#pragma unroll
+    for (int k = 0; k < 2; k++) R[k].p = rowdot(R[k], L.d);
+    double dd = 0, Mdi = 0;
+    if (lane < NVS) { dd = L.d[lane]; Mdi = Mrow(L.d); }
+    STAMP(25);
+    const double dMd = wave_sum(dd * Mdi), gd0 = wave_sum(dd * gm);
+    double al = 1.0, lo = 0, hi = -1;
+    const double d1_0 = gd0 + wave_sum(gg[0] * R[0].p + gg[1] * R[1].p);
+    const double noise = fabs(gd0) + dMd + wave_sum(fabs(gg[0] * R[0].p) + fabs(gg[1] * R[1].p));   // magnitude of the terms phi' is summed from
+#pragma unroll 1
+    for (int ls = 0; ls < 40; ls++) {
+      COUNT(17, 1);
+      double sg_ = 0, sh_ = 0;
+#pragma unroll
+      for (int k = 0; k < 2; k++)
+        if (R[k].active) {
+          double c2, g2, h2;
+          row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, R[k].y + al * R[k].p, &c2, &g2, &h2);
+          sg_ += g2 * R[k].p; sh_ += h2 * R[k].p * R[k].p;
+        }
+      const double d1 = gd0 + al * dMd + wave_sum(sg_);
+      const double d2 = dMd + wave_sum(sh_);
+      if (fabs(d1) <= 1e-10 * fabs(d1_0) || fabs(d1) <= 1e-14 * noise) break;   // converged, or down at the rounding noise of the sum's own terms
+      if (d1 < 0) lo = al; else hi = al;
+      double nx = al - d1 / d2;
+      if (hi < 0) { if (!(nx > lo)) nx = 2 * al; }
+      else if (!(nx > lo && nx < hi)) nx = 0.5 * (lo + hi);
+      al = nx;
+    }
+    STAMP(26);
+    if (lane < NVS) L.qacc[lane] += al * dd;
+    wave_sync();
+    bool moved = false;
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (R[k].active) moved = moved || row_zone(R[k].type, R[k].flim, R[k].y) != row_zone(R[k].type, R[k].flim, R[k].y + R[k].p);
+    if (al == 1.0 && !__any(moved)) break;
+  }
+  const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
+  if (__any(badacc)) return 1;
+  // mj_Euler with implicit joint damping for the robot tree
+  {
+    const double t = matvec_lanes(Mij, L.qacc, lane);
+    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
+    wave_sync();
+    if (mj == 0) L.d[mi] = t;
+    wave_sync();
+    const double x = matvec_lanes(MDinv, L.d, lane);
+    if (mj == 0) {
+      const double v = s.qvel[mi] + h * x;
+      s.qvel[mi] = v;
+      s.qpos[mi] = s.qpos[mi] + h * v;
+    }
+  }
+  hammer_obs_pos(dm_, lane);   // body_xpos of the forward pass inside mj_step (pre-integration)
+  wave_sync();
+  { // the free joints: lanes 8..13 board, 14 the nail's slide joint, 16..21 hammer; quaternions by lanes 0, 1
+    if ((lane >= HM_OB && lane < HM_ON) || (lane >= HM_OH && lane < HM_OH + 6)) {
+      const int fb = lane >= HM_OH ? 1 : 0, k = lane - (fb ? HM_OH : HM_OB);
+      const double acc = L.qacc[lane];
+      hm.acc_warmstart[fb][k] = acc;
+      const double vnew = hm.vel[fb][k] + h * acc;
+      hm.vel[fb][k] = vnew;
+      if (k < 3) hm.pos[fb][k] = hm.pos[fb][k] + h * vnew;
+    } else if (lane == HM_ON) {
+      const double acc = L.qacc[lane];
+      hm.nail_acc_warmstart = acc;
+      const double vnew = hm.nail_v + h * acc;
+      hm.nail_v = vnew;
+      hm.nail_q = hm.nail_q + h * vnew;
+    }
+    wave_sync();
+    if (lane < 2) {
+      const double w0 = hm.vel[lane][3], w1 = hm.vel[lane][4], w2 = hm.vel[lane][5];
+      const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+      if (wn > 1e-12) {
+        const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
+        const double qo[4] = {hm.quat[lane][0], hm.quat[lane][1], hm.quat[lane][2], hm.quat[lane][3]};
+        double qn[4];
+        quatmul(qn, dq, qo);
+        const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        for (int z = 0; z < 4; z++) hm.quat[lane][z] = qn[z] / nn;
+      }
+    }
+  }
+  wave_sync();
+  return nc > 0 ? 2 : 0;   // bit 0: diverged; bit 1: contacts enter the solve (the caller's measure of how busy this env is)
+}
 #else
 PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int ncon) {
   const ModelPtr dm = uniform_model(dm_);
@@ -1246,7 +1692,7 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
     else if (lane < 33) v = s.eef_pos[lane - 30];   // robot0_eef_pos
     else if (lane < 39) v = goal[lane - 33];        // desired_goal
     else if (lane >= 53 && lane < 55) v = s.qpos[NARM + lane - 53];  // robot0_gripper_qpos
-    else if (lane >= 55) v = s.qvel[NARM + lane - 55];               // robot0_gripper_qvel
+    else if (lane >= 55 && lane < 57) v = s.qvel[NARM + lane - 55];  // robot0_gripper_qvel
     else v = 0.0;                                   // PickPlaceHumanCart columns
 #if HRG_STACK
     // CollaborativeStackingCart._setup_observables (collaborative_stacking_cartesian_env.py:1306-1524): vec_eef_to_all_objects (a, b, l, r) in the 12 joint-space
@@ -1265,6 +1711,28 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
       v = ap / HRG_NFINGER;
     } else if (lane >= 47 && lane < 50) v = sk.obs_pos[nxt][lane - 47];
     else if (lane >= 50 && lane < 53) v = sk.target[lane - 50];
+#endif
+#if HRG_HAMMER
+    // CollaborativeHammeringCart._setup_observables (collaborative_hammering_cartesian_env.py:1151-1323; oracle: compute_obs_hammer): hammer_quat (w, x, y, z) 12:16,
+    // board_pos 33:36, vec_eef_to_board 36:39, hammer_gripped 39, vec_eef_to_hammer 40:43, vec_eef_to_nail 43:46, gripper_aperture 46, hammer_pos 47:50, nail_pos 50:53,
+    // board_quat (x, y, z, w) 57:61, nail_hammering_progress 61
+    const hrg_hammer_state& hm = L.hm;
+    if (lane >= 12 && lane < 16) v = hm.quat[1][lane - 12];
+    else if ((lane >= 16 && lane < 18)) v = 0.0;
+    else if (lane >= 33 && lane < 36) v = hm.obs_pos[0][lane - 33];
+    else if (lane >= 36 && lane < 39) v = hm.obs_pos[0][lane - 36] - s.eef_pos[lane - 36];
+    else if (lane == 39) v = (double)hm.gripped;
+    else if (lane >= 40 && lane < 43) v = hm.obs_pos[1][lane - 40] - s.eef_pos[lane - 40];
+    else if (lane >= 43 && lane < 46) v = hm.obs_pos[2][lane - 43] - s.eef_pos[lane - 43];
+    else if (lane == 46) {
+      double ap = 0;
+      for (int f = 0; f < HRG_NFINGER; f++) ap += (s.qpos[NARM + f] - m.finger_qpos_range[0][f]) / (m.finger_qpos_range[1][f] - m.finger_qpos_range[0][f]);
+      v = ap / HRG_NFINGER;
+    } else if (lane >= 47 && lane < 50) v = hm.obs_pos[1][lane - 47];
+    else if (lane >= 50 && lane < 53) v = hm.obs_pos[2][lane - 50];
+    else if (lane >= 57 && lane < 60) v = hm.quat[0][1 + lane - 57];
+    else if (lane == 60) v = hm.quat[0][0];
+    else if (lane == 61) v = clampd(hm.nail_q / m.hm_nail_range, 0.0, 1.0);
 #endif
 #if HRG_BOX
     // PickPlaceHumanCart._setup_observables (pick_place_human_cartesian_env.py:726-841), gripper_aperture (human_env.py:1508-1524)
@@ -1408,6 +1876,34 @@ DI void stack_reset_animation(const DevModel* __restrict__ dm_, int lane) {
 }
 #endif
 
+#if HRG_HAMMER
+// _reset_board + _human_take_board_from_table + _reset_nail as restated in the oracle (hammer_take_board): the board where the right-hand weld holds it, at rest, the
+// nail pulled out at its nail_index-th placement.  Needs hm.mocap_*.
+DI void hammer_take_board(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_hammer_state& hm = L.hm;
+  wave_sync();
+  const double qm[4] = {hm.mocap_quat[1][0], hm.mocap_quat[1][1], hm.mocap_quat[1][2], hm.mocap_quat[1][3]};
+  const double qi[4] = {m.hm_weld_relquat[0], -m.hm_weld_relquat[1], -m.hm_weld_relquat[2], -m.hm_weld_relquat[3]};
+  double qt[4], Rt[9], t[3];
+  quatmul(qt, qm, qi);
+  quat2mat(Rt, qt);
+  m3mulv(t, Rt, m.hm_anchor[1]);
+  const double u0 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)L.st.episode, STREAM_OBJECT, (uint64_t)(2 * hm.nail_index)),
+               u1 = rng_u01(m.seed, (uint64_t)gid, (uint64_t)L.st.episode, STREAM_OBJECT, (uint64_t)(2 * hm.nail_index + 1));
+  wave_sync();
+  if (lane < 4) hm.quat[0][lane] = qt[lane];
+  if (lane < 3) hm.pos[0][lane] = hm.mocap_pos[1][lane] - t[lane];
+  if (lane < 6) { hm.vel[0][lane] = 0.0; hm.acc_warmstart[0][lane] = 0.0; }
+  hm.nail_q = 0.0; hm.nail_v = 0.0; hm.nail_acc_warmstart = 0.0;
+  if (lane == 0) hm.nail_xy[0] = m.hm_nail_bin[0] + (m.hm_nail_bin[1] - m.hm_nail_bin[0]) * u0;
+  if (lane == 1) hm.nail_xy[1] = m.hm_nail_bin[2] + (m.hm_nail_bin[3] - m.hm_nail_bin[2]) * u1;
+  wave_sync();
+}
+#endif
+
 DI void eef_update(const DevModel* __restrict__ dm_) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
@@ -1473,6 +1969,11 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
   s.stream_id = (int32_t)gid;
   if (lane < NARM) s.qpos[lane] = m.init_qpos[lane] + m.init_noise * rng_gauss(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_NOISE, (uint64_t)lane);
   else if (lane < NV) s.qpos[lane] = m.finger_init_qpos[lane - NARM];
+#if HRG_HAMMER
+  // _put_hammer_into_gripper (790-812) closes the gripper on the handle: the fingers start where their pads touch it, commanded shut
+  if (lane >= NARM && lane < NV) s.qpos[lane] = m.hm_finger_grip_qpos[lane - NARM];
+  s.grip_action = -1.0;
+#endif
   const double ux = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 0), uy = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 1),
                uz = rng_u01(m.seed, (uint64_t)gid, (uint64_t)episode, STREAM_HUMAN, 2);
   s.human_pos_offset[0] = m.base_human_pos_offset[0] + (2 * ux - 1) * m.human_rand[0];
@@ -1532,6 +2033,25 @@ HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid
     human_control(dm_, lane, gid);
     stack_reset_animation(dm_, lane);
     stack_update_target(dm_, lane, gid);
+  }
+#elif HRG_HAMMER
+  { // CollaborativeHammeringCart._reset_internal (717-747): the human holds the board, the hammer sits in the closed gripper, phase APPROACH
+    hrg_hammer_state& hm = L.hm;
+    for (int k = lane; k < (int)(sizeof(hrg_hammer_state) / sizeof(double)); k += 64) ((double*)&hm)[k] = 0.0;
+    wave_sync();
+    hm.quat[0][0] = 1.0;
+    wave_sync();
+    human_control(dm_, lane, gid);
+    hammer_take_board(dm_, lane, gid);
+    double Rg[9], t[3];
+    quat2mat(Rg, m.hm_hammer_grip_quat);
+    m3mulv(t, Rg, m.hm_hammer_com);
+    if (lane < 4) hm.quat[1][lane] = m.hm_hammer_grip_quat[lane];
+    if (lane < 3) hm.pos[1][lane] = s.eef_pos[lane] + t[lane];
+    wave_sync();
+    hammer_geometry(dm_, lane);
+    hammer_obs_pos(dm_, lane);
+    wave_sync();
   }
 #else
   goal_sample(dm_, lane, gid, 0);
@@ -1705,6 +2225,9 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
 #if HRG_LIFT
   if (m.task == HRG_TASK_LIFTING) { wave_sync(); if (lane == 0) L.act[NARM] = 1.0; wave_sync(); }   // CollaborativeLiftingCart.step (368-391): the gripper action is replaced by 'close'
 #endif
+#if HRG_HAMMER
+  if (!m.gripper_controllable) { wave_sync(); if (lane == 0) L.act[NARM] = 1.0; wave_sync(); }   // CollaborativeHammeringCart.step (486-487): always close the gripper
+#endif
   if ((m.cp_enabled || m.ik_enabled) && lane < HRG_ACT_DIM) action[lane] = L.act[lane];
   s.timestep = s.timestep + 1;
   L.acc_has_collision = 0; L.acc_collision_type = HRG_COL_NULL; L.acc_failsafe = 0;
@@ -1755,6 +2278,19 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
     if (sk.gripped) r += m.object_gripped_reward;
   }
   const double dense = 0.0;   // _dense_reward is a TODO returning 0 (681-698)
+#elif HRG_HAMMER
+  // CollaborativeHammeringCart: success = the animation ran to its end (_check_success, 576-587); _sparse_reward (522-556); _check_nail_hammered_in (505-520)
+  hrg_hammer_state& hm = L.hm;
+  const double progress = clampd(hm.nail_q / m.hm_nail_range, 0.0, 1.0);
+  const int hammered_in = 1.0 - progress < m.hm_goal_tolerance;
+  const int goal_reached = !crash && hm.task_phase == HRG_HM_COMPLETE;
+  double r;
+  if (goal_reached) r = m.task_reward;
+  else {
+    r = hammered_in ? m.nail_hammered_in_reward : -1.0;
+    if (hm.gripped) r += m.hammer_gripped_reward_bonus;
+  }
+  const double dense = 0.0;   // _dense_reward is a TODO returning 0 (558-574)
 #elif HRG_BOX
   // PickPlaceHumanCart: achieved goal = [eef_pos, object_pos, object_gripped], desired goal = target_pos (574-611);
   // _check_object_in_target_zone (550-572), _sparse_reward (471-500), _dense_reward (502-526)
@@ -2038,6 +2574,28 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
     if (nns > sk.max_stack_height) sk.max_stack_height = nns;
     wave_sync();
   }
+#elif HRG_HAMMER
+  if (!d) write_obs(dm_, lane, goal, obs);   // the step's observation predates the transitions below (CollaborativeHammeringCart.step, 490-503)
+  wave_sync();
+  if (goal_reached && !m.done_at_success && !d) { // _on_goal_reached (749-767): next nail placement, board and nail reset, next animation
+    const int ni = (hm.nail_index + 1) % m.n_obj_placements;
+    const int ai = (s.anim_index + 1) % m.n_anim_ids, st = (int)((double)s.low_level_time / m.anim_step_length);
+    wave_sync();
+    hm.nail_index = ni;
+    s.anim_index = ai; s.animation_time = 0; s.anim_start_time = st;
+    hm.task_phase = HRG_HM_APPROACH; hm.n_delayed = 0;
+    wave_sync();
+    human_control(dm_, lane, gid);
+    wave_sync();
+    hm.task_phase = HRG_HM_APPROACH; hm.n_delayed = 0;   // _reset_animation (764-767, 770-774)
+    hammer_take_board(dm_, lane, gid);
+  }
+  {
+    const int ph = hm.task_phase;
+    wave_sync();
+    if (!d && ph == HRG_HM_PRESENT && hammered_in) hm.task_phase = HRG_HM_RETREAT;   // 496-501
+    wave_sync();
+  }
 #else
   if (goal_reached && !d) { // reach_human_env.py:399-407 (a finished episode resamples its goals at reset anyway)
     s.goal_index = (s.goal_index + 1) % m.n_goals;
@@ -2046,7 +2604,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
 #endif
   STAMP(8);
   if (d) env_reset(dm_, lane, own_gid, obs);
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
   else write_obs(dm_, lane, goal, obs);
 #endif
   STAMP(9);
@@ -2059,6 +2617,10 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
 #define hrg_step_kernel hrg_step_kernel_stack
 #define hrg_reset_kernel hrg_reset_kernel_stack
 typedef hrg_stack_state ObjState;   // the per-env object block this variant streams next to hrg_env_state
+#elif HRG_HAMMER
+#define hrg_step_kernel hrg_step_kernel_hammer
+#define hrg_reset_kernel hrg_reset_kernel_hammer
+typedef hrg_hammer_state ObjState;
 #else
 typedef hrg_box_state ObjState;
 #endif
@@ -2108,6 +2670,20 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
   const double* src = (const double*)&g_L.sk;
   for (int k = lane; k < NB; k += 64) out[k] = src[k];
 }
+#elif HRG_HAMMER
+#define HRG_KERNEL_WAVES 1   // 33 KB of LDS per env (89 dense rows of J over 24 DoF): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
+DI void box_load(const hrg_hammer_state* __restrict__ hammers, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_hammer_state) / sizeof(double));
+  const double* src = (const double*)(hammers + e);
+  double* dst = (double*)&g_L.hm;
+  for (int k = lane; k < NB; k += 64) dst[k] = src[k];
+}
+DI void box_store(hrg_hammer_state* __restrict__ hammers, int e, int lane) {
+  constexpr int NB = (int)(sizeof(hrg_hammer_state) / sizeof(double));
+  double* out = (double*)(hammers + e);
+  const double* src = (const double*)&g_L.hm;
+  for (int k = lane; k < NB; k += 64) out[k] = src[k];
+}
 #else
 #define HRG_KERNEL_WAVES HRG_MIN_WAVES
 #endif
@@ -2125,7 +2701,7 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_
   double* dst = (double*)&L.st;
   constexpr int NW = (int)(sizeof(hrg_env_state) / sizeof(double));
   for (int k = lane; k < NW; k += 64) dst[k] = src[k];
-#if HRG_BOX || HRG_STACK
+#if HRG_BOX || HRG_STACK || HRG_HAMMER
   box_load(boxes, e, lane);
 #endif
   wave_sync();
@@ -2141,7 +2717,7 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_
   }
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
-#if HRG_BOX || HRG_STACK
+#if HRG_BOX || HRG_STACK || HRG_HAMMER
   box_store(boxes, e, lane);
 #endif
 }
@@ -2162,12 +2738,12 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_reset
   wave_sync();
   double* out = (double*)(states + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
-#if HRG_BOX || HRG_STACK
+#if HRG_BOX || HRG_STACK || HRG_HAMMER
   box_store(boxes, e, lane);
 #endif
 }
 
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
 // HumanEnv.check_collision_action for every env: goal configuration of the action at the env's current joint angles -> pre-check capsule model.
 // The check reads the robot part of the state only, so one kernel serves every task.
 __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
@@ -2194,7 +2770,7 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_
                                                                            float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                             int64_t env_id0, hrg_box_state* boxes);
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
 // ... of the stacking variant (hrgym_stack.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                              float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -2202,7 +2778,13 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int 
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                               int64_t env_id0, hrg_stack_state* stacks);
 #endif
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+// ... of the hammering variant (hrgym_hammer.hip)
+extern "C" __attribute__((visibility("hidden"))) void hrg_hammer_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                              float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                              float* scratch_obs, hrg_hammer_state* hammers, StepOrder ord);
+extern "C" __attribute__((visibility("hidden"))) void hrg_hammer_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                               int64_t env_id0, hrg_hammer_state* hammers);
 // the same shims of the handover variant (hrgym_handover.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_ho_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                           float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -2215,6 +2797,15 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_step(int n
                                                                             float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                              int64_t env_id0, hrg_box_state* boxes);
+#endif
+#if HRG_HAMMER
+extern "C" void hrg_hammer_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
+                                       int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, hrg_hammer_state* hammers, StepOrder ord) {
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, hammers, n_envs, ord);
+}
+extern "C" void hrg_hammer_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0, hrg_hammer_state* hammers) {
+  hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, hammers, n_envs);
+}
 #endif
 #if HRG_STACK
 extern "C" void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
@@ -2238,6 +2829,8 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #ifdef HRG_STAMPS
 #if HRG_STACK
 #define hrg_debug_stamps hrg_debug_stamps_stack
+#elif HRG_HAMMER
+#define hrg_debug_stamps hrg_debug_stamps_hammer
 #elif HRG_HANDOVER
 #define hrg_debug_stamps hrg_debug_stamps_ho
 #elif HRG_LIFT
@@ -2245,7 +2838,7 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #elif HRG_BOX
 #define hrg_debug_stamps hrg_debug_stamps_box
 #endif
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
 // waves that live longer than `thresh` shader cycles are also summed into a second set of accumulators: out[0..31] phase sums, out[32] their number, out[33] lifetime sum
 extern "C" int hrg_debug_stamps_slow(double* out, unsigned long long thresh, int reset) {
   unsigned long long h[34];
@@ -2263,7 +2856,10 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
   if (reset) { memset(h, 0, sizeof h); hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), h, sizeof h); }
   return 0;
 }
-#if HRG_STACK
+#if HRG_HAMMER
+#define hrg_debug_envacc hrg_debug_envacc_hammer
+#define hrg_debug_envcyc hrg_debug_envcyc_hammer
+#elif HRG_STACK
 #define hrg_debug_envacc hrg_debug_envacc_stack
 #define hrg_debug_envcyc hrg_debug_envcyc_stack
 #elif HRG_HANDOVER
@@ -2282,7 +2878,7 @@ extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemc
 #endif
 #endif
 
-#if !HRG_BOX && !HRG_STACK
+#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
 
 // ================================================================================================ host side
 static thread_local std::string g_err;
@@ -2306,6 +2902,7 @@ struct hrg_batch {
   float* d_scratch_obs = nullptr;
   hrg_box_state* d_boxes = nullptr;   // the manipulation object of each env (PickPlaceHumanCart)
   hrg_stack_state* d_stacks = nullptr; // the four cubes of each env (CollaborativeStackingCart)
+  hrg_hammer_state* d_hammers = nullptr; // board, hammer, nail of each env (CollaborativeHammeringCart)
   int32_t* d_order = nullptr;          // launch order of the step kernel (StepOrder): two orders of n_envs + two pairs of counters
   int32_t parity = 0;                  // which of the two orders the next step launch reads
   int32_t task = HRG_TASK_REACH;
@@ -2329,6 +2926,7 @@ const char* hrg_version(void) { return "hrgym-hip 0.1.0 (gfx950)"; }
 size_t hrg_state_bytes(void) { return sizeof(hrg_env_state); }
 size_t hrg_box_bytes(void) { return sizeof(hrg_box_state); }
 size_t hrg_stack_bytes(void) { return sizeof(hrg_stack_state); }
+size_t hrg_hammer_bytes(void) { return sizeof(hrg_hammer_state); }
 
 int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t n_envs, int64_t env_id0, int32_t device, hrg_batch** out) {
   if (!desc || !clips || !out || n_envs <= 0) return fail(HRG_ERR_INVALID, "null argument or n_envs <= 0");
@@ -2347,7 +2945,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   for (int c = 0; c < HRG_NSHIELD_RCAP; c++)
     if (desc->scap_body[c] != (c < NARM ? c : NARM - 1)) return fail(HRG_ERR_INVALID, "shield capsule c must sit on link c (gripper on link 6)");
   if (desc->n_bodypart > HRG_NBODYPART_MAX || desc->n_extremity > HRG_NEXTREMITY_MAX) return fail(HRG_ERR_INVALID, "too many body parts");
-  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_REACH_BOX) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
+  if (desc->task < HRG_TASK_REACH || desc->task > HRG_TASK_HAMMERING) return fail(HRG_ERR_UNSUPPORTED, "unknown task");
   if (desc->task == HRG_TASK_STACKING) {
     if (!(desc->box_inertia[0] == desc->box_inertia[1] && desc->box_inertia[1] == desc->box_inertia[2]))
       return fail(HRG_ERR_UNSUPPORTED, "CollaborativeStackingCart: the HIP stepper stacks cubes (object_full_size with three equal edges)");
@@ -2368,6 +2966,15 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
         return fail(HRG_ERR_INVALID, "HumanObjectInspectionCart: every clip needs keyframes (k0 <= k1) and at most 4 loop sines in its info");
   if (desc->ik_enabled && !(desc->ik_max_iter >= 1 && desc->ik_max_iter <= 1000 && desc->ik_damping > 0 && desc->ik_action_limit > 0 && desc->ik_residual_threshold >= 0))
     return fail(HRG_ERR_INVALID, "ik: need 1 <= max_iter <= 1000, damping > 0, action_limit > 0, residual_threshold >= 0");
+  if (desc->task == HRG_TASK_HAMMERING) {
+    if (!(desc->hm_board_mass > 0 && desc->hm_hammer_mass > 0 && desc->hm_nail_mass > 0 && desc->hm_nail_range > 0 && desc->hm_nail_invweight > 0 && desc->n_obj_placements > 0 &&
+          desc->hm_board_inertia[0] > 0 && desc->hm_board_inertia[1] > 0 && desc->hm_board_inertia[2] > 0 && desc->hm_hammer_inertia[0] > 0 && desc->hm_hammer_inertia[1] > 0 &&
+          desc->hm_hammer_inertia[2] > 0))
+      return fail(HRG_ERR_INVALID, "CollaborativeHammeringCart needs positive board / hammer / nail masses and inertias, a nail range and n_obj_placements > 0");
+    for (int c = 0; c < clips->n_clips; c++)
+      if (!(clips->clip_keyframes[c][0] >= 0 && clips->clip_keyframes[c][0] <= clips->clip_keyframes[c][1] && clips->clip_n_loop[c] >= 0 && clips->clip_n_loop[c] <= HRG_MAX_LOOP))
+        return fail(HRG_ERR_INVALID, "CollaborativeHammeringCart: every clip needs two ascending keyframes and at most 4 loop sines in its info");
+  } else
   if (desc->task != HRG_TASK_REACH && !(desc->box_half[0] > 0 && desc->box_half[1] > 0 && desc->box_half[2] > 0 && desc->box_mass > 0 && desc->box_inertia[0] > 0 && desc->box_inertia[1] > 0 &&
                                        desc->box_inertia[2] > 0 && desc->box_inertia_mean > 0 && desc->box_invweight_rot > 0 && desc->n_targets > 0 && desc->n_obj_placements > 0))
     return fail(HRG_ERR_INVALID, "PickPlaceHumanCart needs box_half, box_mass, box_inertia, n_targets, n_obj_placements > 0");
@@ -2481,6 +3088,10 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   HIPCHK_C(hipMemset(b->d_nh, 0, sizeof(int32_t) * (size_t)n_envs));
   HIPCHK_C(hipMalloc(&b->d_boxes, sizeof(hrg_box_state) * (size_t)n_envs));
   HIPCHK_C(hipMemset(b->d_boxes, 0, sizeof(hrg_box_state) * (size_t)n_envs));
+  if (desc->task == HRG_TASK_HAMMERING) {
+    HIPCHK_C(hipMalloc(&b->d_hammers, sizeof(hrg_hammer_state) * (size_t)n_envs));
+    HIPCHK_C(hipMemset(b->d_hammers, 0, sizeof(hrg_hammer_state) * (size_t)n_envs));
+  }
   if (desc->task == HRG_TASK_STACKING) {
     HIPCHK_C(hipMalloc(&b->d_stacks, sizeof(hrg_stack_state) * (size_t)n_envs));
     HIPCHK_C(hipMemset(b->d_stacks, 0, sizeof(hrg_stack_state) * (size_t)n_envs));
@@ -2502,14 +3113,15 @@ void hrg_batch_destroy(hrg_batch* b) {
   hipDeviceSynchronize();
   for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks); hipFree(b->d_order);
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks); hipFree(b->d_hammers); hipFree(b->d_order);
   delete b;
 }
 
 int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void* stream) {
   if (!b) return fail(HRG_ERR_INVALID, "null batch");
   HIPCHK(hipSetDevice(b->device));
-  if (b->task == HRG_TASK_STACKING) hrg_stack_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_stacks);
+  if (b->task == HRG_TASK_HAMMERING) hrg_hammer_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_hammers);
+  else if (b->task == HRG_TASK_STACKING) hrg_stack_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_stacks);
   else if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
@@ -2537,7 +3149,10 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     HIPCHK(hipEventRecord(ev.first, st));
   }
   const StepOrder ord{b->d_order, b->n_envs, b->parity};
-  if (b->task == HRG_TASK_STACKING)
+  if (b->task == HRG_TASK_HAMMERING)
+    hrg_hammer_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                           b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_hammers, ord);
+  else if (b->task == HRG_TASK_STACKING)
     hrg_stack_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                           b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_stacks, ord);
   else if (b->task == HRG_TASK_LIFTING)
@@ -2641,6 +3256,24 @@ int hrg_batch_set_stack(hrg_batch* b, int32_t env, const void* buf_host, size_t 
   return HRG_OK;
 }
 
+int hrg_batch_get_hammer(hrg_batch* b, int32_t env, void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_hammer_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  if (!b->d_hammers) return fail(HRG_ERR_INVALID, "not a CollaborativeHammeringCart batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(buf_host, b->d_hammers + env, bytes, hipMemcpyDeviceToHost));
+  return HRG_OK;
+}
+
+int hrg_batch_set_hammer(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes) {
+  if (!b || env < 0 || env >= b->n_envs || bytes != sizeof(hrg_hammer_state)) return fail(HRG_ERR_INVALID, "bad env index or buffer size");
+  if (!b->d_hammers) return fail(HRG_ERR_INVALID, "not a CollaborativeHammeringCart batch");
+  HIPCHK(hipSetDevice(b->device));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(b->d_hammers + env, buf_host, bytes, hipMemcpyHostToDevice));
+  return HRG_OK;
+}
+
 int hrg_batch_get_states(hrg_batch* b, const int32_t* envs_host, int32_t n, void* states_host, void* boxes_host) {
   if (!b || !envs_host || !states_host || n < 0) return fail(HRG_ERR_INVALID, "null argument");
   HIPCHK(hipSetDevice(b->device));
@@ -2696,4 +3329,4 @@ int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
 }
 
 } // extern "C"
-#endif // !HRG_BOX && !HRG_STACK
+#endif // !HRG_BOX && !HRG_STACK && !HRG_HAMMER

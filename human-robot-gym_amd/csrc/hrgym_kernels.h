@@ -287,6 +287,27 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     }
   }
 #endif
+#if HRG_HAMMER
+  { // _update_mocap_body_transforms (collaborative_hammering_cartesian_env.py:688-715): each hand's mocap body = the hand site, the hand rotation turned
+    // -90 deg (left) / +90 deg (right) about its y axis; computed by the lanes of the two hand bodies
+    const int bl = m.meas_body[m.site_lhand], br = m.meas_body[m.site_rhand];
+    if (lane == bl || lane == br) {
+      const int hd = lane == bl ? 0 : 1;
+      const double sn = hd == 0 ? -1.0 : 1.0;
+      double Rm[9], q[4], site[3], t[3];
+      for (int a = 0; a < 3; a++) { Rm[3 * a] = -sn * R[3 * a + 2]; Rm[3 * a + 1] = R[3 * a + 1]; Rm[3 * a + 2] = sn * R[3 * a]; }
+      const double tr = Rm[0] + Rm[4] + Rm[8];
+      if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+      else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+      else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+      m3mulv(t, R, m.hb_anchor[b]);
+      v3add(site, p, t);
+      for (int a = 0; a < 4; a++) L.hm.mocap_quat[hd][a] = q[a];
+      for (int a = 0; a < 3; a++) L.hm.mocap_pos[hd][a] = site[a];
+    }
+  }
+#endif
   // sites of the measured joints: site k sits at the anchor of body meas_body[k]
   {
     const int k = lane < HRG_NHJ ? lane : 0;
@@ -325,7 +346,7 @@ DI void human_pose_fk(const DevModel* __restrict__ dm_, int lane, int clip, int 
   human_fk_lanes(dm_, lane, mp, mq, fr + 7, hold_body, hold_left);
 }
 
-#if HRG_BOX || HRG_STACK
+#if HRG_BOX || HRG_STACK || HRG_HAMMER
 // amplitude (speed = 0) or speed modifier (1) of layered sine k of the idle loop of animation slot ai in this episode
 // (sample_animation_loop_properties, utils/animation_utils.py:122-176), drawn counter-based on demand
 DI double loop_prop(ModelPtr dm, int64_t gid, int episode, int ai, int clip, int k, int speed) {
@@ -445,6 +466,23 @@ PH_HUMAN void human_control(const DevModel* __restrict__ dm_, int lane, int64_t 
     if (at < 0) at = 0;
     wave_sync();
     sk.task_phase = phase; sk.n_delayed[0] = nd0; sk.n_delayed[1] = nd1;
+  }
+#endif
+#if HRG_HAMMER
+  { // CollaborativeHammeringCart._compute_animation_time (collaborative_hammering_cartesian_env.py:636-680); wave-uniform
+    hrg_hammer_state& hm = L.hm;
+    const int classic = at, len = dm->clips.clip_len[clip];
+    const double k0 = (double)dm->clips.clip_keyframes[clip][0], mid = 0.5 * (k0 + (double)dm->clips.clip_keyframes[clip][1]);
+    int phase = hm.task_phase, nd = hm.n_delayed;
+    if (phase == HRG_HM_APPROACH && (double)at > k0) phase = HRG_HM_PRESENT;
+    else if (phase == HRG_HM_PRESENT && (double)at > mid) {   // idle loop until the nail is hammered in
+      at = (int)layered_sines(dm, gid, s.episode, s.anim_index, clip, 0, dm->clips.clip_n_loop[clip], (double)classic, mid);
+      nd = classic - at;
+    } else if (phase == HRG_HM_RETREAT) at -= nd;
+    if (at >= len - 1) { phase = HRG_HM_COMPLETE; at = len - 1; }
+    if (at < 0) at = 0;
+    wave_sync();
+    hm.task_phase = phase; hm.n_delayed = nd;
   }
 #endif
 #if HRG_LIFT
@@ -700,15 +738,15 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 }
 
 // ================================================================================================ contacts
-#if HRG_STACK
-// Contacts of two boxes with the same half extents (centres pa / pb, rotations Ra / Rb row-major in LDS): separating-axis test over the 15 axes, then
+#if HRG_STACK || HRG_HAMMER
+// Contacts of two boxes with half extents ha / hb (centres pa / pb, rotations Ra / Rb row-major in LDS; the stacking task's cubes share one h): separating-axis test over the 15 axes, then
 // the reference face's rectangle clipped against the incident face (candidates: incident vertices, rectangle corners under the incident face, edge
 // crossings; at most four penetrating candidates that span the patch are kept) or one edge-edge contact.  Restated as in
 // oracle/hrg_oracle.c box_box; one lane runs one pair.  Normal from box a to box b.  Returns the number of contacts (<= 4).
 // near-ties between separating axes / candidate depths go to the earlier one unless the later wins by this margin (1 nm)
 #define BB_TIE 1e-9
 struct BBContact { double pos[3], n[3], dist; };
-DI int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, BBContact* out, double* T) {
+DI int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, BBContact* out, double* T) {
   double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
   v3sub(t, pb, pa);
   for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = Ra[3 * k + i]; B[i][k] = Rb[3 * k + i]; }
@@ -716,12 +754,12 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
   double sf = -1e300, se = -1e300;
   int bf = 0, be = -1;
   for (int i = 0; i < 3; i++) {
-    const double s_ = fabs(ta[i]) - (h[i] + h[0] * AC[i][0] + h[1] * AC[i][1] + h[2] * AC[i][2]);
+    const double s_ = fabs(ta[i]) - (ha[i] + hb[0] * AC[i][0] + hb[1] * AC[i][1] + hb[2] * AC[i][2]);
     if (s_ > 0) return 0;
     if (s_ > sf + BB_TIE) { sf = s_; bf = i; }
   }
   for (int j = 0; j < 3; j++) {
-    const double s_ = fabs(tb[j]) - (h[j] + h[0] * AC[0][j] + h[1] * AC[1][j] + h[2] * AC[2][j]);
+    const double s_ = fabs(tb[j]) - (hb[j] + ha[0] * AC[0][j] + ha[1] * AC[1][j] + ha[2] * AC[2][j]);
     if (s_ > 0) return 0;
     if (s_ > sf + BB_TIE) { sf = s_; bf = 3 + j; }
   }
@@ -732,7 +770,7 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     if (l2 < 1e-12) continue;
     const double l = sqrt(l2);
     const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
-    const double s_ = (fabs(tl) - (h[i1] * AC[i2][j] + h[i2] * AC[i1][j] + h[j1] * AC[i][j2] + h[j2] * AC[i][j1])) / l;
+    const double s_ = (fabs(tl) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1])) / l;
     if (s_ > 0) return 0;
     if (s_ > se + BB_TIE) { se = s_; be = ij; }
   }
@@ -744,8 +782,8 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     if (v3dot(n, t) < 0) v3scl(n, n, -1.0);
     v3cpy(pA, pa); v3cpy(pB, pb);
     for (int k = 0; k < 3; k++) {
-      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * h[k]);
-      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * h[k]);
+      if (k != i) v3madd(pA, pA, A[k], (v3dot(n, A[k]) > 0 ? 1.0 : -1.0) * ha[k]);
+      if (k != j) v3madd(pB, pB, B[k], (v3dot(n, B[k]) > 0 ? -1.0 : 1.0) * hb[k]);
     }
     v3sub(d, pB, pA);
     const double uaub = C[i][j], q1 = v3dot(A[i], d), q2 = -v3dot(B[j], d), den = 1.0 - uaub * uaub;
@@ -763,23 +801,25 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
   double Rf[3][3], In[3][3], pr[3], pi_[3];
   for (int a = 0; a < 3; a++) for (int k = 0; k < 3; k++) { Rf[a][k] = refA ? A[a][k] : B[a][k]; In[a][k] = refA ? B[a][k] : A[a][k]; }
   for (int k = 0; k < 3; k++) { pr[k] = refA ? pa[k] : pb[k]; pi_[k] = refA ? pb[k] : pa[k]; }
+  const double* hr = refA ? ha : hb;   // half extents of the reference / the incident box
+  const double* hi = refA ? hb : ha;
   const double sg = refA ? (ta[r] >= 0 ? 1.0 : -1.0) : (tb[r] >= 0 ? -1.0 : 1.0);
   double nr[3], cr[3], ci[3];
   v3scl(nr, Rf[r], sg);
-  v3madd(cr, pr, nr, h[r]);
+  v3madd(cr, pr, nr, hr[r]);
   int k = 0;
   double best = -1;
   for (int q = 0; q < 3; q++) { const double c_ = fabs(v3dot(In[q], nr)); if (c_ > best) { best = c_; k = q; } }
   const int k1 = (k + 1) % 3, k2 = (k + 2) % 3;
   const double si = v3dot(In[k], nr) > 0 ? -1.0 : 1.0;
-  v3madd(ci, pi_, In[k], si * h[k]);
-  const double hu = h[r1], hv = h[r2];
+  v3madd(ci, pi_, In[k], si * hi[k]);
+  const double hu = hr[r1], hv = hr[r2];
   const double S1[4] = {1, -1, -1, 1}, S2[4] = {1, 1, -1, -1};
   double vu[4], vv[4], vd[4];
   for (int q = 0; q < 4; q++) {
     double x[3], d[3];
-    v3madd(x, ci, In[k1], S1[q] * h[k1]);
-    v3madd(x, x, In[k2], S2[q] * h[k2]);
+    v3madd(x, ci, In[k1], S1[q] * hi[k1]);
+    v3madd(x, x, In[k2], S2[q] * hi[k2]);
     v3sub(d, x, cr);
     vu[q] = v3dot(d, Rf[r1]); vv[q] = v3dot(d, Rf[r2]); vd[q] = v3dot(d, nr);
   }
@@ -792,8 +832,8 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
     double d0[3];
     v3sub(d0, ci, cr);
     const double c0u = v3dot(d0, Rf[r1]), c0v = v3dot(d0, Rf[r2]), c0d = v3dot(d0, nr);
-    const double e1u = h[k1] * v3dot(In[k1], Rf[r1]), e1v = h[k1] * v3dot(In[k1], Rf[r2]), e1d = h[k1] * v3dot(In[k1], nr);
-    const double e2u = h[k2] * v3dot(In[k2], Rf[r1]), e2v = h[k2] * v3dot(In[k2], Rf[r2]), e2d = h[k2] * v3dot(In[k2], nr);
+    const double e1u = hi[k1] * v3dot(In[k1], Rf[r1]), e1v = hi[k1] * v3dot(In[k1], Rf[r2]), e1d = hi[k1] * v3dot(In[k1], nr);
+    const double e2u = hi[k2] * v3dot(In[k2], Rf[r1]), e2v = hi[k2] * v3dot(In[k2], Rf[r2]), e2d = hi[k2] * v3dot(In[k2], nr);
     const double det = e1u * e2v - e1v * e2u;
     if (fabs(det) > 1e-12 * hu * hv)
       for (int q = 0; q < 4; q++) {
@@ -866,6 +906,9 @@ DI int box_box(const double* pa, const double* Ra, const double* pb, const doubl
   }
   return np_;
 }
+DI int box_box(const double* pa, const double* Ra, const double* pb, const double* Rb, const double* h, BBContact* out, double* T) { return box_box2(pa, Ra, h, pb, Rb, h, out, T); }
+#endif
+#if HRG_STACK
 
 // The cubes' part of the stacking task's contact list (after the robot's own rounds): robot capsule x cube first points (cube-major), table corners,
 // floor corners, cube pairs (a < b; one lane per pair), second points of capsules lying along a face; and the object_gripped sensor.
@@ -979,6 +1022,167 @@ DI void collide_cubes(const DevModel* __restrict__ dm_, int lane, int* base_io) 
     }
   }
   sk.gripped = (f0a && f1a) || (f0b && f1b);
+  *base_io = base;
+}
+#endif
+#if HRG_HAMMER
+// world poses of the hammering task's collision geoms, the nail_head body origin and the slide axis -> L.gR, L.gc, L.nail_org, L.nail_axis (oracle: hammer_geometry)
+DI void hammer_geometry(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_hammer_state& hm = L.hm;
+  wave_sync();
+  if (lane < 2) { double Rm[9]; const double q[4] = {hm.quat[lane][0], hm.quat[lane][1], hm.quat[lane][2], hm.quat[lane][3]}; quat2mat(Rm, q); for (int a = 0; a < 9; a++) L.gR[lane][a] = Rm[a]; }
+  wave_sync();
+  if (lane < 3) {
+    const int a = lane;
+    L.gc[HRG_HG_BOARD][a] = hm.pos[0][a];
+    double th = 0, te = 0, tn = 0, tg = 0;
+    for (int k = 0; k < 3; k++) {
+      th += L.gR[1][3 * a + k] * m.hm_geom_pos[HRG_HG_HANDLE][k];
+      te += L.gR[1][3 * a + k] * m.hm_geom_pos[HRG_HG_HEAD][k];
+      const double lk = k == 0 ? hm.nail_xy[0] : (k == 1 ? hm.nail_xy[1] : m.hm_nail_z0 - hm.nail_q);
+      tn += L.gR[0][3 * a + k] * lk;
+      tg += L.gR[0][3 * a + k] * m.hm_geom_pos[HRG_HG_NAIL][k];
+    }
+    L.gc[HRG_HG_HANDLE][a] = hm.pos[1][a] + th;
+    L.gc[HRG_HG_HEAD][a] = hm.pos[1][a] + te;
+    const double org = hm.pos[0][a] + tn;
+    L.nail_org[a] = org;
+    L.gc[HRG_HG_NAIL][a] = org + tg;
+    L.nail_axis[a] = -L.gR[0][3 * a + 2];
+  }
+  wave_sync();
+}
+// body_xpos of board_main, the hammer's root body and nail_head (what the observables read) from the current geometry
+DI void hammer_obs_pos(const DevModel* __restrict__ dm_, int lane) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_hammer_state& hm = L.hm;
+  if (lane < 3) {
+    double t = 0;
+    for (int k = 0; k < 3; k++) t += L.gR[1][3 * lane + k] * m.hm_hammer_com[k];
+    hm.obs_pos[0][lane] = hm.pos[0][lane];
+    hm.obs_pos[1][lane] = hm.pos[1][lane] - t;
+    hm.obs_pos[2][lane] = L.nail_org[lane];
+  }
+}
+// The hammering task's part of the contact list (after the robot's own rounds; oracle: collide_hammer): robot capsule x {board, handle, head} first points
+// (geom-major; the handle meets the two finger bars only), table corners, floor corners, the box pairs head - nail, handle - nail, head - board, handle - board
+// (one lane per pair), second points of capsules lying along a face; and the hammer_gripped sensor.
+DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io) {
+  const ModelPtr dm = uniform_model(dm_);
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_hammer_state& hm = L.hm;
+  int base = *base_io;
+  const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
+  hammer_geometry(dm_, lane);
+  bool f0 = false, f1 = false;
+#pragma unroll 1
+  for (int round = 0; round < 4; round++) {
+    Contact c;
+    c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
+    bool hit = false;
+    if (round == 0 || round == 3) {   // capsule i x geom g: first point / second point (a capsule lying along a face)
+      const bool second = round == 3;
+      const int g = lane < 3 * HRG_NRCAP ? lane / HRG_NRCAP : 0, i = lane - g * HRG_NRCAP < HRG_NRCAP ? lane - g * HRG_NRCAP : 0;
+      const int fb = g == HRG_HG_BOARD ? 0 : 1;
+      const double hb[3] = {m.hm_geom_half[g][0], m.hm_geom_half[g][1], m.hm_geom_half[g][2]};
+      bool near = false;
+      if (lane < 3 * HRG_NRCAP && m.rcap_body[i] >= 0 && !(g == HRG_HG_HANDLE && i < HRG_NRCAP - 2)) {
+        double dc[3];
+        for (int a = 0; a < 3; a++) dc[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]) - L.gc[g][a];
+        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]) + 1e-9;
+        near = v3dot(dc, dc) <= reach * reach;
+      }
+      if (__any(near) && near) {
+        double cs[3], cbp[3];
+        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], L.gc[g], L.gR[fb], hb, cs, cbp);
+        double dd = sqrt(e2), dist = dd - m.rcap_r[i];
+        if (dist < 0) {
+          double s2[3], b2[3];
+          const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], L.gc[g], L.gR[fb], hb, m.rcap_r[i], cs, cbp, second ? 1 : 0, s2, b2);
+          if (two) { v3cpy(cs, s2); v3cpy(cbp, b2); double dv[3]; v3sub(dv, cbp, cs); dd = v3norm(dv); dist = dd - m.rcap_r[i]; }
+          hit = two || !second;
+          if (dd > 1e-9) { v3sub(c.n, cbp, cs); v3scl(c.n, c.n, 1.0 / dd); }
+          else {
+            double loc[3], rel[3], best = 1e300;
+            int ax = 0;
+            v3sub(rel, cs, L.gc[g]);
+            for (int a = 0; a < 3; a++) { loc[a] = L.gR[fb][a] * rel[0] + L.gR[fb][3 + a] * rel[1] + L.gR[fb][6 + a] * rel[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
+            const double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+            for (int a = 0; a < 3; a++) c.n[a] = sg * L.gR[fb][3 * a + ax];
+            dist = -best - m.rcap_r[i];
+          }
+          v3madd(c.pos, cs, c.n, m.rcap_r[i] + 0.5 * dist);
+          c.g1 = i; c.g2 = GEOM_BOX + g; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX + fb; c.dist = dist;
+        }
+      }
+      const uint64_t mask = __ballot(hit);
+      const int slot = base + __popcll(mask & lt);
+      if (hit) {
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      if (!second) {   // hammer_gripped (1283-1289): both fingers touch a geom of the hammer (contacts beyond the reported list do not count)
+        const bool rep = hit && slot < HRG_NCON_MAX && g != HRG_HG_BOARD;
+        f0 = __any(rep && i == HRG_NRCAP - 2); f1 = __any(rep && i == HRG_NRCAP - 1);
+      }
+      base += __popcll(mask);
+    } else if (round == 1) {   // lanes 0..23: table x corner cn of geom g (board, handle, head), lanes 24..47: floor
+      if (lane < 48) {
+        const int pl = lane / 24, g = (lane - 24 * pl) >> 3, cn = lane & 7, fb = g == HRG_HG_BOARD ? 0 : 1;
+        const double hb[3] = {m.hm_geom_half[g][0], m.hm_geom_half[g][1], m.hm_geom_half[g][2]};
+        const double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]};
+        double p[3];
+        m3mulv(p, L.gR[fb], loc);
+        v3add(p, p, L.gc[g]);
+        const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
+        bool ok = true;
+        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+        if (ok && dist < 0) {
+          hit = true;
+          v3set(c.n, 0, 0, 1);
+          v3set(c.pos, p[0], p[1], z0 + 0.5 * dist);
+          c.g1 = pl ? GEOM_FLOOR : GEOM_TABLE; c.g2 = GEOM_BOX + g; c.b1 = -1; c.b2 = BODY_BOX + fb; c.dist = dist;
+        }
+      }
+      const uint64_t mask = __ballot(hit);
+      if (hit) {
+        const int slot = base + __popcll(mask & lt);
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      base += __popcll(mask);
+    } else {   // box pairs: lane p < 4 runs (head | handle) x (nail | board)
+      int nc = 0;
+      BBContact bc[4];
+      int ga = HRG_HG_HEAD, gb = HRG_HG_NAIL;
+      if (lane < 4) {
+        ga = (lane & 1) ? HRG_HG_HANDLE : HRG_HG_HEAD; gb = lane < 2 ? HRG_HG_NAIL : HRG_HG_BOARD;
+        const double ha[3] = {m.hm_geom_half[ga][0], m.hm_geom_half[ga][1], m.hm_geom_half[ga][2]}, hb[3] = {m.hm_geom_half[gb][0], m.hm_geom_half[gb][1], m.hm_geom_half[gb][2]};
+        double d[3];
+        v3sub(d, L.gc[gb], L.gc[ga]);
+        const double ra = sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]), rb = sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]);
+        // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
+        if (!(v3dot(d, d) > (ra + rb) * (ra + rb))) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + 72 * lane);
+      }
+      int pre = 0, tot = 0;
+      for (int q = 0; q < 4; q++) { const int nq = __shfl(nc, q, 64); if (q < lane) pre += nq; tot += nq; }
+      for (int q = 0; q < nc; q++) {
+        const int slot = base + pre + q;
+        c.g1 = GEOM_BOX + ga; c.g2 = GEOM_BOX + gb; c.b1 = BODY_BOX + HRG_HM_HAMMER; c.b2 = BODY_BOX + (gb == HRG_HG_NAIL ? HRG_HM_NAIL : HRG_HM_BOARD); c.dist = bc[q].dist;
+        v3cpy(c.n, bc[q].n); v3cpy(c.pos, bc[q].pos);
+        if (slot < NCON_DYN) L.con[slot] = c;
+        if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
+      }
+      base += tot;
+    }
+  }
+  hm.gripped = f0 && f1;
   *base_io = base;
 }
 #endif
@@ -1177,6 +1381,9 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
 #if HRG_STACK
   collide_cubes(dm_, lane, &base);
 #endif
+#if HRG_HAMMER
+  collide_hammer(dm_, lane, &base);
+#endif
   const int ncon = base < HRG_NCON_MAX ? base : HRG_NCON_MAX;
   if (lane < HRG_NCON_MAX && lane >= ncon) { L.st.con_pairs[lane][0] = -1; L.st.con_pairs[lane][1] = -1; }
   L.st.ncon = ncon;
@@ -1186,7 +1393,14 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
 
 // the manipulation object is whitelisted -> COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717)
 // GEOM_BOX + c: cube c of the stacking task; ReachHuman's smallBox is NOT whitelisted (a robot contact with it is a static collision)
-DI int geom_class(int g, int task) { return g < HRG_NRCAP ? HRG_GEOM_ROBOT : (g < GEOM_TABLE ? HRG_GEOM_HUMAN : (g >= GEOM_BOX && task != HRG_TASK_REACH_BOX ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC)); }
+// the hammering task white-lists the hammer's two geoms only: "the board is not white-listed" (collaborative_hammering_cartesian_env.py:1325-1337)
+DI int geom_class(int g, int task) {
+  if (g < HRG_NRCAP) return HRG_GEOM_ROBOT;
+  if (g < GEOM_TABLE) return HRG_GEOM_HUMAN;
+  if (g < GEOM_BOX || task == HRG_TASK_REACH_BOX) return HRG_GEOM_STATIC;
+  if (task == HRG_TASK_HAMMERING) return g == GEOM_BOX + HRG_HG_HANDLE || g == GEOM_BOX + HRG_HG_HEAD ? HRG_GEOM_ALLOWED : HRG_GEOM_STATIC;
+  return HRG_GEOM_ALLOWED;
+}
 DI int cantor(int a, int b) { return (a + b) * (a + b + 1) / 2 + b; }
 
 // HumanEnv._collision_detection, human_env.py:1082-1123 (+ 966-1080).  lanes = contacts of the substep; the reference's loop over the contact list is

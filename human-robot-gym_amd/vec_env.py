@@ -80,7 +80,9 @@ PICK_PLACE_OBS_KEYS = ["object_gripped", "vec_eef_to_object", "vec_eef_to_target
                        "dist_eef_to_human_lh", "dist_eef_to_human_rh"]
 STACKING_OBS_KEYS = ["object_gripped", "vec_eef_to_all_objects", "gripper_aperture", "dist_eef_to_human_head", "dist_eef_to_human_lh", "dist_eef_to_human_rh"]   # CS-SAC.yaml run.obs_keys
 LIFTING_OBS_KEYS = ["board_quat", "dist_eef_to_human_head", "vec_eef_to_human_lh", "vec_eef_to_human_rh"]   # CL-SAC.yaml run.obs_keys
-DEFAULT_OBS_KEYS = {k: (OBS_KEYS if k == "ReachHuman" else (LIFTING_OBS_KEYS if k == "CollaborativeLiftingCart" else (STACKING_OBS_KEYS if k == "CollaborativeStackingCart" else PICK_PLACE_OBS_KEYS)))
+HAMMERING_OBS_KEYS = ["hammer_gripped", "vec_eef_to_nail", "nail_hammering_progress", "vec_eef_to_board", "board_quat", "dist_eef_to_human_head", "dist_eef_to_human_lh",
+                      "dist_eef_to_human_rh"]   # no run config ships for this task; the expert reads vec_eef_to_nail (collaborative_hammering_cart_expert.py:24-25)
+DEFAULT_OBS_KEYS = {k: (HAMMERING_OBS_KEYS if k == "CollaborativeHammeringCart" else OBS_KEYS if k == "ReachHuman" else (LIFTING_OBS_KEYS if k == "CollaborativeLiftingCart" else (STACKING_OBS_KEYS if k == "CollaborativeStackingCart" else PICK_PLACE_OBS_KEYS)))
                     for k in ENV_DEFAULTS}
 # columns of the kernel's observation superset (include/hrgym.h HRG_OBS_DIM) per robosuite observable / modality key
 OBS_COLUMNS = {
@@ -103,6 +105,21 @@ OBS_COLUMNS = {
     "vec_eef_to_all_objects": list(range(12, 18)) + list(range(33, 39)), "vec_eef_to_object_a": range(12, 15), "vec_eef_to_object_b": range(15, 18),
     "vec_eef_to_object_l": range(33, 36), "vec_eef_to_object_r": range(36, 39), "next_target_pos": range(50, 53),
 }
+
+
+# per-task column overrides: the same observable name sits in other columns of the superset (oracle: compute_obs_hammer)
+OBS_COLUMNS_TASK = {
+    "CollaborativeHammeringCart": {   # collaborative_hammering_cartesian_env.py:1151-1323
+        "hammer_quat": range(12, 16), "board_pos": range(33, 36), "vec_eef_to_board": range(36, 39), "hammer_gripped": range(39, 40),
+        "vec_eef_to_hammer": range(40, 43), "vec_eef_to_nail": range(43, 46), "hammer_pos": range(47, 50), "nail_pos": range(50, 53),
+        "board_quat": range(57, 61), "nail_hammering_progress": range(61, 62),
+        # "object_quat" is never in this env's observation cache, so the two relative quaternions are constant zeros in the reference (1217-1225, 1259-1267)
+        "quat_eef_to_hammer": [62, 63, 62, 63], "quat_eef_to_board": [62, 63, 62, 63],
+        "desired_goal": range(50, 53),   # _get_desired_goal_from_obs: nail_pos (606-621)
+    },
+}
+for _k in ("hammer_quat", "hammer_gripped", "vec_eef_to_hammer", "vec_eef_to_nail", "hammer_pos", "nail_pos", "nail_hammering_progress", "quat_eef_to_hammer", "quat_eef_to_board"):
+    OBS_COLUMNS.setdefault(_k, OBS_COLUMNS_TASK["CollaborativeHammeringCart"][_k])
 
 
 _EAGER_KEYS = frozenset(("terminal_observation", "episode", "TimeLimit.truncated"))   # what SB3's rollout loops look up on every info
@@ -245,7 +262,7 @@ class HipVecEnv(_VecEnvBase):
         # the cube tasks [eef_pos, object_pos, object_gripped] vs target_pos (pick_place_human_cartesian_env.py:574-611)
         self.goal_env = bool(goal_env)
         if self.goal_env:
-            if env_id in ("HumanObjectInspectionCart", "CollaborativeLiftingCart", "CollaborativeStackingCart"):
+            if env_id in ("HumanObjectInspectionCart", "CollaborativeLiftingCart", "CollaborativeStackingCart", "CollaborativeHammeringCart"):
                 raise NotImplementedError("goal_env: this task's success is a task phase, not a function of the goals")
             if obs_keys is None:  # goal_env_wrapper.py:62-71
                 obs_keys = ["object-state", "robot0_proprio-state", "desired_goal"]
@@ -265,6 +282,8 @@ class HipVecEnv(_VecEnvBase):
         cols_of = dict(OBS_COLUMNS)
         if env_id != "ReachHuman":
             cols_of["desired_goal"] = OBS_COLUMNS["target_pos"]   # _get_desired_goal_from_obs of the cube tasks
+        cols_of.update(OBS_COLUMNS_TASK.get(env_id, {}))
+        self._cols_of = cols_of
         self._cols = np.array([c for k in keys for c in cols_of[k]], dtype=np.int64)  # GymWrapper: concatenate in key order
         kw = dict(env_kwargs or {})
         if seed is not None:
@@ -434,6 +453,8 @@ class HipVecEnv(_VecEnvBase):
         states, boxes = batch.get_states(np.asarray(idx, np.int32))
         if self.env_id == "CollaborativeStackingCart":   # CollaborativeStackingEnvState (collaborative_stacking_cartesian_env.py:63-97): the four cubes + stack bookkeeping
             return [(st, batch.get_stack(i)) for st, i in zip(states, idx)]
+        if self.env_id == "CollaborativeHammeringCart":  # CollaborativeHammeringEnvState (collaborative_hammering_cartesian_env.py:56-89): board, hammer, nail + bookkeeping
+            return [(st, batch.get_hammer(i)) for st, i in zip(states, idx)]
         has_box = self.env_id != "ReachHuman"
         return [(st, boxes[k] if has_box else None) for k, st in enumerate(states)]
 
@@ -446,10 +467,10 @@ class HipVecEnv(_VecEnvBase):
             raise ValueError(f"{len(states)} states for {len(idx)} envs")
         from ._cstruct import BoxState, EnvState
         st_arr = (EnvState * len(idx))(*[st for st, _ in states])
-        if self.env_id == "CollaborativeStackingCart":
+        if self.env_id in ("CollaborativeStackingCart", "CollaborativeHammeringCart"):
             batch.set_states(np.asarray(idx, np.int32), st_arr, None)
             for i, (_, sk) in zip(idx, states):
-                batch.set_stack(i, sk)
+                (batch.set_stack if self.env_id == "CollaborativeStackingCart" else batch.set_hammer)(i, sk)
             return
         boxes = [b for _, b in states]
         bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and self.env_id != "ReachHuman" else None
