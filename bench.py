@@ -113,6 +113,7 @@ OTHER_TASKS = {  # --env values beyond the two benchmark configurations: (env kw
     "RobotHumanHandoverCart": (dict(horizon=1000, shield_type="PFL"), "hrg_step_kernel_ho"),
     "CollaborativeLiftingCart": (dict(horizon=5000), "hrg_step_kernel_lift"),
     "CollaborativeStackingCart": (dict(horizon=3000), "hrg_step_kernel_stack"),
+    "CollaborativeHammeringCart": (dict(horizon=1000), "hrg_step_kernel_hammer"),
 }
 
 
@@ -235,6 +236,8 @@ def main():
     if args.env in OTHER_TASKS:
         env_kwargs = dict(shield_type=args.shield, control_freq=10, seed=1234)
         env_kwargs.update(OTHER_TASKS[args.env][0])
+        from human_robot_gym_amd.mixed import task_env_kwargs
+        env_kwargs.update(task_env_kwargs(args.env))   # what goes with the task's synthetic clips (hammering: the weld pose that holds the board level)
         args.shield = env_kwargs["shield_type"]
     elif pick_place:  # training/config/environment/pick_place_human_cart.yaml
         env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=1000, done_at_success=False, goal_dist=0.1,
@@ -315,13 +318,13 @@ def main():
         elapsed = float(t.item())
     if rank == 0:
         lib = load_library()
-        obj_bytes = lib.hrg_stack_bytes() if args.env == "CollaborativeStackingCart" else (lib.hrg_box_bytes() if pick_place else 0)   # the task's object block, streamed next to the env block
+        obj_bytes = lib.hrg_stack_bytes() if args.env == "CollaborativeStackingCart" else (lib.hrg_hammer_bytes() if args.env == "CollaborativeHammeringCart" else (lib.hrg_box_bytes() if pick_place else 0))   # the task's object block, streamed next to the env block
         state_bytes = lib.hrg_state_bytes() + obj_bytes
         per_env = algorithmic_bytes_per_env_step(C, state_bytes, desc.n_cycles)
         if mixed_tasks:  # each task streams its own object block; the kernels overlap, so the launch duration is the step's wall time
             tot = 0
             for env_id, sl in zip(G.env_ids, G.slices):
-                ob = 0 if env_id == "ReachHuman" else (lib.hrg_stack_bytes() if env_id == "CollaborativeStackingCart" else lib.hrg_box_bytes())
+                ob = 0 if env_id == "ReachHuman" else (lib.hrg_stack_bytes() if env_id == "CollaborativeStackingCart" else (lib.hrg_hammer_bytes() if env_id == "CollaborativeHammeringCart" else lib.hrg_box_bytes()))
                 tot += (sl.stop - sl.start) * algorithmic_bytes_per_env_step(C, lib.hrg_state_bytes() + ob, desc.n_cycles)
             per_env = tot / n
             kernel_ms = 1e3 * elapsed / args.steps

@@ -22,6 +22,8 @@ ICRA_TASKS = (
 )
 
 
+# ... and with the one task of the reference that is not part of that suite (CollaborativeHammeringCart has no experiment config): every task the stepper covers
+ALL_TASKS = ICRA_TASKS + (("CollaborativeHammeringCart", dict(horizon=1000, shield_type="SSM")),)
 _STEP_MS = {"CollaborativeStackingCart": 10.65, "RobotHumanHandoverCart": 6.13, "HumanRobotHandoverCart": 5.06, "CollaborativeLiftingCart": 4.42,
             "HumanObjectInspectionCart": 3.05, "PickPlaceHumanCart": 2.2, "ReachHuman": 1.39}
 
@@ -155,7 +157,7 @@ def make_mixed_batch(n_envs, tasks=ICRA_TASKS, env_kwargs=None, clips=None, n_cl
     for (env_id, kw), k in zip(tasks, counts):
         if k == 0:
             continue
-        kw = dict(env_kwargs or {}, **kw)
+        kw = dict(task_env_kwargs(env_id), **dict(env_kwargs or {}, **kw))
         if seed is not None:
             kw["seed"] = int(seed)
         c = (clips or {}).get(env_id) if isinstance(clips, dict) else None
@@ -209,7 +211,7 @@ class _MixedBackend:
 def make_mixed_vec_env(n_envs, tasks=ICRA_TASKS, obs_keys=None, env_kwargs=None, seed=None, start_index=0, clips=None, n_clips=13,
                        device=0, info_dicts=True, concurrent=True):
     """A `HipVecEnv`-shaped VecEnv over a mixed batch.  One policy sees every task, so the observation is the same columns for all
-    of them: `obs_keys` (names valid for every task) or, by default, the whole 57-column observation superset (columns a task does
+    of them: `obs_keys` (names valid for every task) or, by default, the whole 64-column observation superset (columns a task does
     not fill are zero).  `infos[i]["task"]` names the task of row i; `env.task_slices` maps env ids to row ranges."""
     batch = make_mixed_batch(n_envs, tasks, env_kwargs=env_kwargs, clips=clips, n_clips=n_clips, seed=seed, env_id0=start_index,
                              device=device, concurrent=concurrent)

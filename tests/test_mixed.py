@@ -27,18 +27,19 @@ def test_mixed_batch_fails_loudly_without_a_gpu():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("concurrent", [True, False])
-def test_mixed_batch_equals_the_per_task_batches(concurrent):
-    """Each task's rows of a mixed batch are bit-identical to that task stepped alone (same global env ids, same actions)."""
+@pytest.mark.parametrize("concurrent,tasks", [(True, "ICRA_TASKS"), (False, "ICRA_TASKS"), (True, "ALL_TASKS")])
+def test_mixed_batch_equals_the_per_task_batches(concurrent, tasks):
+    """Each task's rows of a mixed batch are bit-identical to that task stepped alone (same global env ids, same actions); ALL_TASKS adds the hammering task."""
     import torch
     from human_robot_gym_amd._lib import HipBatch
-    n = 42
-    M = mixed.make_mixed_batch(n, n_clips=3, seed=5, concurrent=concurrent)
-    assert M.env_ids == [t[0] for t in mixed.ICRA_TASKS] and M.n == n
+    tasks = getattr(mixed, tasks)
+    n = 7 * len(tasks)
+    M = mixed.make_mixed_batch(n, tasks=tasks, n_clips=3, seed=5, concurrent=concurrent)
+    assert M.env_ids == [t[0] for t in tasks] and M.n == n
     singles = []
-    for (env_id, kw), sl in zip(mixed.ICRA_TASKS, M.slices):
+    for (env_id, kw), sl in zip(tasks, M.slices):
         clips = mixed.task_clips(env_id, 3)
-        desc = hrg.build_model_desc(dict(kw, seed=5), n_clips=clips.n_clips, env_id=env_id)
+        desc = hrg.build_model_desc(dict(mixed.task_env_kwargs(env_id), **dict(kw, seed=5)), n_clips=clips.n_clips, env_id=env_id)
         singles.append(HipBatch(desc, clips, sl.stop - sl.start, env_id0=sl.start))
     obs = M.reset().cpu().numpy()
     for S, sl in zip(singles, M.slices):
@@ -63,9 +64,9 @@ def test_mixed_batch_equals_the_per_task_batches(concurrent):
 @pytest.mark.gpu
 def test_mixed_vec_env_surface():
     env = mixed.make_mixed_vec_env(12, env_kwargs=dict(horizon=5), tasks=[(e, dict(k, horizon=5)) for e, k in mixed.ICRA_TASKS], n_clips=2, seed=1)
-    assert env.num_envs == 12 and env.observation_space.shape == (57,) and env.action_space.shape == (7,)
+    assert env.num_envs == 12 and env.observation_space.shape == (64,) and env.action_space.shape == (7,)
     obs = env.reset()
-    assert obs.shape == (12, 57) and obs.dtype == np.float32
+    assert obs.shape == (12, 64) and obs.dtype == np.float32
     assert np.all(obs[env.task_slices["ReachHuman"], 39:53] == 0)              # cube columns: zero for ReachHuman
     assert np.any(obs[env.task_slices["PickPlaceHumanCart"], 47:50] != 0)      # object_pos
     rng = np.random.RandomState(0)
@@ -76,7 +77,7 @@ def test_mixed_vec_env_surface():
         for d, done in zip(infos, dones):
             assert ("terminal_observation" in d) == bool(done)
             if done:
-                assert d["terminal_observation"].shape == (57,) and d["episode"]["l"] <= 5
+                assert d["terminal_observation"].shape == (64,) and d["episode"]["l"] <= 5
         n_done += int(dones.sum())
     assert n_done >= 12                                                         # horizon 5: every env timed out once (a board may also be dropped earlier)
     env2 = mixed.make_mixed_vec_env(8, obs_keys=["robot0_eef_pos", "dist_eef_to_human_head"], n_clips=2)
