@@ -765,6 +765,11 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   }
   STAMP(21);
   COUNT(19, __popcll(__ballot(R[0].active)) + __popcll(__ballot(R[1].active)));
+  // does a contact join the board / nail block to another block (hammer on the board or the nail, robot on the board)?  Otherwise the Newton system splits.
+  bool bc_ = false;
+  if (lane < nc) { const Contact& cc = L.con[lane]; const bool b1 = cc.b1 == BODY_BOX + HRG_HM_BOARD || cc.b1 == BODY_BOX + HRG_HM_NAIL, b2 = cc.b2 == BODY_BOX + HRG_HM_BOARD || cc.b2 == BODY_BOX + HRG_HM_NAIL;
+    bc_ = (b1 && cc.b2 >= 0) || (b2 && cc.b1 >= 0); }
+  const bool board_coupled = __any(bc_);
   wave_sync();
   auto rowdot = [&](const HRow& w, const double* x) -> double {
     if (!w.active) return 0.0;
@@ -876,9 +881,22 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     COUNT(18, 1);
     {
       bool good = true;
-      tiles_pivots<3, 0, 0>(T, mi, mj, 8, good);
-      tiles_pivots<3, 1, 0>(T, mi, mj, 7, good);
-      tiles_pivots<3, 2, 0>(T, mi, mj, 6, good);
+      if (board_coupled) {
+        tiles_pivots<3, 0, 0>(T, mi, mj, 8, good);
+        tiles_pivots<3, 1, 0>(T, mi, mj, 7, good);
+        tiles_pivots<3, 2, 0>(T, mi, mj, 6, good);
+      } else {   // no contact row joins the board / nail to the robot or the hammer: the board block on its own, robot + hammer as 2 x 2 tiles
+        Tiles<2> T2;
+        Tiles<1> T1;
+        T2.t[0][0] = T.t[0][0]; T2.t[0][1] = T.t[0][2]; T2.t[1][0] = T.t[2][0]; T2.t[1][1] = T.t[2][2];
+        T1.t[0][0] = T.t[1][1];
+        tiles_pivots<2, 0, 0>(T2, mi, mj, 8, good);
+        tiles_pivots<2, 1, 0>(T2, mi, mj, 6, good);
+        tiles_pivots<1, 0, 0>(T1, mi, mj, 7, good);
+        T.t[0][0] = T2.t[0][0]; T.t[0][2] = T2.t[0][1]; T.t[2][0] = T2.t[1][0]; T.t[2][2] = T2.t[1][1];
+        T.t[1][1] = T1.t[0][0];
+        T.t[0][1] = 0.0; T.t[1][0] = 0.0; T.t[1][2] = 0.0; T.t[2][1] = 0.0;
+      }
       if (!good) break;
     }
     STAMP(24);
@@ -2671,7 +2689,10 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
   for (int k = lane; k < NB; k += 64) out[k] = src[k];
 }
 #elif HRG_HAMMER
-#define HRG_KERNEL_WAVES 1   // 33 KB of LDS per env (89 dense rows of J over 24 DoF): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
+#ifndef HRG_HAMMER_WAVES
+#define HRG_HAMMER_WAVES 2   // 256 registers: five 30 KB workgroups per CU instead of four (8.88 -> 8.09 ms per 4096-env step; 752 B/lane of scratch)
+#endif
+#define HRG_KERNEL_WAVES HRG_HAMMER_WAVES   // 30 KB of LDS per env (89 dense rows of J over 24 DoF): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
 DI void box_load(const hrg_hammer_state* __restrict__ hammers, int e, int lane) {
   constexpr int NB = (int)(sizeof(hrg_hammer_state) / sizeof(double));
   const double* src = (const double*)(hammers + e);

@@ -1093,10 +1093,15 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
       const double hb[3] = {m.hm_geom_half[g][0], m.hm_geom_half[g][1], m.hm_geom_half[g][2]};
       bool near = false;
       if (lane < 3 * HRG_NRCAP && m.rcap_body[i] >= 0 && !(g == HRG_HG_HANDLE && i < HRG_NRCAP - 2)) {
-        double dc[3];
+        // broadphase: the capsule's bounding sphere against the box itself (distance of its centre to the box in the box frame); conservative
+        double dc[3], d2 = 0;
         for (int a = 0; a < 3; a++) dc[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]) - L.gc[g][a];
-        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]) + 1e-9;
-        near = v3dot(dc, dc) <= reach * reach;
+        for (int a = 0; a < 3; a++) {
+          const double la = fabs(L.gR[fb][a] * dc[0] + L.gR[fb][3 + a] * dc[1] + L.gR[fb][6 + a] * dc[2]) - hb[a];
+          if (la > 0) d2 += la * la;
+        }
+        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + 1e-9;
+        near = d2 <= reach * reach;
       }
       if (__any(near) && near) {
         double cs[3], cbp[3];
@@ -1164,11 +1169,16 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
       if (lane < 4) {
         ga = (lane & 1) ? HRG_HG_HANDLE : HRG_HG_HEAD; gb = lane < 2 ? HRG_HG_NAIL : HRG_HG_BOARD;
         const double ha[3] = {m.hm_geom_half[ga][0], m.hm_geom_half[ga][1], m.hm_geom_half[ga][2]}, hb[3] = {m.hm_geom_half[gb][0], m.hm_geom_half[gb][1], m.hm_geom_half[gb][2]};
-        double d[3];
-        v3sub(d, L.gc[gb], L.gc[ga]);
-        const double ra = sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]), rb = sqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]);
+        // broadphase: the circumsphere of the hammer's box against the other box itself (conservative: separated boxes give no contacts anyway)
+        double d[3], d2 = 0;
+        v3sub(d, L.gc[ga], L.gc[gb]);
+        for (int a = 0; a < 3; a++) {
+          const double la = fabs(L.gR[0][a] * d[0] + L.gR[0][3 + a] * d[1] + L.gR[0][6 + a] * d[2]) - hb[a];
+          if (la > 0) d2 += la * la;
+        }
+        const double ra = sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]) + 1e-9;
         // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
-        if (!(v3dot(d, d) > (ra + rb) * (ra + rb))) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + 72 * lane);
+        if (!(d2 > ra * ra)) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + 72 * lane);
       }
       int pre = 0, tot = 0;
       for (int q = 0; q < 4; q++) { const int nq = __shfl(nc, q, 64); if (q < lane) pre += nq; tot += nq; }
