@@ -2675,7 +2675,10 @@ DI void box_store(hrg_box_state* __restrict__ boxes, int e, int lane) {
   if (lane < NB) out[lane] = src[lane];
 }
 #elif HRG_STACK
-#define HRG_KERNEL_WAVES 1   // 35 KB of LDS per env (92 compact contact rows, the packed 32x32 Hessian): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
+#ifndef HRG_STACK_WAVES
+#define HRG_STACK_WAVES 2   // measured: 8.05 -> 7.45 ms per 4096-env step (mixed six-task batch 5.68 -> 5.33 ms), 768 B/lane of scratch
+#endif
+#define HRG_KERNEL_WAVES HRG_STACK_WAVES   // 28 KB of LDS per env (92 compact contact rows): 1 = 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs; 2 = 256 registers, five per CU
 DI void box_load(const hrg_stack_state* __restrict__ stacks, int e, int lane) {
   constexpr int NB = (int)(sizeof(hrg_stack_state) / sizeof(double));
   const double* src = (const double*)(stacks + e);

@@ -3,5 +3,5 @@
 // code reaches the other tasks' kernels.
 #define HRG_STACK 1
 #undef HRG_WG_WAVES
-#define HRG_WG_WAVES 1   // 38 KB of LDS per env: one env per workgroup
+#define HRG_WG_WAVES 1   // 28 KB of LDS per env: one env per workgroup
 #include "hrgym_hip.hip"
