@@ -1689,6 +1689,16 @@ DI void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
   wave_sync();
 }
 
+#if HRG_LIFT || HRG_HANDOVER
+// rotation matrix (row-major) -> unit quaternion (w, x, y, z), largest-component branch
+DI void mat2quat(double* q, const double* R) {
+  const double tr = R[0] + R[4] + R[8];
+  if (tr > 0) { const double s_ = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s_; q[1] = (R[7] - R[5]) / s_; q[2] = (R[2] - R[6]) / s_; q[3] = (R[3] - R[1]) / s_; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s_ = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s_; q[1] = 0.25 * s_; q[2] = (R[1] + R[3]) / s_; q[3] = (R[2] + R[6]) / s_; }
+  else if (R[4] > R[8]) { const double s_ = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s_; q[1] = (R[1] + R[3]) / s_; q[2] = 0.25 * s_; q[3] = (R[5] + R[7]) / s_; }
+  else { const double s_ = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s_; q[1] = (R[2] + R[6]) / s_; q[2] = (R[5] + R[7]) / s_; q[3] = 0.25 * s_; }
+}
+#endif
 // observation: object-state (vec/dist eef -> L hand, R hand, head; human_env.py:1536-1590) + goal_difference
 // (environments/manipulation/reach_human_env.py:649-651); lanes = observation entries
 DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal, float* out) {
@@ -1770,6 +1780,20 @@ DI void write_obs(const DevModel* __restrict__ dm_, int lane, const double* goal
       v = ap / HRG_NFINGER;
     } else if (lane >= 47 && lane < 50) v = bx.obs_pos[lane - 47];
     else if (lane >= 50 && lane < 53) v = bx.target[lane - 50];
+#if HRG_LIFT || HRG_HANDOVER
+    if (lane >= 57 && lane < 61 && (HRG_IS_HANDOVER(m.task) || m.task == HRG_TASK_LIFTING)) {
+      // quat_eef_to_object (human_robot_handover_cartesian_env.py:916-924, robot_human_handover_cartesian_env.py:998-1006) / quat_eef_to_board
+      // (collaborative_lifting_cartesian_env.py:1057-1065) as the reference computes them (oracle: compute_obs_e): the (x, y, z, w) observables are read as
+      // (w, x, y, z), so the product is that of the scrambled quaternions (scalar x, vector (y, z, w)); A conj(B) as (x, y, z, w)
+      double qe[4], Re[9];
+      for (int a = 0; a < 9; a++) Re[a] = L.kR[NARM][a];
+      mat2quat(qe, Re);
+      const double sA = bx.quat[1], vA[3] = {bx.quat[2], bx.quat[3], bx.quat[0]}, sB = qe[1], vB[3] = {qe[2], qe[3], qe[0]};
+      double cr[3];
+      v3cross(cr, vA, vB);
+      v = lane == 60 ? sA * sB + v3dot(vA, vB) : -sA * vB[lane - 57] + sB * vA[lane - 57] - cr[lane - 57];
+    }
+#endif
 #if HRG_LIFT
     if (m.task == HRG_TASK_LIFTING) { // collaborative_lifting_cartesian_env.py:982-1085: board_balance in the first target column, board_quat (x, y, z, w) in 43-45 and 51
       if (lane >= 43 && lane < 46) v = bx.quat[1 + lane - 43];
@@ -1932,14 +1956,6 @@ DI void eef_update(const DevModel* __restrict__ dm_) {
 }
 
 #if HRG_LIFT
-// rotation matrix (row-major) -> unit quaternion (w, x, y, z), largest-component branch
-DI void mat2quat(double* q, const double* R) {
-  const double tr = R[0] + R[4] + R[8];
-  if (tr > 0) { const double s_ = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s_; q[1] = (R[7] - R[5]) / s_; q[2] = (R[2] - R[6]) / s_; q[3] = (R[3] - R[1]) / s_; }
-  else if (R[0] > R[4] && R[0] > R[8]) { const double s_ = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s_; q[1] = 0.25 * s_; q[2] = (R[1] + R[3]) / s_; q[3] = (R[2] + R[6]) / s_; }
-  else if (R[4] > R[8]) { const double s_ = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s_; q[1] = (R[1] + R[3]) / s_; q[2] = 0.25 * s_; q[3] = (R[5] + R[7]) / s_; }
-  else { const double s_ = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s_; q[1] = (R[2] + R[6]) / s_; q[2] = (R[5] + R[7]) / s_; q[3] = 0.25 * s_; }
-}
 // _update_mocap_body_transforms (collaborative_lifting_cartesian_env.py:590-616): the two mocap bodies sit at the hand sites
 DI void lifting_mocap(const DevModel* __restrict__ dm_, int lane) {
   const ModelPtr dm = uniform_model(dm_);

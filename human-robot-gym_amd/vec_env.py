@@ -100,6 +100,8 @@ OBS_COLUMNS = {
     "board_pos": range(47, 50), "vec_eef_to_board": range(40, 43), "board_gripped": range(39, 40), "board_balance": range(50, 51),
     "board_quat": [43, 44, 45, 51],
     "object_quat": range(12, 16),   # the cube tasks: orientation of the manipulation object, (x, y, z, w)
+    # the handover tasks' quat_eef_to_object / CollaborativeLiftingCart's quat_eef_to_board, computed like the reference does (see oracle compute_obs_e)
+    "quat_eef_to_object": range(57, 61),
     # CollaborativeStackingCart (collaborative_stacking_cartesian_env.py:1306-1524): the vectors to the four cubes (a, b, l, r) take the 12 joint-space columns the cube
     # tasks leave empty; vec_eef_to_object / object_pos follow the cube the robot has to place next; next_target_pos sits in the target columns
     "vec_eef_to_all_objects": list(range(12, 18)) + list(range(33, 39)), "vec_eef_to_object_a": range(12, 15), "vec_eef_to_object_b": range(15, 18),
@@ -118,8 +120,9 @@ OBS_COLUMNS_TASK = {
         "desired_goal": range(50, 53),   # _get_desired_goal_from_obs: nail_pos (606-621)
     },
 }
-for _k in ("hammer_quat", "hammer_gripped", "vec_eef_to_hammer", "vec_eef_to_nail", "hammer_pos", "nail_pos", "nail_hammering_progress", "quat_eef_to_hammer", "quat_eef_to_board"):
+for _k in ("hammer_quat", "hammer_gripped", "vec_eef_to_hammer", "vec_eef_to_nail", "hammer_pos", "nail_pos", "nail_hammering_progress", "quat_eef_to_hammer"):
     OBS_COLUMNS.setdefault(_k, OBS_COLUMNS_TASK["CollaborativeHammeringCart"][_k])
+OBS_COLUMNS["quat_eef_to_board"] = range(57, 61)   # CollaborativeLiftingCart (hammering overrides it with its constant zeros)
 
 
 _EAGER_KEYS = frozenset(("terminal_observation", "episode", "TimeLimit.truncated"))   # what SB3's rollout loops look up on every info

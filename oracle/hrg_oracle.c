@@ -1268,7 +1268,11 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
 }
 
 /* =============================================================================================== env */
-static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const hrg_box_state* bx, const double* goal, float* obs) {
+static void mat2quat(double* q, const double* R);
+/* Re: rotation matrix of the robot's right_hand body (= the finger bodies' frame) of the last forward pass, or NULL (tasks without a relative-quaternion observable) */
+static void compute_obs_e(const hrg_model_desc* m, const hrg_env_state* s, const hrg_box_state* bx, const double* goal, const double* Re, float* obs);
+static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const hrg_box_state* bx, const double* goal, float* obs) { compute_obs_e(m, s, bx, goal, NULL, obs); }
+static void compute_obs_e(const hrg_model_desc* m, const hrg_env_state* s, const hrg_box_state* bx, const double* goal, const double* Re, float* obs) {
   /* object-state: vec/dist eef -> {L hand, R hand, head} (human_env.py:1536-1590, reach_human_env.py:637-640),
    * then goal_difference (reach_human_env.py:649-651) */
   int sites[3] = {m->site_lhand, m->site_rhand, m->site_head};
@@ -1297,6 +1301,19 @@ static void compute_obs(const hrg_model_desc* m, const hrg_env_state* s, const h
       obs[43 + a] = (float)(bx->target[a] - s->eef_pos[a]);
       obs[47 + a] = (float)bx->obs_pos[a];
       obs[50 + a] = (float)bx->target[a];
+    }
+    if (Re && (HRG_IS_HANDOVER(m->task) || m->task == HRG_TASK_LIFTING)) {
+      /* quat_eef_to_object (human_robot_handover_cartesian_env.py:916-924, robot_human_handover_cartesian_env.py:998-1006) / quat_eef_to_board
+       * (collaborative_lifting_cartesian_env.py:1057-1065), restated as the reference computes them: object_quat / board_quat and robot0_eef_quat are
+       * (x, y, z, w) arrays, quat_to_rot reads them as (w, x, y, z) -- so the rotations that get multiplied are those of the scrambled quaternions
+       * (scalar x, vector (y, z, w)).  Result = A conj(B) as (x, y, z, w); its overall sign is a convention (scipy keeps whatever the product gives). */
+      double qe[4];
+      mat2quat(qe, Re);
+      const double sA = bx->quat[1], vA[3] = {bx->quat[2], bx->quat[3], bx->quat[0]}, sB = qe[1], vB[3] = {qe[2], qe[3], qe[0]};
+      double cr[3];
+      v3cross(cr, vA, vB);
+      for (int a = 0; a < 3; a++) obs[57 + a] = (float)(-sA * vB[a] + sB * vA[a] - cr[a]);
+      obs[60] = (float)(sA * sB + v3dot(vA, vB));
     }
     if (m->task == HRG_TASK_LIFTING) { /* collaborative_lifting_cartesian_env.py:982-1085: board_pos / vec_eef_to_board / board_gripped sit in the object columns;
                                         * board_balance takes the first target column, board_quat columns 43-45 and 51 (quat_eef_to_board: not served) */
@@ -1665,7 +1682,7 @@ static void env_reset(hrgo_batch* B, int e, float* obs) {
     if (m->task != HRG_TASK_LIFTING) v3cpy(bx->obs_pos, bx->pos);
     if (m->task == HRG_TASK_REACH_BOX) goal_of(B, gid, s, 0, s->cur_goal);
   } else goal_of(B, gid, s, 0, s->cur_goal);
-  if (obs) compute_obs(m, s, bx, s->cur_goal, obs);
+  if (obs) compute_obs_e(m, s, bx, s->cur_goal, k.R[NARM], obs);
 }
 
 static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
@@ -1915,7 +1932,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
     const double scaling = (hand[2] - m->table_top_z) / dir[2];
     for (int a = 0; a < 3; a++) bx->target[a] = hand[a] - scaling * dir[a];
   }
-  compute_obs(m, s, bx, goal, term_obs);
+  compute_obs_e(m, s, bx, goal, k.R[NARM], term_obs);
   double dist2 = 0, dense;
   int goal_reached;
   double r;

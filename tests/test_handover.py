@@ -259,3 +259,33 @@ def test_choreographed_handover_clips_hold_the_hand_out_within_reach():
             assert (h[k0][1] < 0) == left                                       # facing the robot: left hand at -y
             assert h[0][0] > 1.2 and h[-1][0] > 1.2 and h[0][2] < 0.7           # arms down at the start and the end
             assert np.allclose(other, other[0])                                 # the other arm never moves
+
+
+@pytest.mark.parametrize("env_id", ["HumanRobotHandoverCart", "RobotHumanHandoverCart", "CollaborativeLiftingCart"])
+def test_relative_quaternion_observable_follows_the_reference_formula(env_id):
+    """quat_eef_to_object / quat_eef_to_board (human_robot_handover_cartesian_env.py:916-924, collaborative_lifting_cartesian_env.py:1057-1065): the reference feeds
+    its (x, y, z, w) observables to quat_to_rot, which expects (w, x, y, z).  The superset's columns 57:61 reproduce exactly that computation -- checked here by
+    running the reference's own expression with scipy on the observed object quaternion and the end-effector orientation (sign = convention)."""
+    from scipy.spatial.transform import Rotation
+    from oracle.oracle import OracleBatch
+    from human_robot_gym_amd.mixed import task_clips
+    from human_robot_gym_amd.model import robot_fk_numpy
+    clips = task_clips(env_id, 2, min_frames=200, max_frames=260)
+    d = hrg.build_model_desc(dict(shield_type="OFF", horizon=50, seed=3), n_clips=clips.n_clips, env_id=env_id)
+    B = OracleBatch(d, clips, 3)
+    obs = B.reset()
+    quat_to_rot = lambda q: Rotation.from_quat([q[1], q[2], q[3], q[0]])       # utils/mjcf_utils.py:94-97
+    rot_to_quat = lambda r: [r.as_quat()[3], r.as_quat()[0], r.as_quat()[1], r.as_quat()[2]]   # utils/mjcf_utils.py:88-91
+    for e in range(3):
+        st, bx = B.get_state(e), B.get_box(e)
+        R, _ = robot_fk_numpy(d, list(st.qpos))
+        eef_xyzw = Rotation.from_matrix(R[6]).as_quat()                          # robot0_eef_quat: T.convert_quat(body_xquat(right_hand), "xyzw")
+        obj_xyzw = np.array([bx.quat[1], bx.quat[2], bx.quat[3], bx.quat[0]])   # object_quat / board_quat: (x, y, z, w)
+        if env_id != "CollaborativeLiftingCart":
+            np.testing.assert_allclose(obs[e, 12:16], obj_xyzw, atol=1e-6)
+        q = rot_to_quat(quat_to_rot(obj_xyzw) * quat_to_rot(eef_xyzw).inv())
+        want = np.array([q[1], q[2], q[3], q[0]])                                # T.convert_quat(quat, "xyzw")
+        got = obs[e, 57:61].astype(np.float64)
+        assert np.linalg.norm(got) == pytest.approx(1.0, abs=1e-6)
+        assert min(np.abs(got - want).max(), np.abs(got + want).max()) < 2e-6
+    B.close()

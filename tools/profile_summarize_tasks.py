@@ -3,7 +3,7 @@
 import csv, glob, json, os, sys
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02t"
 go, pr = "gpurun_out", "profiles"
-tasks = ["HumanObjectInspectionCart", "HumanRobotHandoverCart", "RobotHumanHandoverCart", "CollaborativeLiftingCart", "CollaborativeStackingCart"]
+tasks = ["HumanObjectInspectionCart", "HumanRobotHandoverCart", "RobotHumanHandoverCart", "CollaborativeLiftingCart", "CollaborativeStackingCart", "CollaborativeHammeringCart"]
 L = [f"# rocprofv3 summary `{tag}` — the collaboration tasks' kernel variants (`bash tools/profile_capture_tasks.sh {tag}`, 1 x MI355X, 4096 envs each)", "",
      "`rocprofv3 --kernel-trace --stats -- python3 bench.py --env TASK --steps 40 --warmup 10 --preroll 200 --no-cpu-baseline` per task (kernel_stats.csv row of the step kernel), and the",
      f"un-profiled `python3 bench.py --env TASK --steps 60 --warmup 10 --cpu-budget 6` JSON line (steady state: pre-roll of min(horizon, 1000) steps, staggered episode phases) (`{tag}_<task>_bench.json`).", "",
@@ -33,7 +33,7 @@ for t in tasks:
         T.append(f"| {t} | {v['FETCH_SIZE']:.0f} | {v['WRITE_SIZE']:.0f} | {fm:.1f} (x2 = {2 * fm:.1f}) | {wm:.1f} | **{2 * fm + wm:.1f}** | {rf['algorithmic_bytes_per_launch'] / 1e6:.1f} | {v['vgpr']} | {v['scratch']} |")
 L += ["", "Shield types as in `training/icra_2024_run_experiments.sh:4-9` (PFL for the handover tasks, SSM otherwise); 13 synthetic clips with the animation info each task reads",
       "(`mixed.task_clips`); random joint-space actions U(-1,1)^7.  The handover kernel runs two physics passes per shield cycle (the reference's extra `sim.step()`); the stacking",
-      "kernel steps a 32-DoF system (robot tree + four free cubes) at one wave per SIMD (38 KB of LDS per env)."]
+      "kernel steps a 32-DoF system (robot tree + four free cubes) and the hammering kernel a 24-DoF system (robot tree, board + nail, hammer), both at two waves per SIMD where their ~30 KB of LDS per env allow (five workgroups per CU)."]
 if len(T) == 5:   # no PMC passes were captured for this tag
     T = ["", "HBM traffic (PMC) was not captured for the task variants under this tag; `profiles/r01t_tasks_summary.md` holds round 1's."]
 open(f"{pr}/{tag}_tasks_summary.md", "w").write("\n".join(L + T) + "\n")
