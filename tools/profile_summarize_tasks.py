@@ -21,7 +21,10 @@ for t in tasks:
     L.append(f"| {t} | `{rf['kernel']}` | {row['Calls']} | {float(row['AverageNs']):.0f} | {row['MinNs']} | {row['MaxNs']} | {b['value']:.0f} | {b['ms_per_step']:.3f} | {rf['kernel_ms']:.3f} | "
              f"{rf['algorithmic_bytes_per_launch'] / 1e6:.1f} | {rf['frac']:.5f} | {b['cpu_baseline']['value']:.0f} ({b['cpu_baseline']['cores']} cores) / {b['cpu_baseline'].get('value_16_threads', 0):.0f} |")
     v = {}
-    for sub, cn in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+    cond = f"{go}/summ/{tag}_tasks_pmc.json"   # condensed on the GPU box by tools/profile_pmc_tasks_condense.py (the raw counter CSVs exceed gpurun's return limit)
+    if os.path.exists(cond) and t in json.load(open(cond)):
+        v = dict(json.load(open(cond))[t])
+    for sub, cn in (() if v else (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE"))):
         g = sorted(glob.glob(f"{go}/{tag}_{t}_{sub}/*/*_counter_collection.csv"), key=os.path.getmtime)
         if not g:
             continue
