@@ -2709,7 +2709,8 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
 }
 #elif HRG_HAMMER
 #ifndef HRG_HAMMER_WAVES
-#define HRG_HAMMER_WAVES 2   // 256 registers: five 30 KB workgroups per CU instead of four (8.88 -> 8.09 ms per 4096-env step; 752 B/lane of scratch)
+#define HRG_HAMMER_WAVES 1   // 2 (256 registers, five 30 KB workgroups per CU) is 9 % faster (8.88 -> 8.09 ms per 4096-env step) but spills 752 B per lane inside the cycle
+                             // loop: 990 MB through HBM per launch against 74 MB at one wave per SIMD (100 MB algorithmic; profiles/r02t_tasks_summary.md)
 #endif
 #define HRG_KERNEL_WAVES HRG_HAMMER_WAVES   // 30 KB of LDS per env (89 dense rows of J over 24 DoF): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
 DI void box_load(const hrg_hammer_state* __restrict__ hammers, int e, int lane) {

@@ -6,7 +6,7 @@ TAG=${1:-r02t}
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
-for T in HumanObjectInspectionCart HumanRobotHandoverCart RobotHumanHandoverCart CollaborativeLiftingCart CollaborativeStackingCart CollaborativeHammeringCart; do
+for T in ${TASKS:-HumanObjectInspectionCart HumanRobotHandoverCart RobotHumanHandoverCart CollaborativeLiftingCart CollaborativeStackingCart CollaborativeHammeringCart}; do
   cd /tmp
   rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/${TAG}_${T}_trace -- python3 $R/bench.py --env $T --steps 40 --warmup 10 --preroll 200 --no-cpu-baseline > $R/gpurun_out/${TAG}_${T}_trace.log 2>&1
   cd $R

@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$PWD}
 mkdir -p $R/gpurun_out
 cd /tmp
-for T in HumanObjectInspectionCart HumanRobotHandoverCart RobotHumanHandoverCart CollaborativeLiftingCart CollaborativeStackingCart CollaborativeHammeringCart; do
+for T in ${TASKS:-HumanObjectInspectionCart HumanRobotHandoverCart RobotHumanHandoverCart CollaborativeLiftingCart CollaborativeStackingCart CollaborativeHammeringCart}; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${T}_fetch -- python3 $R/bench.py --env $T --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_${T}_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/gpurun_out/${TAG}_${T}_write -- python3 $R/bench.py --env $T --steps 20 --warmup 3 --no-cpu-baseline > $R/gpurun_out/${TAG}_${T}_write.log 2>&1
   echo "$T pmc done"
