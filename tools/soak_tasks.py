@@ -11,9 +11,9 @@ from human_robot_gym_amd._lib import HipBatch  # noqa: E402
 
 n, steps = 4096, 600
 for env_id, shield in (("ReachHuman", "SSM"), ("PickPlaceHumanCart", "SSM"), ("HumanObjectInspectionCart", "SSM"), ("HumanRobotHandoverCart", "PFL"), ("RobotHumanHandoverCart", "PFL"),
-                       ("CollaborativeLiftingCart", "SSM"), ("CollaborativeStackingCart", "SSM")):
+                       ("CollaborativeLiftingCart", "SSM"), ("CollaborativeStackingCart", "SSM"), ("CollaborativeHammeringCart", "SSM")):
     clips = mixed.task_clips(env_id, 5, min_frames=300, max_frames=600) if env_id != "ReachHuman" else hrg.synthetic_clips(5, seed=0)
-    d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31), n_clips=clips.n_clips, env_id=env_id)
+    d = hrg.build_model_desc(dict(shield_type=shield, horizon=150, seed=31, **mixed.task_env_kwargs(env_id)), n_clips=clips.n_clips, env_id=env_id)
     G = HipBatch(d, clips, n)
     G.reset()
     g = torch.Generator(device="cpu").manual_seed(4)
@@ -30,7 +30,13 @@ for env_id, shield in (("ReachHuman", "SSM"), ("PickPlaceHumanCart", "SSM"), ("H
             print(f"  {env_id} step {k}: object z min {z.min():.3f} max {z.max():.3f}; below table-5mm {(z < 0.8 + 0.02 - 5e-3).mean():.3f}; gripped {o[:, 39].mean():.3f}", flush=True)
     order, nb = G.launch_order()
     perm_ok = bool(np.array_equal(np.sort(order), np.arange(n)))
-    if env_id == "CollaborativeStackingCart":
+    if env_id == "CollaborativeHammeringCart":
+        hms = [G.get_hammer(e) for e in range(0, n, 8)]
+        ph = np.bincount([h.task_phase for h in hms], minlength=6)
+        qn = max(abs(np.linalg.norm(list(h.quat[b])) - 1) for h in hms for b in range(2))
+        print(f"{env_id}: crashes {crashes} dones {dones} positive rewards {wins} non-finite {bad} phases {ph.tolist()} gripped {np.mean([h.gripped for h in hms]):.3f} "
+              f"nail progress mean {np.mean([min(max(h.nail_q / 0.06, 0), 1) for h in hms]):.3f} |quat|-1 {qn:.2e} launch order a permutation {perm_ok} busy {nb}", flush=True)
+    elif env_id == "CollaborativeStackingCart":
         sks = [G.get_stack(e) for e in range(0, n, 8)]
         ph = np.bincount([s_.task_phase for s_ in sks], minlength=6)
         qn = max(abs(np.linalg.norm(list(s_.quat[c])) - 1) for s_ in sks for c in range(4))
