@@ -96,7 +96,7 @@ def test_random_actions_parity_resync(shield):
 
 def test_random_actions_parity_free_running():
     O, G, _ = _pair(16, dict(shield_type="SSM", horizon=30, seed=3))
-    st = _rollout(O, G, 16, 45, 2, False, "random_free", min_live=0.7, act_scale=0.3)   # incl. auto-resets
+    st = _rollout(O, G, 16, 45, 2, False, "random_free", min_live=0.9, act_scale=0.3)   # incl. auto-resets (measured: 16 of 16 stay in)
     assert st["hammer_contacts"] > 0
 
 
@@ -131,7 +131,7 @@ def test_hammer_on_nail_and_board_parity():
     st = _rollout(O, G, 4, 22, 3, True, "on_nail", scenario=_on_the_nail, act_scale=0.0)
     assert st["box_box"] > 0 and st["nail_contacts"] > 0
     O, G, d = _pair(4, dict(shield_type="OFF", horizon=100, seed=4))
-    _rollout(O, G, 4, 20, 3, False, "on_nail_free", scenario=_on_the_nail, act_scale=0.0, min_live=0.5)
+    _rollout(O, G, 4, 20, 3, False, "on_nail_free", scenario=_on_the_nail, act_scale=0.0, min_live=0.75)
 
 
 def test_scripted_episode_through_success_parity():

@@ -87,18 +87,22 @@ def test_mixed_vec_env_surface():
 
 
 @pytest.mark.gpu
-def test_six_task_mixed_batch_at_4096_envs():
+@pytest.mark.parametrize("suite", ["ICRA_TASKS", "ALL_TASKS"])
+def test_six_task_mixed_batch_at_4096_envs(suite):
     """BASELINE configs[4] on one GPU: the six ICRA tasks, 4096 envs split evenly, each task's kernel on its own stream.  Size-independent properties over
     40 steps, and every task's rows bit-identical to the task stepped alone at the same global env ids."""
     import torch
     from human_robot_gym_amd._lib import HipBatch
     n = 4096
-    M = mixed.make_mixed_batch(n, seed=11)
-    assert len(M.env_ids) == 6 and M.n == n and [sl.stop - sl.start for sl in M.slices] == [683, 683, 683, 683, 682, 682]
+    tasks = getattr(mixed, suite)   # ALL_TASKS: the six ICRA tasks + CollaborativeHammeringCart, seven kernels in one batch
+    M = mixed.make_mixed_batch(n, tasks=tasks, seed=11)
+    assert len(M.env_ids) == len(tasks) and M.n == n and [sl.stop - sl.start for sl in M.slices] == mixed.split_evenly(n, len(tasks))
+    if suite == "ICRA_TASKS":
+        assert [sl.stop - sl.start for sl in M.slices] == [683, 683, 683, 683, 682, 682]
     singles = []
-    for (env_id, kw), sl in zip(mixed.ICRA_TASKS, M.slices):
+    for (env_id, kw), sl in zip(tasks, M.slices):
         clips = mixed.task_clips(env_id, 13)
-        singles.append(HipBatch(hrg.build_model_desc(dict(kw, seed=11), n_clips=clips.n_clips, env_id=env_id), clips, sl.stop - sl.start, env_id0=sl.start))
+        singles.append(HipBatch(hrg.build_model_desc(dict(mixed.task_env_kwargs(env_id), **dict(kw, seed=11)), n_clips=clips.n_clips, env_id=env_id), clips, sl.stop - sl.start, env_id0=sl.start))
     obs = M.reset()
     for S, sl in zip(singles, M.slices):
         assert torch.equal(obs[sl], S.reset())
