@@ -1069,7 +1069,7 @@ DI void hammer_obs_pos(const DevModel* __restrict__ dm_, int lane) {
     hm.obs_pos[2][lane] = L.nail_org[lane];
   }
 }
-// The hammering task's part of the contact list (after the robot's own rounds; oracle: collide_hammer): robot capsule x {board, handle, head} first points
+// The hammering task's part of the contact list (after the robot's own rounds; oracle: collide_hammer): robot capsule x {board, handle, head, nail head} first points
 // (geom-major; the handle meets the two finger bars only), table corners, floor corners, the box pairs head - nail, handle - nail, head - board, handle - board
 // (one lane per pair), second points of capsules lying along a face; and the hammer_gripped sensor.
 DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io) {
@@ -1088,11 +1088,11 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
     bool hit = false;
     if (round == 0 || round == 3) {   // capsule i x geom g: first point / second point (a capsule lying along a face)
       const bool second = round == 3;
-      const int g = lane < 3 * HRG_NRCAP ? lane / HRG_NRCAP : 0, i = lane - g * HRG_NRCAP < HRG_NRCAP ? lane - g * HRG_NRCAP : 0;
-      const int fb = g == HRG_HG_BOARD ? 0 : 1;
+      const int g = lane < HRG_HM_NGEOM * HRG_NRCAP ? lane / HRG_NRCAP : 0, i = lane - g * HRG_NRCAP < HRG_NRCAP ? lane - g * HRG_NRCAP : 0;
+      const int fb = (g == HRG_HG_HANDLE || g == HRG_HG_HEAD) ? 1 : 0;   // rotation: the nail head turns with the board
       const double hb[3] = {m.hm_geom_half[g][0], m.hm_geom_half[g][1], m.hm_geom_half[g][2]};
       bool near = false;
-      if (lane < 3 * HRG_NRCAP && m.rcap_body[i] >= 0 && !(g == HRG_HG_HANDLE && i < HRG_NRCAP - 2)) {
+      if (lane < HRG_HM_NGEOM * HRG_NRCAP && m.rcap_body[i] >= 0 && !(g == HRG_HG_HANDLE && i < HRG_NRCAP - 2)) {
         // broadphase: the capsule's bounding sphere against the box itself (distance of its centre to the box in the box frame); conservative
         double dc[3], d2 = 0;
         for (int a = 0; a < 3; a++) dc[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]) - L.gc[g][a];
@@ -1123,7 +1123,7 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
             dist = -best - m.rcap_r[i];
           }
           v3madd(c.pos, cs, c.n, m.rcap_r[i] + 0.5 * dist);
-          c.g1 = i; c.g2 = GEOM_BOX + g; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX + fb; c.dist = dist;
+          c.g1 = i; c.g2 = GEOM_BOX + g; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX + (g == HRG_HG_NAIL ? HRG_HM_NAIL : fb); c.dist = dist;
         }
       }
       const uint64_t mask = __ballot(hit);
@@ -1133,7 +1133,7 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
         if (slot < HRG_NCON_MAX) { L.st.con_pairs[slot][0] = c.g1; L.st.con_pairs[slot][1] = c.g2; }
       }
       if (!second) {   // hammer_gripped (1283-1289): both fingers touch a geom of the hammer (contacts beyond the reported list do not count)
-        const bool rep = hit && slot < HRG_NCON_MAX && g != HRG_HG_BOARD;
+        const bool rep = hit && slot < HRG_NCON_MAX && fb == 1;
         f0 = __any(rep && i == HRG_NRCAP - 2); f1 = __any(rep && i == HRG_NRCAP - 1);
       }
       base += __popcll(mask);

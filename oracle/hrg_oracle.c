@@ -2847,10 +2847,10 @@ static void hammer_geometry(const hrg_model_desc* m, const hrg_hammer_state* hm,
   for (int a = 0; a < 3; a++) G->axis[a] = -G->R[0][3 * a + 2]; /* joint axis (0, 0, -1) of the board */
 }
 
-/* contact list of the hammering task: the robot's own contacts (collide), then per geom g (board, handle, head) the robot capsules' first points, the
+/* contact list of the hammering task: the robot's own contacts (collide), then per geom g (board, handle, head, nail head) the robot capsules' first points, the
  * corners on the table and on the floor, then the box pairs (head - nail, handle - nail, head - board, handle - board), then the second points of capsules
  * lying along a face.  The handle meets the two finger bars only (the stand-in hand capsule envelops the real gripper's palm, through which the handle
- * passes); robot - nail contacts are not generated.  hammer_gripped (1283-1289): _check_grasp = both fingers touch a geom of the hammer. */
+ * passes).  hammer_gripped (1283-1289): _check_grasp = both fingers touch a geom of the hammer. */
 static int collide_hammer(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, hrg_hammer_state* hm, const hammer_geo* G, contact_t* con) {
   int n = collide(m, k, h, NULL, con);
   double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3], Rb[9];
@@ -2865,11 +2865,11 @@ static int collide_hammer(const hrg_model_desc* m, const robot_kin* k, const hum
   }
 #define EMIT(G1, G2, B1, B2, DIST, NRM, POS) \
   do { if (n < HRG_NCON_MAX) { con[n].g1 = G1; con[n].g2 = G2; con[n].b1 = B1; con[n].b2 = B2; con[n].dist = DIST; v3cpy(con[n].n, NRM); v3cpy(con[n].pos, POS); n++; } } while (0)
-  int n_second = 0, second_i[3 * HRG_NRCAP], second_g[3 * HRG_NRCAP];
-  double second_s[3 * HRG_NRCAP][3], second_b[3 * HRG_NRCAP][3];
+  int n_second = 0, second_i[HRG_HM_NGEOM * HRG_NRCAP], second_g[HRG_HM_NGEOM * HRG_NRCAP];
+  double second_s[HRG_HM_NGEOM * HRG_NRCAP][3], second_b[HRG_HM_NGEOM * HRG_NRCAP][3];
   int f0 = 0, f1 = 0;
-  for (int g = HRG_HG_BOARD; g <= HRG_HG_HEAD; g++) {
-    const double* Rx = G->R[HM_GEOM_BODY[g]];
+  for (int g = HRG_HG_BOARD; g <= HRG_HG_NAIL; g++) {
+    const double* Rx = G->R[HM_GEOM_BODY[g] == HRG_HM_HAMMER ? 1 : 0]; /* the nail head turns with the board */
     const double* hb = m->hm_geom_half[g];
     const int body = BODY_HM(HM_GEOM_BODY[g]);
     for (int i = 0; i < HRG_NRCAP; i++) {
@@ -2893,13 +2893,13 @@ static int collide_hammer(const hrg_model_desc* m, const robot_kin* k, const hum
         dist = -best - m->rcap_r[i];
       }
       v3madd(pos, cs, nn, m->rcap_r[i] + 0.5 * dist);
-      if (n < HRG_NCON_MAX && g != HRG_HG_BOARD) { f0 |= i == HRG_NRCAP - 2; f1 |= i == HRG_NRCAP - 1; }
+      if (n < HRG_NCON_MAX && (g == HRG_HG_HANDLE || g == HRG_HG_HEAD)) { f0 |= i == HRG_NRCAP - 2; f1 |= i == HRG_NRCAP - 1; }
       EMIT(i, GEOM_HM(g), m->rcap_body[i], body, dist, nn, pos);
     }
   }
   for (int pl = 0; pl < 2; pl++)
     for (int g = HRG_HG_BOARD; g <= HRG_HG_HEAD; g++) {
-      const double* Rx = G->R[HM_GEOM_BODY[g]];
+      const double* Rx = G->R[HM_GEOM_BODY[g] == HRG_HM_HAMMER ? 1 : 0];
       const double* hb = m->hm_geom_half[g];
       for (int cn = 0; cn < 8; cn++) {
         double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]}, p[3];

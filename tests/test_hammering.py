@@ -129,6 +129,17 @@ def test_gripper_holds_the_hammer_and_hammer_contacts_are_whitelisted():
     B.set_hammer(0, hm)
     _, _, _, info = B.step(np.zeros((2, 7)))
     assert info[0, 1] & CONST["HRG_COL_STATIC"] and info[0, 3] >= 1
+    # ... and so is one with the nail head (not white-listed either): the board moved so that the nail sits at a finger bar
+    hm, st = B.get_hammer(1), B.get_state(1)
+    Rb = _quat2mat(hm.quat[0])
+    nail = Rb @ np.array([hm.nail_xy[0], hm.nail_xy[1], d.hm_nail_z0])
+    hm.pos[0][:] = (np.array(st.eef_pos) + [0.0, 0.03, -0.02] - nail).tolist()
+    hm.pos[1][:] = [0.3, -0.8, 3.0]                                                      # the hammer out of the way
+    B.set_hammer(1, hm)
+    before = B.step(np.zeros((2, 7)))[3][1, 3] if False else None
+    info = B.step(np.zeros((2, 7)))[3]   # (the weld pulls the board back within the step: the contact shows in the step's collision counters, not in its last substep's list)
+    assert info[1, 1] & CONST["HRG_COL_STATIC"]
+    assert info[1, 3] >= 1
     B.close()
 
 

@@ -36,7 +36,7 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
         assert_state_close(O.get_state(e), G.get_state(e), f"reset env {e}")
     rng = np.random.RandomState(seed)
     live = np.ones(n, bool)
-    stats = dict(hammer_contacts=0, box_box=0, nail_contacts=0, phases=set(), max_ncon=0, gripped=0)
+    stats = dict(hammer_contacts=0, box_box=0, nail_contacts=0, phases=set(), max_ncon=0, gripped=0, static=0)
     for k in range(n_steps):
         if scenario is not None:
             scenario(k, [O, G])
@@ -72,6 +72,7 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
         stats["box_box"] += int(((po[chk][:, :, 0] >= G0) & (po[chk][:, :, 1] >= G0)).sum())
         stats["nail_contacts"] += int((po[chk][:, :, 1] == G0 + 3).sum())
         stats["max_ncon"] = max(stats["max_ncon"], int(no[chk].max()) if chk.any() else 0)
+        stats["static"] = max(stats["static"], int(i_o[chk, 3].max()) if chk.any() else 0)
         for e in range(n):
             stats["phases"].add(int(phm[e].task_phase)); stats["gripped"] += int(phm[e].gripped)
             if chk[e]:
@@ -123,6 +124,26 @@ def _on_the_nail(k, Bs):
             hm.vel[1][:] = [0.0] * 6
             hm.acc_warmstart[1][:] = [0.0] * 6
             B.set_hammer(e, hm)
+
+
+def _nail_at_the_finger(k, Bs):
+    """Step 3: env 0's board is moved so that the nail head sits at a finger bar (robot - nail contacts: a static collision, rows on the board and the slide joint)."""
+    if k != 3:
+        return
+    for B in Bs:
+        hm, st = B.get_hammer(0), B.get_state(0)
+        Rb = _quat2mat(hm.quat[0])
+        nail = Rb @ np.array([hm.nail_xy[0], hm.nail_xy[1], 0.086])
+        hm.pos[0][:] = (np.array(st.eef_pos) + [0.0, 0.03, -0.02] - nail).tolist()
+        hm.pos[1][:] = [0.3, -0.8, 3.0]
+        hm.vel[1][:] = [0.0] * 6
+        B.set_hammer(0, hm)
+
+
+def test_robot_nail_contact_parity():
+    O, G, d = _pair(2, dict(shield_type="OFF", horizon=100, seed=7))
+    st = _rollout(O, G, 2, 10, 4, True, "nail_finger", scenario=_nail_at_the_finger, act_scale=0.0)
+    assert st["static"] >= 1   # (the weld pulls the board back within the step: the contact shows in the collision counters, not in the last substep's list)
 
 
 def test_hammer_on_nail_and_board_parity():
