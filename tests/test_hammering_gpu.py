@@ -172,3 +172,42 @@ def test_scripted_episode_through_success_parity():
                 done_once[(e, hm.nail_index)] = True
     st = _rollout(O, G, 2, 110, 6, True, "scripted", scenario=scenario, act_scale=0.0)
     assert st["phases"] >= {0, 1, 3}
+
+
+def test_box_box_fuzz_parity():
+    """Box-box contacts of boxes with different extents, fuzzed: every other step the hammer of every env is thrown at the board / the nail in a random pose
+    (head or handle a few millimetres inside the board's top face, tilted up to 35 deg, or the head on the nail), then one step on both steppers from
+    the same state.  Face / edge / vertex configurations of the SAT + clipping code with unequal half extents, the coupled 24-DoF Newton step, the nail's rows."""
+    n = 48
+    O, G, d = _pair(n, dict(shield_type="OFF", horizon=200, seed=9))
+    rs = np.random.RandomState(5)
+
+    def scenario(k, Bs):
+        if k < 3 or k % 2 == 0:
+            return
+        hm0 = [Bs[0].get_hammer(e) for e in range(n)]
+        poses = []
+        for e in range(n):
+            hm = hm0[e]
+            Rb = _quat2mat(hm.quat[0])
+            ax = rs.randn(3); ax /= np.linalg.norm(ax)
+            ang = rs.uniform(0, 0.6)
+            qt = np.concatenate([[np.cos(ang / 2)], np.sin(ang / 2) * ax])
+            base = np.array([np.sqrt(0.5), 0, np.sqrt(0.5), 0])                    # handle level, head pointing down
+            w1, v1, w2, v2 = qt[0], qt[1:], base[0], base[1:]
+            q = np.concatenate([[w1 * w2 - v1 @ v2], w1 * v2 + w2 * v1 + np.cross(v1, v2)])
+            Rh = _quat2mat(q)
+            head = np.array([0.0, 0.0, 0.0875 + 0.01925 - 0.06726677713338856])
+            if e % 3 == 0:    # head over the nail
+                tgt = np.array(hm.pos[0]) + Rb @ np.array([hm.nail_xy[0], hm.nail_xy[1], 0.086 + 0.003 + 0.0616 - rs.uniform(0, 0.004)])
+            else:             # head over a random spot of the board's nail half
+                tgt = np.array(hm.pos[0]) + Rb @ np.array([rs.uniform(-0.3, 0.4), rs.uniform(-0.15, 0.15), 0.015 + 0.0616 - rs.uniform(0, 0.004)])
+            poses.append((tgt - Rh @ head, q))
+        for B in Bs:
+            for e in range(n):
+                hm = B.get_hammer(e)
+                hm.pos[1][:] = poses[e][0].tolist(); hm.quat[1][:] = poses[e][1].tolist()
+                hm.vel[1][:] = [0.0] * 6; hm.acc_warmstart[1][:] = [0.0] * 6
+                B.set_hammer(e, hm)
+    st = _rollout(O, G, n, 16, 8, True, "boxbox_fuzz", scenario=scenario, act_scale=0.0)
+    assert st["box_box"] > 20 * 4
