@@ -221,7 +221,7 @@ struct Lds {
   hrg_env_state st;
   // robot tree at the simulation state (live across the whole cycle)
   double kR[NV][9], kp[NV][3], Sw[NV][3], Sv[NV][3], vw[NV][3], vv[NV][3];
-  double M[NV * NV], H[NV * NV], Hinv[NV];
+  double M[NV * NV];                     // (the Newton systems live in registers; the IK front-end borrows M / bias as scratch for its 6 x 6 factor)
   double bias[NV], a0[NVS], Ma0[NVS], ctrl[NV], qacc[NVS], g[NVS], d[NVS];
 #if HRG_BOX
   hrg_box_state bx;                      // the cube (streamed from its own HBM array)

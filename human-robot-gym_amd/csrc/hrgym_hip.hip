@@ -1634,9 +1634,9 @@ DI void ik_action(const DevModel* __restrict__ dm_, int lane) {
     bool ok;
     const double lij = chol_lanes(aij, lane, &ok);
     if (!ok) break;
-    chol_store(lij, lane, L.H, L.Hinv);
+    chol_store(lij, lane, L.M, L.bias);   // scratch: the mass matrix and the bias vector are rebuilt by the first cycle's dynamics terms before anything reads them
     wave_sync();
-    const double y = chol_solve_lanes(L.H, L.Hinv, lane < 6 ? ee[lane] : 0.0, lane);
+    const double y = chol_solve_lanes(L.M, L.bias, lane < 6 ? ee[lane] : 0.0, lane);
     double dq = 0;
     for (int a = 0; a < 6; a++) { const double ya = __shfl(y, a, 64); if (lane < NARM) dq += J[a * 6 + lane] * ya; }
     double mx = 0;
