@@ -83,3 +83,26 @@ def test_make_vec_env_refuses_an_opaque_wrapper_class_and_unimplemented_env_kwar
         with pytest.raises(NotImplementedError):
             hrg.build_model_desc(kw)
     hrg.build_model_desc(dict(randomize_initial_pos=False, table_friction=(1.0, 5e-3, 1e-4), initialization_noise="default", has_renderer=False))
+
+
+def test_hammering_environment_config_of_the_reference_is_accepted():
+    """training/config/environment/default/collaborative_hammering_cart.yaml through the one-import boundary, oracle backend."""
+    from human_robot_gym_amd.mixed import task_clips
+    cfg = _config()
+    cfg.environment = NS(env_id="CollaborativeHammeringCart", robot_base_offset=[0.0, 0.0, 0.0], env_configuration="default", controller_configs=None, gripper_types="default",
+                         initialization_noise="default", use_camera_obs=False, use_object_obs=True, has_renderer=False, has_offscreen_renderer=False, render_camera=None,
+                         hard_reset=False, control_freq=10, horizon=5, shield_type="SSM", control_sample_time=0.004, seed=3, verbose=False,
+                         table_full_size=[1.5, 2.0, 0.05], table_friction=[1.0, 5e-3, 1e-4], board_full_size=[1.0, 0.4, 0.03], nail_hammered_in_reward=-1.0,
+                         hammer_gripped_reward_bonus=0.0, goal_tolerance=0.05, n_nail_placements_sampled_per_100_steps=1, gripper_controllable=False,
+                         human_animation_names=[f"CollaborativeHammering/{i}" for i in range(9)], obstacle_placement_initializer=None, human_animation_freq=100)
+    cfg.run.obs_keys = ["hammer_gripped", "vec_eef_to_nail", "nail_hammering_progress", "board_quat", "quat_eef_to_board"]
+    cfg.run.vec_env_kwargs = dict(backend=OracleBackend, clips=task_clips("CollaborativeHammeringCart", 2, min_frames=200, max_frames=260))
+    env = hrg.create_training_vec_env(cfg)
+    assert env.observation_space.shape == (1 + 3 + 1 + 4 + 4,) and env._desc.task == 9 and env._desc.gripper_controllable == 0
+    obs = env.reset()
+    assert obs.shape == (3, 13) and np.all(obs[:, 9:13] == 0.0)              # quat_eef_to_board: constant zeros in the reference (1276-1282)
+    assert np.allclose(np.linalg.norm(obs[:, 5:9], axis=1), 1.0, atol=1e-6)   # board_quat
+    for _ in range(5):
+        obs, rew, done, infos = env.step(np.zeros((3, 7)))
+    assert done.all() and infos[0]["TimeLimit.truncated"]
+    env.close()
