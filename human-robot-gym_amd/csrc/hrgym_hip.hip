@@ -2139,6 +2139,11 @@ __device__ __noinline__ void handover_first_pass_tail(const DevModel* __restrict
 #endif
 #if HRG_FAIR
 static __device__ int g_fair[8 * 8 * 2 * 16 * 4 * 8];   // progress + 1 of the wave in slot w of a SIMD (0: no wave there)
+// The readers of an entry are the waves of the SAME compute unit (other workgroups, but behind the same vector L1 and the same XCD's L2): workgroup-scope atomics
+// (plain cached loads / write-through stores) are coherent among them; agent scope sends every access past the caches (16 MB more HBM traffic per 4096-env launch).
+#ifndef FAIR_SCOPE
+#define FAIR_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
+#endif
 DI int fair_key() {
   unsigned hw, xcc;
   asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)\n\ts_getreg_b32 %1, hwreg(HW_REG_XCC_ID)" : "=s"(hw), "=s"(xcc));
@@ -2147,14 +2152,14 @@ DI int fair_key() {
 }
 DI void fair_publish(int lane, int progress) {   // progress >= 0; -1 = this wave is done
   const int key = fair_key();
-  if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, FAIR_SCOPE);
 }
 // top of a cycle: publish this wave's progress and start reading the siblings' (the load's latency hides behind the shield phase) ...
 DI int fair_begin(int lane, int progress) {
   const int key = fair_key(), base = key & ~7;
-  if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, FAIR_SCOPE);
   int v = 0;
-  if (lane < 8) v = __hip_atomic_load(&g_fair[base + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (lane < 8) v = __hip_atomic_load(&g_fair[base + lane], __ATOMIC_RELAXED, FAIR_SCOPE);
   return v;
 }
 // ... and after it: behind a sibling -> higher issue priority, ahead of them -> lower
