@@ -242,18 +242,13 @@ struct Lds {
   double nail_org[3], nail_axis[3];      // nail_head body origin and the slide axis, world
   double Mb[64], fb[8];                  // mass matrix (8 x 8, pad DoF with a unit diagonal) and applied force of the board + nail subtree
   double Ihw[9], tauh[3];                // the hammer's world-frame rotational inertia and gyroscopic torque
-  double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];
 #elif HRG_STACK
   hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)
-  double cR[NCUBE][9];                   // cube rotation matrices at the current substep
-  double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];                 // (the coupled Newton system lives in registers: Tiles, hrgym_hip.hip)
 #elif HRG_BOX
-  double rcen[HRG_NRCAP][3];             // collide -> classify / constraint-row set-up
-  Contact con[NCON_DYN];                 // (the coupled 14-DoF Newton system lives in registers: Tiles<2>)
+  Contact con[NCON_DYN];                 // collide -> constraint-row set-up (the coupled 14-DoF Newton system lives in registers: Tiles<2>)
 #else
-  double rcen[HRG_NRCAP][3];
   Contact con[NCON_DYN];
 #endif
   union {
@@ -266,9 +261,13 @@ struct Lds {
     struct {  // robot_dynamics_terms
       double com[NV][3], Iw[NV][6], cI[NV][10], F[NV][6], aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
     };
-    struct {  // human_control + collide
+    struct {  // human_control + collide + classify (the dynamics step's rows take this space afterwards)
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
       int cur[HRG_NPREV_MAX];
+      double rcen[HRG_NRCAP][3];         // capsule centres: collide -> classify (the speed of a robot geom at a human contact)
+#if HRG_STACK
+      double cR[NCUBE][9];               // cube rotation matrices of the substep's narrowphase
+#endif
     };
 #if HRG_HAMMER
     struct {  // dynamics_step (hammering): dense rows of J over the 24 DoF (+1 pad: odd stride) -- 4 per contact, then the 9 equality rows; per-row gradient / curvature
