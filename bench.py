@@ -22,8 +22,9 @@ Rank 0 prints ONE JSON line (contract in the task statement) with two extra obje
                  live with HIP events on the launch stream (hrg_batch_kernel_time).  `traffic`, `valu_*` and `fp64_*`
                  are PMC figures of a committed capture of this same command (`traffic_source` names the file): a
                  counter pass slows the kernel and cannot run inside the timed region.
-  cpu_baseline — the CPU oracle (oracle/hrg_oracle.c, kind "port") on the host: P worker threads pinned one per
-                 physical core of the affinity mask, barrier per vec-step (the SubprocVecEnv shape), bounded sample.
+  cpu_baseline — the CPU oracle (oracle/hrg_oracle.c, kind "port") on the host: P worker threads, barrier per vec-step
+                 (the SubprocVecEnv shape), envs of a vec-step drawn dynamically; several legs (all physical cores pinned,
+                 16 threads, the cgroup's cpu quota), `value` = the best, each with worker-busy and throttling figures.
 """
 import argparse
 import json
@@ -65,14 +66,59 @@ def physical_cores():
     return avail, firsts
 
 
+def cgroup_cpu_limit():
+    """(cpus the cgroup may use per period or None, path read): cgroup v2 `cpu.max` / v1 `cpu.cfs_quota_us`.  The affinity mask of a container usually shows every
+    logical cpu of the host while the CFS quota caps the cpu TIME it gets: threads beyond the quota do not add throughput, they are throttled."""
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q, per = open(path).read().split()[:2]
+            return (None if q == "max" else float(q) / float(per)), path
+        except (OSError, ValueError):
+            pass
+    try:
+        q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return (None if q <= 0 else q / per), "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"
+    except (OSError, ValueError):
+        return None, None
+
+
+def _throttled_usec():
+    for path in ("/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat"):
+        try:
+            d = dict(l.split()[:2] for l in open(path).read().splitlines() if l.strip())
+            if "throttled_usec" in d:
+                return float(d["throttled_usec"])
+            if "throttled_time" in d:
+                return float(d["throttled_time"]) / 1e3
+        except (OSError, ValueError):
+            pass
+    return None
+
+
+def _sockets(cpus):
+    seen = set()
+    for c in cpus:
+        try:
+            seen.add(open(f"/sys/devices/system/cpu/cpu{c}/topology/physical_package_id").read().strip())
+        except OSError:
+            pass
+    return len(seen) or None
+
+
 def cpu_baseline(env_kwargs, clips_seed, budget_s=10.0, env_id="ReachHuman", n_envs=ENVS_PER_GPU, wrappers=None, preroll=100):
-    """Oracle on the host cores, the shape of the reference's SubprocVecEnv (one worker per core, synchronised once per vec-step):
-    P pthreads inside the oracle library, each stepping n/P envs, pthread barrier per vec-step.  Timed twice: P = physical cores of the
-    affinity mask (the headline figure) and P = 16 (the CPU share gpurun documents for a 1-GPU box)."""
+    """Oracle on the host cores, the shape of the reference's SubprocVecEnv (P workers, synchronised once per vec-step): P pthreads inside the oracle library,
+    pthread barrier per vec-step.  Round 3: the envs of a vec-step are drawn by the workers in runs of 8 from a shared counter (the per-env cost depends on its
+    state, and a pinned worker of a shared host may lose its core: with fixed env ranges every vec-step waited for its unluckiest worker -- round 2's 128 pinned
+    threads were SLOWER than 16), and the legs are chosen with the cgroup's cpu quota in view.  Legs: every physical core of the affinity mask (pinned), 16 threads
+    (the CPU share gpurun documents for a 1-GPU box), and the quota's own thread count when it differs.  `value` = the best leg; every leg reports its throughput,
+    how busy its workers were (seconds inside env_step / wall seconds, mean and min over the workers) and the time the cgroup spent throttled during it."""
+    import math
     import numpy as np
     import human_robot_gym_amd as hrg
     from oracle.oracle import OracleBatch
     avail, firsts = physical_cores()
+    quota, quota_src = cgroup_cpu_limit()
     n = n_envs
     clips = _bench_clips(env_id, clips_seed)
     desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=env_id, **(wrappers or {}))
@@ -83,28 +129,41 @@ def cpu_baseline(env_kwargs, clips_seed, budget_s=10.0, env_id="ReachHuman", n_e
     if wrappers:
         pool[:, :, :3] *= 0.15
 
-    def timed(workers, cpus, budget):
-        B.rollout_parallel(pool, 2, workers, cpus)   # warm-up of the thread team / caches
+    def timed(workers, cpus, budget, chunk=8):
+        B.rollout_parallel2(pool, 2, workers, cpus, chunk)   # warm-up of the thread team / caches
+        th0 = _throttled_usec()
         t0 = time.perf_counter()
-        k = 0
-        chunk = 4
+        k, per_call, busy = 0, 8, np.zeros(workers)
         while True:
-            B.rollout_parallel(pool, chunk, workers, cpus)
-            k += chunk
+            busy += B.rollout_parallel2(pool, per_call, workers, cpus, chunk)
+            k += per_call
             el = time.perf_counter() - t0
             if el >= budget:
-                return n * k / el, k, el
+                break
+        th1 = _throttled_usec()
+        return {"threads": workers, "pinned": cpus is not None, "value": n * k / el, "vec_steps": k, "seconds": round(el, 2),
+                "worker_busy_mean": round(float(busy.mean() / el), 3), "worker_busy_min": round(float(busy.min() / el), 3),
+                "cgroup_throttled_s": None if th0 is None or th1 is None else round((th1 - th0) / 1e6, 2)}
 
-    # the same pre-roll as the GPU leg, so that both time the steady state (bounded: the CPU is ~20-30x slower)
-    B.rollout_parallel(pool, min(preroll, 24), len(firsts), firsts)
-    v_all, k_all, el_all = timed(len(firsts), firsts, budget_s)
+    # the same pre-roll as the GPU leg, so that both time the steady state (bounded: the CPU is ~20-50x slower)
     p16 = min(16, len(avail))
-    v16, k16, el16 = timed(p16, None, 0.6 * budget_s)
+    B.rollout_parallel2(pool, min(preroll, 24), min(len(firsts), 32), None, 8)
+    legs = {"all_physical_cores_pinned": timed(len(firsts), firsts, 0.5 * budget_s)}
+    legs["16_threads"] = timed(p16, None, 0.5 * budget_s)
+    if quota is not None and int(math.ceil(quota)) not in (len(firsts), p16):
+        pq = max(1, min(len(avail), int(math.ceil(quota))))
+        legs["cgroup_quota_threads"] = timed(pq, None, 0.5 * budget_s)
+    legs["16_threads_fixed_env_ranges"] = timed(p16, None, 0.3 * budget_s, chunk=0)   # round 2's partition, for the comparison
     B.close()
-    return {"value": v_all, "unit": "env steps/s", "cores": len(firsts), "kind": "port",
-            "sample": f"{n} envs x {k_all} vec-steps ({el_all:.1f} s), oracle/hrg_oracle.c, {len(firsts)} pthreads pinned one per physical core "
-                      f"({len(avail)} logical cpus in the affinity mask), barrier per vec-step",
-            "value_16_threads": v16, "sample_16_threads": f"{n} envs x {k16} vec-steps ({el16:.1f} s) on {p16} unpinned threads"}
+    best = max((k for k in legs if k != "16_threads_fixed_env_ranges"), key=lambda k: legs[k]["value"])
+    L = legs[best]
+    return {"value": L["value"], "unit": "env steps/s", "cores": L["threads"], "kind": "port",
+            "sample": f"{n} envs x {L['vec_steps']} vec-steps ({L['seconds']} s), oracle/hrg_oracle.c, leg '{best}': {L['threads']} pthreads"
+                      f"{' pinned one per physical core' if L['pinned'] else ''}, envs of a vec-step drawn in runs of 8, barrier per vec-step",
+            "host": {"logical_cpus_in_affinity_mask": len(avail), "physical_cores": len(firsts), "sockets": _sockets(avail), "cgroup_cpu_quota": quota,
+                     "cgroup_cpu_quota_source": quota_src, "loadavg_1min": round(os.getloadavg()[0], 1)},
+            "legs": legs,
+            "value_16_threads": legs["16_threads"]["value"]}
 
 
 OTHER_TASKS = {  # --env values beyond the two benchmark configurations: (env kwargs, kernel) per training/icra_2024_run_experiments.sh:4-9
@@ -156,22 +215,122 @@ def make_gather(G, world, mode="serial"):
     return (lambda k: dist.all_gather_into_tensor(gathered, G.packed_head)), (lambda: None), gathered
 
 
-def spawn_ranks(n, argv):
+def spawn_ranks(n, argv, script=None, deadline_s=3000.0, poll_s=0.2):
     """`python bench.py --gpus N` without a launcher: start the N ranks as children (RANK/LOCAL_RANK/WORLD_SIZE/MASTER_* in their env).
-    This parent never initialises torch.cuda or HIP and never execs; rank 0's stdout (the one JSON line) is passed through."""
+    This parent never initialises torch.cuda or HIP and never execs; rank 0's stdout (the one JSON line) is passed through, the other ranks'
+    stdout is dropped (their stderr stays visible).  The children are polled: the first one that exits non-zero -- a HIP error, an import error, an
+    assert before or inside init_process_group -- ends the run: its siblings, which would otherwise sit in the RCCL rendezvous or a collective holding
+    their GPUs, are terminated (killed after 5 s), and that exit code is returned.  `deadline_s` bounds the whole run the same way (exit code 124).
+    Nothing is restarted.  `script`: the program the ranks run (default: this file); tests pass a stub."""
     import socket
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    script = os.path.abspath(script or __file__)
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                    HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env, stdout=None if r == 0 else subprocess.DEVNULL))
-    rc = 0
-    for p in procs:
-        rc = max(rc, abs(p.wait()))
-    return rc
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+
+    def stop_all():
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 5.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.0, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+
+    t_dead = time.monotonic() + deadline_s
+    try:
+        while True:
+            codes = [p.poll() for p in procs]
+            bad = [(r, c) for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                r, c = bad[0]
+                print(f"bench.py: rank {r} exited with code {c}; stopping the other ranks", file=sys.stderr)
+                stop_all()
+                return abs(c) if abs(c) < 256 else 1
+            if all(c == 0 for c in codes):
+                return 0
+            if time.monotonic() > t_dead:
+                print(f"bench.py: the {n} ranks did not finish within {deadline_s:.0f} s; stopping them", file=sys.stderr)
+                stop_all()
+                return 124
+            time.sleep(poll_s)
+    except BaseException:
+        stop_all()
+        raise
+
+
+def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None):
+    """The benchmark's workloads by name (BASELINE.json configs): env kwargs as the reference's training configs set them, envs per GPU, wrappers.
+    tests/test_bench_state_gpu.py builds its batches through this function and `make_bench_batch`, so what it compares with the oracle is what is timed."""
+    pick_place = env != "ReachHuman"   # every other task carries the manipulation object's state block
+    if env == "mixed":
+        if ik:
+            raise SystemExit("--ik: the mixed batch takes joint-space actions")
+        env_kwargs, shield = dict(seed=1234), "per task"
+    elif env in OTHER_TASKS:
+        env_kwargs = dict(shield_type=shield, control_freq=10, seed=1234)
+        env_kwargs.update(OTHER_TASKS[env][0])
+        from human_robot_gym_amd.mixed import task_env_kwargs
+        env_kwargs.update(task_env_kwargs(env))   # what goes with the task's synthetic clips (hammering: the weld pose that holds the board level)
+        shield = env_kwargs["shield_type"]
+    elif pick_place:  # training/config/environment/pick_place_human_cart.yaml
+        env_kwargs = dict(shield_type=shield, control_freq=10, horizon=1000, done_at_success=False, goal_dist=0.1,
+                          reward_shaping=False, collision_reward=0, object_gripped_reward=-0.25, seed=1234)
+    else:             # training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
+        env_kwargs = dict(shield_type=shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
+                          reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
+    n = envs_per_gpu or (8192 if env == "PickPlaceHumanCart" else ENVS_PER_GPU)
+    wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if ik else {}
+    return dict(env=env, shield=shield, ik=bool(ik), n=n, env_kwargs=env_kwargs, wrappers=wrappers, pick_place=pick_place)
+
+
+def make_bench_batch(W, rank=0, local_rank=0, stagger=True):
+    """(batch, model desc, mixed task list or None, staggered) of a `bench_workload`: reset, TimeLimit phases staggered over the horizon."""
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd._lib import HipBatch
+    n, env = W["n"], W["env"]
+    mixed_tasks = None
+    if env == "mixed":  # one HipBatch per task on its own stream, one packed output block (human_robot_gym_amd/mixed.py)
+        from human_robot_gym_amd import mixed
+        mixed_tasks = [t[0] for t in mixed.ICRA_TASKS]
+        G = mixed.make_mixed_batch(n, seed=1234, env_id0=rank * n, device=local_rank)
+        desc = hrg.build_model_desc(dict(seed=1234), env_id="PickPlaceHumanCart")   # (substeps per step and the horizon field of the report only)
+    else:
+        clips = _bench_clips(env, 0)
+        desc = hrg.build_model_desc(W["env_kwargs"], n_clips=clips.n_clips, env_id=env, **W["wrappers"])
+        G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
+    G.reset()
+    staggered = False
+    if not mixed_tasks and stagger:   # spread the TimeLimit phase: ~n / horizon envs time out in every step instead of all of them every `horizon` steps
+        G.stagger_episode_phases(int(desc.horizon))
+        staggered = True
+    return G, desc, mixed_tasks, staggered
+
+
+def bench_action_pool(n, dev, rank=0, ik=False, n_pool=32):
+    """The benchmark's synthetic actions: a pool of U(-1, 1)^7 batches on the device, cycled step by step."""
+    import torch
+    from human_robot_gym_amd._cstruct import CONST as C
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1234 + rank)
+    pool = [torch.rand((n, C["HRG_ACT_DIM"]), generator=gen, device=dev, dtype=torch.float64) * 2 - 1 for _ in range(n_pool)]
+    if ik:  # position deltas U(-0.15, 0.15)^3, gripper U(-1, 1)
+        for a in pool:
+            a[:, :3] *= 0.15
+    return pool
+
+
+def bench_preroll_steps(desc, preroll=None):
+    """Untimed steps before the warm-up: one horizon, at most 1000."""
+    return preroll if preroll is not None else min(int(desc.horizon), 1000)
 
 
 def main():
@@ -231,47 +390,11 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    # ReachHuman training configuration: training/config/environment/reach_human.yaml + human_reach_ppo_parallel.yaml
-    pick_place = args.env != "ReachHuman"   # every other task carries the manipulation object's state block
-    if args.env in OTHER_TASKS:
-        env_kwargs = dict(shield_type=args.shield, control_freq=10, seed=1234)
-        env_kwargs.update(OTHER_TASKS[args.env][0])
-        from human_robot_gym_amd.mixed import task_env_kwargs
-        env_kwargs.update(task_env_kwargs(args.env))   # what goes with the task's synthetic clips (hammering: the weld pose that holds the board level)
-        args.shield = env_kwargs["shield_type"]
-    elif pick_place:  # training/config/environment/pick_place_human_cart.yaml
-        env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=1000, done_at_success=False, goal_dist=0.1,
-                          reward_shaping=False, collision_reward=0, object_gripped_reward=-0.25, seed=1234)
-    else:
-        env_kwargs = dict(shield_type=args.shield, control_freq=10, horizon=100, done_at_success=True, goal_dist=0.1,
-                          reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
-    n = args.envs_per_gpu or (8192 if args.env == "PickPlaceHumanCart" else ENVS_PER_GPU)
-    wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if args.ik else {}
-    mixed_tasks = None
-    if args.env == "mixed":  # one HipBatch per task on its own stream, one packed output block (human_robot_gym_amd/mixed.py)
-        from human_robot_gym_amd import mixed
-        if args.ik:
-            raise SystemExit("--ik: the mixed batch takes joint-space actions")
-        mixed_tasks = [t[0] for t in mixed.ICRA_TASKS]
-        G = mixed.make_mixed_batch(n, seed=1234, env_id0=rank * n, device=local_rank)
-        desc = hrg.build_model_desc(dict(seed=1234), env_id="PickPlaceHumanCart")   # (substeps per step and the horizon field of the report only)
-        args.shield = "per task"
-    else:
-        clips = _bench_clips(args.env, 0)
-        desc = hrg.build_model_desc(env_kwargs, n_clips=clips.n_clips, env_id=args.env, **wrappers)
-        G = HipBatch(desc, clips, n, env_id0=rank * n, device=local_rank)
+    W = bench_workload(args.env, args.shield, args.ik, args.envs_per_gpu)
+    args.shield, n, env_kwargs, wrappers, pick_place = W["shield"], W["n"], W["env_kwargs"], W["wrappers"], W["pick_place"]
+    G, desc, mixed_tasks, staggered = make_bench_batch(W, rank=rank, local_rank=local_rank, stagger=not args.no_stagger)
     dev = G.device
-    G.reset()
-    staggered = False
-    if not mixed_tasks and not args.no_stagger:   # spread the TimeLimit phase: ~n / horizon envs time out in every step instead of all of them every `horizon` steps
-        G.stagger_episode_phases(int(desc.horizon))
-        staggered = True
-    gen = torch.Generator(device=dev)
-    gen.manual_seed(1234 + rank)
-    pool = [torch.rand((n, C["HRG_ACT_DIM"]), generator=gen, device=dev, dtype=torch.float64) * 2 - 1 for _ in range(32)]
-    if args.ik:  # position deltas U(-0.15, 0.15)^3, gripper U(-1, 1)
-        for a in pool:
-            a[:, :3] *= 0.15
+    pool = bench_action_pool(n, dev, rank, args.ik)
     fresh = [torch.empty_like(pool[0]) for _ in range(2)]  # the kernel rewrites action rows in place when wrappers are on
     # N > 1: every rank's packed outputs are published to all ranks with one RCCL all-gather per step on the compute stream.
     publish = finish = None
@@ -289,7 +412,7 @@ def main():
             publish(k)
 
     # pre-roll: spread the episode phases (a fresh batch has every env at timestep 0, nobody braking, no contacts yet)
-    preroll = args.preroll if args.preroll is not None else min(int(desc.horizon), 1000)
+    preroll = bench_preroll_steps(desc, args.preroll)
     for k in range(preroll):
         one_step(k, exchange=False)
     for k in range(args.warmup):

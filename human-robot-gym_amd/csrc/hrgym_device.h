@@ -60,70 +60,20 @@
 #endif
 #define BODY_BOX 100            // body code of the cube in Contact.b1/b2
 #define DI __device__ __forceinline__
-// tuning knobs (measured on MI355X, profiles/README.md).  Shipping configuration: every phase inlined into the kernel,
-// 128-VGPR cap (4 waves/SIMD: all 4096 envs of a batch resident at once, 16 single-wave workgroups per CU) and the
-// per-cycle "opaque lane id / opaque model pointer" barriers that stop loop-invariant hoisting out of the 25-cycle loop.
-// Phases as real functions (HRG_NOINLINE=1) run at the same speed but save callee-saved VGPRs to scratch on every call:
-// 2.3 GB of HBM writes per launch instead of 57 MB.
-#ifndef HRG_NOINLINE
-#define HRG_NOINLINE 0
-#endif
+// Shipping configuration (measured on MI355X, profiles/README.md): every phase inlined into the kernel, 128-VGPR cap (4 waves/SIMD: all 4096 envs of a
+// batch resident at once, 16 single-wave workgroups per CU) and the per-cycle "opaque lane id / opaque model pointer" barriers that stop loop-invariant
+// hoisting out of the 25-cycle loop.  Phases as real functions ran at the same speed but saved callee-saved VGPRs to scratch on every call (2.3 GB of HBM
+// writes per launch instead of 57 MB): the switches that built them are gone, the measurements are in DESIGN.md section 8.
 #ifndef HRG_MIN_WAVES
 #define HRG_MIN_WAVES 4
 #endif
-#if HRG_NOINLINE
-#define HRG_PHASE __device__ __noinline__
-#else
 #define HRG_PHASE __device__ __forceinline__
-#endif
-// phases that need more than the ~78 caller-saved VGPRs would save/restore callee-saved registers on every call
-// (scratch traffic): HRG_BIGINLINE=1 inlines those into the kernel instead
-// HRG_CYCLEFN=1: one real function per shield cycle (all phases inlined inside it) instead of one per phase
-#ifndef HRG_CYCLEFN
-#define HRG_CYCLEFN 0
-#endif
-#ifndef HRG_BIGINLINE
-#define HRG_BIGINLINE 0
-#endif
-#if HRG_BIGINLINE
-#define HRG_BIGPHASE __device__ __forceinline__
-#else
-#define HRG_BIGPHASE HRG_PHASE
-#endif
-// tuning experiments: HRG_NI_MASK makes single phases real functions (1 dynamics terms, 2 human, 4 shield, 8 collide, 16 classify, 32 dynamics step)
-#ifndef HRG_NI_MASK
-#define HRG_NI_MASK 0
-#endif
-#if (HRG_NI_MASK) & 1
-#define PH_DYNTERMS __device__ __noinline__
-#else
 #define PH_DYNTERMS HRG_PHASE
-#endif
-#if (HRG_NI_MASK) & 2
-#define PH_HUMAN __device__ __noinline__
-#else
-#define PH_HUMAN HRG_BIGPHASE
-#endif
-#if (HRG_NI_MASK) & 4
-#define PH_SHIELD __device__ __noinline__
-#else
-#define PH_SHIELD HRG_BIGPHASE
-#endif
-#if (HRG_NI_MASK) & 8
-#define PH_COLLIDE __device__ __noinline__
-#else
+#define PH_HUMAN HRG_PHASE
+#define PH_SHIELD HRG_PHASE
 #define PH_COLLIDE HRG_PHASE
-#endif
-#if (HRG_NI_MASK) & 16
-#define PH_CLASSIFY __device__ __noinline__
-#else
 #define PH_CLASSIFY HRG_PHASE
-#endif
-#if (HRG_NI_MASK) & 32
-#define PH_DYNSTEP __device__ __noinline__
-#else
-#define PH_DYNSTEP HRG_BIGPHASE
-#endif
+#define PH_DYNSTEP HRG_PHASE
 #define HRG_PI 3.14159265358979323846
 #define SIXTH (1.0 / 6.0)   // cubic term of the constant-jerk profiles: a product, not an FP64 division per segment
 
@@ -306,7 +256,10 @@ DI int hrg_lane() { return (int)(threadIdx.x & 63u); }
 // manoeuvre) from the front, the others from the back -- so busy envs start first and, with the dispatcher's placement (consecutive workgroups go round the 256 CUs, and
 // round the 4 SIMDs of a CU every 256), land on different SIMDs instead of piling their long instruction streams onto one.  buf = [order A (n) | order B (n) |
 // front/back counters A (2) | counters B (2)]; the launch with parity p reads order p, fills order 1-p through counters 1-p and clears counters p for the launch after it.
-struct StepOrder { int32_t* buf; int32_t n; int32_t parity; };
+// fair = the progress table of the level-waves priority (hrgym_hip.hip, HRG_FAIR): ONE table per device, shared by every kernel variant, so that waves of different
+// kernels of a mixed batch that share a SIMD see each other.
+#define HRG_FAIR_SLOTS (8 * 8 * 2 * 16 * 4 * 8)   // XCC x SE x SH x CU x SIMD x wave slot
+struct StepOrder { int32_t* buf; int32_t n; int32_t parity; int32_t* fair; };
 DI int hrg_env() { return (int)blockIdx.x * HRG_WG_WAVES + (int)(threadIdx.x >> 6); }
 #define HRG_LAUNCH_DIMS(n) dim3(((n) + HRG_WG_WAVES - 1) / HRG_WG_WAVES), dim3(64 * HRG_WG_WAVES)
 

@@ -2138,9 +2138,11 @@ __device__ __noinline__ void handover_first_pass_tail(const DevModel* __restrict
 #endif
 #endif
 #if HRG_FAIR
-static __device__ int g_fair[8 * 8 * 2 * 16 * 4 * 8];   // progress + 1 of the wave in slot w of a SIMD (0: no wave there)
+// the table: progress + 1 of the wave in slot w of a SIMD (0: no wave there); device memory owned by the host side, one per device (StepOrder.fair)
 // The readers of an entry are the waves of the SAME compute unit (other workgroups, but behind the same vector L1 and the same XCD's L2): workgroup-scope atomics
-// (plain cached loads / write-through stores) are coherent among them; agent scope sends every access past the caches (16 MB more HBM traffic per 4096-env launch).
+// (plain cached loads / write-through stores) are coherent among them in practice; agent scope sends every access past the caches (16 MB more HBM traffic per
+// 4096-env launch).  The memory model does not promise visibility across workgroups at workgroup scope: the table is a heuristic, a stale entry costs a priority
+// level for one cycle and never a result.
 #ifndef FAIR_SCOPE
 #define FAIR_SCOPE __HIP_MEMORY_SCOPE_WORKGROUP
 #endif
@@ -2150,12 +2152,12 @@ DI int fair_key() {
   const unsigned wave = hw & 0xf, simd = (hw >> 4) & 3, cu = (hw >> 8) & 0xf, sh = (hw >> 12) & 1, se = (hw >> 13) & 7;
   return (int)((((((xcc & 7) * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd) * 8 + (wave & 7));
 }
-DI void fair_publish(int lane, int progress) {   // progress >= 0; -1 = this wave is done
+DI void fair_publish(int* g_fair, int lane, int progress) {   // progress >= 0; -1 = this wave is done
   const int key = fair_key();
   if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, FAIR_SCOPE);
 }
 // top of a cycle: publish this wave's progress and start reading the siblings' (the load's latency hides behind the shield phase) ...
-DI int fair_begin(int lane, int progress) {
+DI int fair_begin(int* g_fair, int lane, int progress) {
   const int key = fair_key(), base = key & ~7;
   if (lane == 0) __hip_atomic_store(&g_fair[key], progress + 1, __ATOMIC_RELAXED, FAIR_SCOPE);
   int v = 0;
@@ -2177,22 +2179,10 @@ DI void fair_apply(int lane, int progress, int v, bool busy) {
   int pr;
   if (vmax == 0) pr = 0;                           // no sibling
   else {
-#if HRG_FAIR == 5                                  // proportional: one level per cycle behind the leader
-    pr = own < vmax ? vmax - own : 0;
-    if (busy) pr++;
-    if (pr > 3) pr = 3;
-#elif HRG_FAIR == 6                                // two levels
-    pr = (own < vmax || busy) ? 3 : 0;
-#elif HRG_FAIR == 3 || HRG_FAIR == 4               // three checkpoints per cycle: one unit behind is noise
-    pr = vmax - own >= 2 ? 3 : (vmax - own == 1 ? 2 : (own > vmin ? 0 : 1));
-#else
     pr = own < vmax ? (own <= vmin ? 3 : 2)        // somebody is ahead of this wave: last -> 3, in between -> 2
                     : (own > vmin ? 0 : 1);        // this wave leads -> 0; all level -> 1
-#endif
-#if HRG_FAIR == 2 || HRG_FAIR == 4
-    if (busy && pr < 2) pr = 2;
-#endif
   }
+  if (busy && pr < 2) pr = 2;                      // busy envs at least 2, also when no sibling has published yet
   pr = __builtin_amdgcn_readfirstlane(pr);
   if (pr == 3) __builtin_amdgcn_s_setprio(3);
   else if (pr == 2) __builtin_amdgcn_s_setprio(2);
@@ -2203,12 +2193,8 @@ DI void fair_apply(int lane, int progress, int v, bool busy) {
 
 // one shield cycle (human_env.py:503-526): controller goal on policy steps, shield, dynamics terms, PD+ torque,
 // human playback, contacts, integration.  Returns 1 when the simulation diverged.
-#if HRG_CYCLEFN
-__device__ __noinline__
-#else
-DI
-#endif
-int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, int busy, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+DI int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, int cyc, int busy, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int32_t* fair) {
+  (void)fair;
   // opaque per cycle: nothing derived from the lane id is hoisted out of the 25-cycle loop and kept live (spilled)
   asm volatile("" : "+v"(lane));
   const ModelPtr dm = uniform_model(dm_);
@@ -2216,13 +2202,9 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
   STAMP(0);
-#if HRG_FAIR == 3 || HRG_FAIR == 4
-#define FAIR_P(k) (3 * cyc + (k))
-#else
 #define FAIR_P(k) cyc
-#endif
 #if HRG_FAIR
-  int fair_v = fair_begin(lane, FAIR_P(0));
+  int fair_v = fair_begin(fair, lane, FAIR_P(0));
   const bool fair_busy = __builtin_amdgcn_readfirstlane((busy || !s.is_safe) ? 1 : 0) != 0;
 #elif !defined(HRG_NO_PRIO)
   // a launch ends with its slowest wave, and the waves of a SIMD share its issue slots: an env whose robot was in contact in the last substep (Newton
@@ -2256,9 +2238,6 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 #endif
   if (pm & 2) robot_dynamics_terms(dm_, lane);
   STAMP(2);
-#if HRG_FAIR == 3 || HRG_FAIR == 4
-  fair_v = fair_begin(lane, FAIR_P(1));
-#endif
   if (cyc == 0) { // Controller.update(): mj_fullM -> stale 6x6 block
     if (lane < NARM * NARM) s.mass_matrix[lane] = L.M[(lane / NARM) * NV + (lane % NARM)];
     wave_sync();
@@ -2284,10 +2263,6 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   wave_sync();
   STAMP(3);
   if (pm & 4) human_control(dm_, lane, gid); // _control_human + kinematics of sim.forward() #2
-#if HRG_FAIR == 3 || HRG_FAIR == 4
-  fair_apply(lane, FAIR_P(1), fair_v, fair_busy);
-  fair_v = fair_begin(lane, FAIR_P(2));
-#endif
 #if HRG_LIFT
   if (m.task == HRG_TASK_LIFTING) lifting_mocap(dm_, lane);   // CollaborativeLiftingCart._control_human (583-588)
 #endif
@@ -2325,9 +2300,6 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
   classify(dm_, lane, ncon, &hc, &ct);
   L.acc_has_collision = hc; L.acc_collision_type = ct;
   STAMP(6);
-#if HRG_FAIR == 3 || HRG_FAIR == 4
-  fair_apply(lane, FAIR_P(2), fair_v, fair_busy);
-#endif
   if (pm & 16) { const int r = dynamics_step(dm_, lane, ncon); crash = r & 1; busy_out |= r & 2; }
   STAMP(7);
 #endif
@@ -2344,11 +2316,12 @@ int cycle_body(const DevModel* __restrict__ dm_, int lane, int e, int64_t gid, i
 // HumanEnv.step (human_env.py:470-586) + ReachHuman.step tail (reach_human_env.py:399-407) + TimeLimit
 // (wrappers/time_limit.py:31-44) + VecEnv auto-reset
 DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_gid, double* __restrict__ action, float* obs, float* term_obs,
-                 float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh) {
+                 float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int32_t* fair) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
   hrg_env_state& s = L.st;
+  (void)fair;
   const int64_t gid = s.stream_id;  // in-episode draws follow the state's streams (= own_gid unless the state was copied in)
   int has_collision = 0, collision_type = HRG_COL_NULL, crash = 0;
   STAMP_INIT(lane);
@@ -2368,9 +2341,9 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
   wave_sync();
   int busy = 0;   // of the previous substep; a step starts unbiased
 #pragma unroll 1
-  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) { const int r = cycle_body(dm_, lane, e, gid, cyc, busy, dbg_r, dbg_h, dbg_nh); crash = r & 1; busy = r >> 1; }
+  for (int cyc = 0; cyc < m.n_cycles && !crash; cyc++) { const int r = cycle_body(dm_, lane, e, gid, cyc, busy, dbg_r, dbg_h, dbg_nh, fair); crash = r & 1; busy = r >> 1; }
 #if HRG_FAIR
-  fair_publish(lane, -1);   // this wave's slot is free again
+  fair_publish(fair, lane, -1);   // this wave's slot is free again
   __builtin_amdgcn_s_setprio(0);
 #endif
   has_collision = L.acc_has_collision; collision_type = L.acc_collision_type;
@@ -2852,7 +2825,7 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_
   wave_sync();
   float* tobs = term_obs ? term_obs + (size_t)e * HRG_OBS_DIM : scratch_obs + (size_t)e * HRG_OBS_DIM;
   const int busy = env_step(dm, lane, e, env_id0 + e, actions + (size_t)e * HRG_ACT_DIM, obs + (size_t)e * HRG_OBS_DIM, tobs, reward + e, done + e,
-                            info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh);
+                            info + (size_t)e * HRG_INFO_DIM, dbg_r, dbg_h, dbg_nh, ord.fair);
   wave_sync();
   if (lane == 0) {   // this env's place in the next launch
     int32_t* ctr = ord.buf + 2 * (size_t)ord.n + 2 * (1 - ord.parity);
@@ -3056,6 +3029,19 @@ struct hrg_batch {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
 };
+
+// the progress table of the level-waves priority (StepOrder.fair): one per device, shared by the batches and kernel variants that run on it; never freed
+static int32_t* fair_table(int device) {
+  static int32_t* tab[64] = {nullptr};
+  if (device < 0 || device >= 64) return nullptr;
+  if (!tab[device]) {
+    int32_t* p = nullptr;
+    if (hipMalloc(&p, sizeof(int32_t) * HRG_FAIR_SLOTS) != hipSuccess) return nullptr;
+    if (hipMemset(p, 0, sizeof(int32_t) * HRG_FAIR_SLOTS) != hipSuccess) { hipFree(p); return nullptr; }
+    tab[device] = p;
+  }
+  return tab[device];
+}
 
 static void mat_from_quat(double* M, const double* q) {
   double w = q[0], x = q[1], y = q[2], z = q[3];
@@ -3293,7 +3279,9 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
     else { HIPCHK(hipEventCreate(&ev.first)); HIPCHK(hipEventCreate(&ev.second)); }
     HIPCHK(hipEventRecord(ev.first, st));
   }
-  const StepOrder ord{b->d_order, b->n_envs, b->parity};
+  int32_t* fair = fair_table(b->device);
+  if (!fair) return fail(HRG_ERR_HIP, "cannot allocate the wave-progress table");
+  const StepOrder ord{b->d_order, b->n_envs, b->parity, fair};
   if (b->task == HRG_TASK_HAMMERING)
     hrg_hammer_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                            b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_hammers, ord);

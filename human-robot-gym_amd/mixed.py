@@ -25,9 +25,8 @@ ICRA_TASKS = (
 # ... and with the one task of the reference that is not part of that suite (CollaborativeHammeringCart has no experiment config): every task the stepper covers
 ALL_TASKS = ICRA_TASKS + (("CollaborativeHammeringCart", dict(horizon=1000, shield_type="SSM")),)
 # ms per 4096-env step of each task's kernel alone (profiles/r02t_tasks_summary.md): the mixed batch launches its kernels longest first.  The batch is bound by LDS residency
-# (the tasks' LDS images exceed the chip's 41 MB), so the order matters by 5 - 10 % -- but which order wins does not reproduce from one GPU box to the next: over all 720 orders
-# (tools/mixed_order_search.py) and A/B/A/B against the drift of the simulation state (tools/mixed_order_ab.py) "short kernels first" measured 5.33 vs 5.60 ms on one box and
-# 5.95 vs 5.71 ms on another.  Longest first is the order that was never the worst.
+# (the tasks' LDS images exceed the chip's 41 MB), so the order matters by 5 - 10 %, but which order wins did not reproduce from one GPU box to the next (round 2: a search over
+# all 720 orders and an A/B/A/B run, "short kernels first" 5.33 vs 5.60 ms on one box and 5.95 vs 5.71 ms on another).  Longest first is the order that was never the worst.
 _STEP_MS = {"CollaborativeHammeringCart": 8.9, "CollaborativeStackingCart": 7.44, "RobotHumanHandoverCart": 5.15, "HumanRobotHandoverCart": 4.86, "CollaborativeLiftingCart": 3.02,
             "HumanObjectInspectionCart": 2.92, "PickPlaceHumanCart": 2.1, "ReachHuman": 1.32}
 
@@ -97,8 +96,6 @@ class MixedBatch:
         self._launch_order = sorted(range(len(parts)), key=lambda i: -_STEP_MS.get(parts[i][0], 2.1) * int(parts[i][3]))
         with torch.cuda.device(self.device):
             self.streams = [torch.cuda.Stream() for _ in parts] if self.concurrent else None   # (high-priority streams for the long kernels: no effect, 8.46 vs 8.47 ms)
-        with torch.cuda.device(self.device):
-            self.streams = [torch.cuda.Stream() for _ in parts] if self.concurrent else None
 
     def _each(self, fn):
         t = self.torch

@@ -153,8 +153,11 @@ STACKING_ENV_KWARGS = dict(
     done_at_success=True,
     stack_weld_relpos=[0.0, 0.045, 0.0],   # relpose of lh_weld_eq / rh_weld_eq (1263-1281)
 )
-# CollaborativeHammeringCart constructor defaults (collaborative_hammering_cartesian_env.py:291-367) overlaid with
-# training/config/environment/default/collaborative_hammering_cart.yaml
+# CollaborativeHammeringCart constructor defaults (collaborative_hammering_cartesian_env.py:291-367) overlaid with training/config/environment/default/
+# collaborative_hammering_cart.yaml (table / board sizes, sampling rates) and, on top, the TOP-LEVEL training/config/environment/collaborative_hammering_cart.yaml
+# -- the convention of every other task here (what make_vec_env(env_id) steps is what the reference's training config for that env would step).  The top-level
+# file sets collision_reward 0, nail_hammered_in_reward 0.0, done_at_success false; its defaults list composes default/pick_place_human_cart instead of
+# default/collaborative_hammering_cart (a quirk of the reference: the task has no experiment config), which is NOT followed -- the task's own default file is.
 HAMMERING_ENV_KWARGS = dict(
     PICK_PLACE_ENV_KWARGS,
     horizon=1000,
@@ -162,9 +165,11 @@ HAMMERING_ENV_KWARGS = dict(
     board_full_size=[1.0, 0.4, 0.03],
     n_nail_placements_sampled_per_100_steps=1,
     goal_tolerance=0.05,
-    collision_reward=-10.0,
+    collision_reward=0.0,
     hammer_gripped_reward_bonus=0.0,
-    nail_hammered_in_reward=-1.0,
+    nail_hammered_in_reward=0.0,
+    done_at_collision=False,
+    done_at_success=False,
     task_reward=1.0,
     human_animation_freq=100,
     human_rand=[0.0, 0.0, 0.0],

@@ -381,7 +381,12 @@ class HipVecEnv(_VecEnvBase):
         self._ep_len += 1
         if (self._cp is not None or self._ik is not None) and self.info_dicts:
             self._actions = np.array(self._backend.executed_actions(), copy=True)
-        infos = self._make_infos(info, dones, term_obs) if self.info_dicts else [{} for _ in range(self.num_envs)]
+        if self.info_dicts:
+            infos = self._make_infos(info, dones, term_obs)
+        else:
+            infos = [{} for _ in range(self.num_envs)]
+            if self._monitor is not None:   # the Monitor csv does not depend on the per-env dicts: episode rows from the done mask and the info block
+                self._monitor_rows(np.asarray(info), np.nonzero(dones)[0])
         if self.expert_obs_keys is not None:
             self._expert_cur = np.array(full, copy=True)   # after an auto-reset: the new episode's first observation (wrapper reset())
         self._ep_ret[dones] = 0
@@ -409,12 +414,25 @@ class HipVecEnv(_VecEnvBase):
                 set_(d, "TimeLimit.truncated", tr)
                 set_(d, "terminal_observation", self._view(np.array(term_obs[i])))
                 set_(d, "episode", {"r": float(self._ep_ret[i]), "l": int(self._ep_len[i]), "t": now})
-                if self._monitor is not None:
-                    extra = [str(d[k]) for k in self._monitor_keys]
-                    self._monitor.write(",".join([f"{round(float(self._ep_ret[i]), 6)}", str(int(self._ep_len[i])), str(now)] + extra) + "\n")
             if self._monitor is not None:
-                self._monitor.flush()
+                self._monitor_rows(info, idx, now)
         return infos
+
+    def _monitor_rows(self, info, idx, now=None):
+        """One r,l,t(+info_keywords) row per finished episode (SB3 Monitor [UPSTREAM]); info_keywords are columns of the kernel's info block."""
+        if not len(idx):
+            return
+        now = round(time.time() - self._t_start, 6) if now is None else now
+        for i in idx.tolist():
+            extra = []
+            keys = list(self._info_keys)
+            for k in self._monitor_keys:
+                if k not in keys:
+                    raise KeyError(f"Monitor info_keywords: {k!r} is not a column of the info block ({keys})")
+                v = int(info[i, keys.index(k)])
+                extra.append(str(bool(v)) if k in _BOOL_KEYS else str(v))
+            self._monitor.write(",".join([f"{round(float(self._ep_ret[i]), 6)}", str(int(self._ep_len[i])), str(now)] + extra) + "\n")
+        self._monitor.flush()
 
     def close(self):
         if getattr(self, "_monitor", None) is not None:
@@ -458,7 +476,7 @@ class HipVecEnv(_VecEnvBase):
             return [(st, batch.get_stack(i)) for st, i in zip(states, idx)]
         if self.env_id == "CollaborativeHammeringCart":  # CollaborativeHammeringEnvState (collaborative_hammering_cartesian_env.py:56-89): board, hammer, nail + bookkeeping
             return [(st, batch.get_hammer(i)) for st, i in zip(states, idx)]
-        has_box = self.env_id != "ReachHuman"
+        has_box = self._reach_box or self.env_id != "ReachHuman"   # ReachHuman with its smallBox carries the object block too
         return [(st, boxes[k] if has_box else None) for k, st in enumerate(states)]
 
     def set_environment_state(self, states, indices=None):
@@ -476,7 +494,7 @@ class HipVecEnv(_VecEnvBase):
                 (batch.set_stack if self.env_id == "CollaborativeStackingCart" else batch.set_hammer)(i, sk)
             return
         boxes = [b for _, b in states]
-        bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and self.env_id != "ReachHuman" else None
+        bx_arr = (BoxState * len(idx))(*boxes) if all(b is not None for b in boxes) and (self._reach_box or self.env_id != "ReachHuman") else None
         batch.set_states(np.asarray(idx, np.int32), st_arr, bx_arr)
 
     def check_collision_action(self, actions):

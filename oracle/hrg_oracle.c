@@ -22,6 +22,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "../include/hrgym.h"
 #include "../include/hrgym_state.h"
@@ -3397,40 +3398,95 @@ int hrgo_step_range(hrgo_batch* B, int e0, int e1, double* actions, float* obs, 
   }
   return 0;
 }
-/* CPU-baseline harness (bench.py's cpu_baseline leg): the shape of the reference's SubprocVecEnv (utils/env_util_SB3.py:75-87) -- P workers, each
- * stepping its share of the envs, synchronised once per vec-step.  n_steps vec-steps with actions cycled from a pool [n_pool][n_envs][HRG_ACT_DIM];
- * cpus (or NULL) pins worker w to logical cpu cpus[w] (one per physical core). */
+/* CPU-baseline harness (bench.py's cpu_baseline leg): the shape of the reference's SubprocVecEnv (utils/env_util_SB3.py:75-87) -- P workers stepping
+ * the envs of a vec-step, synchronised once per vec-step.  n_steps vec-steps with actions cycled from a pool [n_pool][n_envs][HRG_ACT_DIM];
+ * cpus (or NULL) pins worker w to logical cpu cpus[w] (one per physical core).
+ * chunk = 0: worker w owns the fixed env range [n w / P, n (w + 1) / P) (one env process per worker, as SubprocVecEnv has it).
+ * chunk > 0: the workers of a vec-step draw runs of `chunk` envs from a shared counter until the step is used up -- the per-env cost depends on the
+ *            env's state (contacts, fail-safe manoeuvres: 2 - 3 x), and on a shared host a pinned worker may lose its core for a while; with fixed ranges
+ *            every vec-step then waits for its unluckiest worker.  Results do not depend on who steps an env (envs never interact).
+ * busy_s (or NULL): per worker, the seconds it spent inside env_step (the rest of the wall time it waited at the barrier). */
 typedef struct {
-  hrgo_batch* B; int w, nw, n_steps, n_pool; const double* pool; float* obs; float* reward; uint8_t* done; int32_t* info; pthread_barrier_t* bar; int cpu;
+  hrgo_batch* B; int w, nw, n_steps, n_pool, chunk; const double* pool; double* actions; float* obs; float* term_obs; float* reward; uint8_t* done; int32_t* info;
+  pthread_barrier_t* bar; int cpu; int* next; double busy;
 } hrgo_worker_t;
+static double now_s(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return (double)t.tv_sec + 1e-9 * (double)t.tv_nsec; }
 static void* hrgo_worker(void* arg) {
   hrgo_worker_t* W = (hrgo_worker_t*)arg;
   if (W->cpu >= 0) { cpu_set_t set; CPU_ZERO(&set); CPU_SET(W->cpu, &set); pthread_setaffinity_np(pthread_self(), sizeof set, &set); }
-  const int n = W->B->n_envs, e0 = (int)((long long)n * W->w / W->nw), e1 = (int)((long long)n * (W->w + 1) / W->nw);
+  const int n = W->B->n_envs;
   double act[HRG_ACT_DIM];
   for (int k = 0; k < W->n_steps; k++) {
-    const double* a = W->pool + (size_t)(k % W->n_pool) * n * HRG_ACT_DIM;
-    for (int e = e0; e < e1; e++) {
-      float tmp[HRG_OBS_DIM];
-      memcpy(act, a + (size_t)e * HRG_ACT_DIM, sizeof act); /* the wrappers rewrite the action row in place: work on a copy of the pool */
-      env_step(W->B, e, act, W->obs + (size_t)e * HRG_OBS_DIM, tmp, W->reward + e, W->done + e, W->info + (size_t)e * HRG_INFO_DIM);
+    const double* a = W->pool ? W->pool + (size_t)(k % W->n_pool) * n * HRG_ACT_DIM : NULL;
+    const double t0 = now_s();
+    for (;;) {
+      int e0, e1;
+      if (W->chunk > 0) { e0 = __atomic_fetch_add(&W->next[k], W->chunk, __ATOMIC_RELAXED); e1 = e0 + W->chunk < n ? e0 + W->chunk : n; }
+      else { e0 = (int)((long long)n * W->w / W->nw); e1 = (int)((long long)n * (W->w + 1) / W->nw); }
+      for (int e = e0; e < e1; e++) {
+        float tmp[HRG_OBS_DIM];
+        double* ap = act;
+        if (a) memcpy(act, a + (size_t)e * HRG_ACT_DIM, sizeof act); /* the wrappers rewrite the action row in place: work on a copy of the pool */
+        else ap = W->actions + (size_t)e * HRG_ACT_DIM;              /* a caller's own action block (one vec-step): rewritten in place like hrgo_step does */
+        env_step(W->B, e, ap, W->obs + (size_t)e * HRG_OBS_DIM, W->term_obs ? W->term_obs + (size_t)e * HRG_OBS_DIM : tmp, W->reward + e, W->done + e,
+                 W->info + (size_t)e * HRG_INFO_DIM);
+      }
+      if (W->chunk <= 0 || e1 >= n) break;
     }
+    W->busy += now_s() - t0;
     pthread_barrier_wait(W->bar); /* VecEnv.step_wait: every worker has finished the step */
   }
   return NULL;
 }
-int hrgo_rollout_parallel(hrgo_batch* B, int n_workers, const int32_t* cpus, int n_steps, const double* pool, int n_pool, float* obs, float* reward, uint8_t* done, int32_t* info) {
-  if (n_workers < 1 || n_workers > 1024 || n_pool < 1) return -1;
+static int run_workers(hrgo_batch* B, int n_workers, const int32_t* cpus, int n_steps, const double* pool, int n_pool, double* actions, int chunk, float* obs, float* term_obs,
+                       float* reward, uint8_t* done, int32_t* info, double* busy_s) {
+  if (n_workers < 1 || n_workers > 1024 || n_pool < 1 || n_steps < 0) return -1;
   pthread_t th[1024];
-  static hrgo_worker_t W[1024];
+  hrgo_worker_t* W = (hrgo_worker_t*)calloc((size_t)n_workers, sizeof *W);
+  int* next = (int*)calloc((size_t)n_steps + 1, sizeof(int));
   pthread_barrier_t bar;
   pthread_barrier_init(&bar, NULL, (unsigned)n_workers);
+  int started = 0, rc = 0;
   for (int w = 0; w < n_workers; w++) {
-    W[w] = (hrgo_worker_t){B, w, n_workers, n_steps, n_pool, pool, obs, reward, done, info, &bar, cpus ? cpus[w] : -1};
-    if (pthread_create(&th[w], NULL, hrgo_worker, &W[w]) != 0) return -2;
+    W[w] = (hrgo_worker_t){B, w, n_workers, n_steps, n_pool, chunk, pool, actions, obs, term_obs, reward, done, info, &bar, cpus ? cpus[w] : -1, next, 0.0};
+    if (pthread_create(&th[w], NULL, hrgo_worker, &W[w]) != 0) { rc = -2; break; }
+    started++;
   }
-  for (int w = 0; w < n_workers; w++) pthread_join(th[w], NULL);
+  if (rc != 0) { /* a team that is short of a member would wait at the barrier for ever: the members that did start are cancelled */
+    for (int w = 0; w < started; w++) pthread_cancel(th[w]);
+  }
+  for (int w = 0; w < started; w++) pthread_join(th[w], NULL);
+  if (busy_s) for (int w = 0; w < n_workers; w++) busy_s[w] = W[w].busy;
   pthread_barrier_destroy(&bar);
+  free(next); free(W);
+  return rc;
+}
+int hrgo_rollout_parallel(hrgo_batch* B, int n_workers, const int32_t* cpus, int n_steps, const double* pool, int n_pool, float* obs, float* reward, uint8_t* done, int32_t* info) {
+  return run_workers(B, n_workers, cpus, n_steps, pool, n_pool, NULL, 0, obs, NULL, reward, done, info, NULL);
+}
+int hrgo_rollout_parallel2(hrgo_batch* B, int n_workers, const int32_t* cpus, int n_steps, const double* pool, int n_pool, int chunk, float* obs, float* reward, uint8_t* done,
+                           int32_t* info, double* busy_s) {
+  return run_workers(B, n_workers, cpus, n_steps, pool, n_pool, NULL, chunk, obs, NULL, reward, done, info, busy_s);
+}
+/* one vec-step of the whole batch on n_workers threads (what hrgo_step does on one): the parity tests at the benchmark's batch sizes */
+int hrgo_step_parallel(hrgo_batch* B, int n_workers, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done, int32_t* info) {
+  return run_workers(B, n_workers, NULL, 1, NULL, 1, actions, 8, obs, term_obs, reward, done, info, NULL);
+}
+/* all state blocks at once (arrays of n_envs blocks; a NULL pointer skips that kind): copying a HIP batch's state into the checker and back */
+int hrgo_get_states(hrgo_batch* B, hrg_env_state* st, hrg_box_state* box, hrg_stack_state* stk, hrg_hammer_state* hmr) {
+  const size_t n = (size_t)B->n_envs;
+  if (st) memcpy(st, B->st, n * sizeof *st);
+  if (box) memcpy(box, B->box, n * sizeof *box);
+  if (stk) memcpy(stk, B->stk, n * sizeof *stk);
+  if (hmr) memcpy(hmr, B->hmr, n * sizeof *hmr);
+  return 0;
+}
+int hrgo_set_states(hrgo_batch* B, const hrg_env_state* st, const hrg_box_state* box, const hrg_stack_state* stk, const hrg_hammer_state* hmr) {
+  const size_t n = (size_t)B->n_envs;
+  if (st) memcpy(B->st, st, n * sizeof *st);
+  if (box) memcpy(B->box, box, n * sizeof *box);
+  if (stk) memcpy(B->stk, stk, n * sizeof *stk);
+  if (hmr) memcpy(B->hmr, hmr, n * sizeof *hmr);
   return 0;
 }
 int hrgo_get_state(hrgo_batch* B, int e, void* buf, size_t bytes) {

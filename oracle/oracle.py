@@ -85,6 +85,47 @@ class OracleBatch:
                                             _p(self.obs), _p(self.reward), _p(self.done), _p(self.info))
         assert rc == 0, rc
 
+    def rollout_parallel2(self, pool, n_steps, n_workers, cpus=None, chunk=8):
+        """rollout_parallel with the envs of a vec-step drawn in runs of `chunk` from a shared counter (0: fixed ranges); returns the seconds each worker
+        spent stepping envs (the rest of the wall time it waited at the per-step barrier)."""
+        pool = np.ascontiguousarray(pool, np.float64)
+        assert pool.ndim == 3 and pool.shape[1:] == (self.n, self.C["HRG_ACT_DIM"])
+        cp = None if cpus is None else np.ascontiguousarray(cpus, np.int32)
+        assert cp is None or len(cp) >= n_workers
+        busy = np.zeros(n_workers, np.float64)
+        rc = self.lib.hrgo_rollout_parallel2(self.h, ctypes.c_int(n_workers), None if cp is None else _p(cp), ctypes.c_int(n_steps), _p(pool), ctypes.c_int(len(pool)),
+                                             ctypes.c_int(chunk), _p(self.obs), _p(self.reward), _p(self.done), _p(self.info), _p(busy))
+        assert rc == 0, rc
+        return busy
+
+    def step_parallel(self, actions, n_workers=None):
+        """`step` on n_workers threads (default: the CPUs of the affinity mask, at most 32): parity tests at the benchmark's batch sizes."""
+        import os
+        a = np.ascontiguousarray(actions, np.float64)
+        assert a.shape == (self.n, self.C["HRG_ACT_DIM"])
+        self.last_actions = a
+        nw = n_workers or max(1, min(32, len(os.sched_getaffinity(0))))
+        rc = self.lib.hrgo_step_parallel(self.h, ctypes.c_int(nw), _p(a), _p(self.obs), _p(self.term_obs), _p(self.reward), _p(self.done), _p(self.info))
+        assert rc == 0, rc
+        return self.obs.copy(), self.reward.copy(), self.done.copy(), self.info.copy()
+
+    def get_states_all(self, box=False, stack=False, hammer=False):
+        """(EnvState[n], BoxState[n] | None, StackState[n] | None, HammerState[n] | None): every state block of the batch in one call."""
+        from human_robot_gym_amd._cstruct import BoxState, StackState, HammerState
+        st = (self.EnvState * self.n)()
+        bx = (BoxState * self.n)() if box else None
+        sk = (StackState * self.n)() if stack else None
+        hm = (HammerState * self.n)() if hammer else None
+        ref = lambda x: ctypes.byref(x) if x is not None else None
+        assert self.lib.hrgo_get_states(self.h, ctypes.byref(st), ref(bx), ref(sk), ref(hm)) == 0
+        return st, bx, sk, hm
+
+    def set_states_all(self, st=None, bx=None, sk=None, hm=None):
+        for x in (st, bx, sk, hm):
+            assert x is None or len(x) == self.n
+        ref = lambda x: ctypes.byref(x) if x is not None else None
+        assert self.lib.hrgo_set_states(self.h, ref(st), ref(bx), ref(sk), ref(hm)) == 0
+
     def get_state(self, e):
         s = self.EnvState()
         assert self.lib.hrgo_get_state(self.h, ctypes.c_int(e), ctypes.byref(s), ctypes.c_size_t(ctypes.sizeof(s))) == 0

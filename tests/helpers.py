@@ -143,3 +143,59 @@ class OracleBackend:
 
     def close(self):
         self.B.close()
+
+
+# ---------------------------------------------------------------------------------------------- bulk comparisons (benchmark-size batches)
+def struct_leaves(t, base=0, path=""):
+    """[(path, byte offset, numpy dtype, count)] of the scalar leaves of a ctypes struct type (arrays of scalars are one leaf)."""
+    import ctypes
+    out = []
+    for name, ft in t._fields_:
+        off = base + getattr(t, name).offset
+        p = f"{path}.{name}" if path else name
+        dims = 1
+        et = ft
+        while issubclass(et, ctypes.Array):
+            dims *= et._length_
+            et = et._type_
+        if issubclass(et, ctypes.Structure):
+            for k in range(dims):
+                out += struct_leaves(et, off + k * ctypes.sizeof(et), f"{p}[{k}]" if dims > 1 or issubclass(ft, ctypes.Array) else p)
+        else:
+            dt = {ctypes.c_double: np.float64, ctypes.c_float: np.float32, ctypes.c_int32: np.int32, ctypes.c_uint32: np.uint32, ctypes.c_int64: np.int64,
+                  ctypes.c_uint64: np.uint64, ctypes.c_uint8: np.uint8}[et]
+            out.append((p, off, dt, dims))
+    return out
+
+
+def states_as_bytes(arr):
+    """ctypes array of n structs -> uint8 [n, sizeof] view."""
+    import ctypes
+    n = len(arr)
+    return np.frombuffer(arr, dtype=np.uint8).reshape(n, ctypes.sizeof(arr._type_))
+
+
+def compare_states_bulk(so, sg, skip=(), only=None):
+    """Two ctypes arrays of the same struct type, env by env: integers bit-exact, floats within RTOL / ATOL (ltt.T: atol 2e-5, see assert_state_close).
+    Leaves whose path contains one of `skip` are left out; with `only`, just the leaves whose path contains one of its entries are compared.  Returns (ok [n] bool, first mismatch message or None)."""
+    t = so._type_
+    bo, bg = states_as_bytes(so), states_as_bytes(sg)
+    n = len(so)
+    ok = np.ones(n, bool)
+    msg = None
+    for path, off, dt, cnt in struct_leaves(t):
+        if any(s in path for s in skip) or (only is not None and not any(s in path for s in only)):
+            continue
+        w = np.dtype(dt).itemsize * cnt
+        a = np.ascontiguousarray(bo[:, off:off + w]).view(dt).reshape(n, cnt)
+        b = np.ascontiguousarray(bg[:, off:off + w]).view(dt).reshape(n, cnt)
+        if np.issubdtype(dt, np.floating):
+            atol = 2e-5 if path.endswith("ltt.T") else ATOL
+            good = np.all(np.abs(b - a) <= atol + RTOL * np.abs(a), axis=1)
+        else:
+            good = np.all(a == b, axis=1)
+        if msg is None and not good.all():
+            e = int(np.nonzero(~good)[0][0])
+            msg = f"{path}: env {e}: oracle {a[e].tolist()} hip {b[e].tolist()}"
+        ok &= good
+    return ok, msg

@@ -1,0 +1,187 @@
+"""The state the benchmark times, compared with the oracle at the benchmark's batch size.  -m gpu.
+
+Every other HIP-vs-oracle test runs tens of envs from a reset.  The headline numbers are measured on 4096 / 8192 envs after a pre-roll of one horizon with the
+TimeLimit phases staggered, a launch order that is re-permuted every step and hardware-position-indexed priority tables: this is the one place where all of
+that meets the checker.  Each case builds its batch through bench.py's own functions (`bench_workload`, `make_bench_batch`, `bench_action_pool`,
+`bench_preroll_steps`), rolls it on the HIP path to where bench.py starts its timed region (pre-roll + the default warm-up), copies EVERY env's state blocks
+into the oracle and steps both for a few policy steps with the HIP state re-synchronised after each: info / done / contact pairs / integer state bit-exact,
+observations / reward / float state within 1e-5 relative, for every env.  Envs that leave the comparison are counted by cause and bounded:
+  violent  -- |qvel| > 5 rad/s before or after the step, or a simulation crash: chaotic, compared nowhere in the suite;
+  flicker  -- the contact LIST differs while every float of the state agrees to 1e-7: a resting contact at distance zero.
+"""
+import ctypes
+import os
+import sys
+import time
+
+import numpy as np
+import pytest
+
+from helpers import ATOL, RTOL, assert_state_close, compare_states_bulk, states_as_bytes
+
+pytestmark = pytest.mark.gpu
+
+N_STEPS = 4
+REP = ("ltt.dur", "ltt.jerk", "safe_path.dur", "safe_path.jerk")   # representations compared through the motion they define (helpers.assert_state_close)
+
+
+def _kinds(env_id):
+    """which object block a task streams next to hrg_env_state"""
+    if env_id == "ReachHuman":
+        return None
+    return {"CollaborativeStackingCart": "stack", "CollaborativeHammeringCart": "hammer"}.get(env_id, "box")
+
+
+def _hip_states(G, kind):
+    from human_robot_gym_amd._cstruct import StackState, HammerState
+    idx = np.arange(G.n, dtype=np.int32)
+    st, bx = G.get_states(idx)
+    sk = (StackState * G.n)(*[G.get_stack(e) for e in range(G.n)]) if kind == "stack" else None
+    hm = (HammerState * G.n)(*[G.get_hammer(e) for e in range(G.n)]) if kind == "hammer" else None
+    return st, (bx if kind == "box" else None), sk, hm
+
+
+def _hip_set_states(G, kind, st, bx, sk, hm):
+    idx = np.arange(G.n, dtype=np.int32)
+    G.set_states(idx, st, bx if kind == "box" else None)
+    if kind == "stack":
+        for e in range(G.n):
+            G.set_stack(e, sk[e])
+    if kind == "hammer":
+        for e in range(G.n):
+            G.set_hammer(e, hm[e])
+
+
+def _qvel_max(st):
+    from human_robot_gym_amd._cstruct import EnvState
+    off = EnvState.qvel.offset
+    b = states_as_bytes(st)
+    return np.abs(np.ascontiguousarray(b[:, off:off + 8 * 8]).view(np.float64)).max(axis=1)
+
+
+def _compare_part(name, k, G, O, a_np, kind, tally):
+    """One policy step of one task's batch on both sides (the HIP step has been launched and synchronised by the caller); returns the oracle's post state."""
+    pre = O.get_states_all()[0]
+    o_o, r_o, d_o, i_o = O.step_parallel(a_np)
+    post = O.get_states_all(box=kind == "box", stack=kind == "stack", hammer=kind == "hammer")
+    o_g, r_g, d_g, i_g = [x.cpu().numpy() for x in (G.obs, G.reward, G.done, G.info)]
+    t_g = G.term_obs.cpu().numpy()
+    violent = (i_o[:, 11] != 0) | (_qvel_max(pre) > 5.0) | (_qvel_max(post[0]) > 5.0)
+    hip = _hip_states(G, kind)
+    po, no = O.contacts()
+    pg, ng = G.contacts()
+    con_same = (no == ng) & np.all(po == pg, axis=(1, 2))
+    msg = f"{name} step {k}"
+    # --- state blocks: everything but the contact list and the representation tables, vectorised over the batch
+    ok, why = compare_states_bulk(post[0], hip[0], skip=REP + ("ncon", "con_pairs", "n_prev", "prev_pairs"))
+    for a, b in zip(post[1:], hip[1:]):
+        if a is not None:
+            ok2, why2 = compare_states_bulk(a, b)
+            why = why or why2
+            ok &= ok2
+    # --- flicker: the contact list differs, every float of the state agrees (to 1e-7 absolute): a zero-load contact listed on one side only
+    flick = ~con_same & ~violent
+    if flick.any():
+        bo, bg = states_as_bytes(post[0]), states_as_bytes(hip[0])
+        from human_robot_gym_amd._cstruct import EnvState
+        nd = EnvState.timestep.offset // 8   # the doubles come first
+        fo, fg = bo[:, :8 * nd].copy().view(np.float64), bg[:, :8 * nd].copy().view(np.float64)
+        flick &= np.all(np.abs(fo - fg) <= 1e-7 + 1e-7 * np.abs(fo), axis=1)
+    chk = ~violent & ~flick
+    tally["violent"] += int(violent.sum()); tally["flicker"] += int(flick.sum()); tally["compared"] += int(chk.sum()); tally["total"] += len(chk)
+    assert con_same[chk].all(), f"{msg}: contact pairs differ in envs {np.nonzero(chk & ~con_same)[0][:8].tolist()}"
+    bad = np.nonzero(chk & ~ok)[0]
+    assert bad.size == 0, f"{msg}: state differs in {bad.size} envs (first: {why})"
+    # the representation tables: equal for almost every env; the rest through the motion they define (slow path, few envs)
+    ok_rep, _ = compare_states_bulk(post[0], hip[0], only=REP)
+    slow = np.nonzero(chk & ~ok_rep)[0]
+    tally["rep_slow_path"] += int(slow.size)
+    assert slow.size <= max(8, len(chk) // 50), f"{msg}: {slow.size} envs need the sampled comparison of their trajectory tables"
+    for e in slow:
+        assert_state_close(post[0][int(e)], hip[0][int(e)], f"{msg} env {int(e)}")
+    np.testing.assert_array_equal(i_g[chk], i_o[chk], err_msg=msg)
+    np.testing.assert_array_equal(d_g[chk], d_o[chk], err_msg=msg)
+    np.testing.assert_allclose(o_g[chk], o_o[chk], rtol=RTOL, atol=1e-6, err_msg=msg)
+    np.testing.assert_allclose(r_g[chk], r_o[chk], rtol=RTOL, atol=1e-6, err_msg=msg)
+    np.testing.assert_allclose(t_g[chk], O.term_obs[chk], rtol=RTOL, atol=1e-6, err_msg=msg)
+    tally["resets"] += int(d_o[chk].sum()); tally["contacts"] += int(no[chk].sum()); tally["unsafe"] += int((i_o[chk][:, 8] > 0).sum())
+    return post
+
+
+def _run(env, shield="SSM"):
+    import torch
+    import bench
+    import human_robot_gym_amd as hrg
+    from human_robot_gym_amd import mixed
+    from oracle.oracle import OracleBatch
+    W = bench.bench_workload(env, shield)
+    G, desc, mixed_tasks, staggered = bench.make_bench_batch(W)
+    n = W["n"]
+    assert n == (8192 if env == "PickPlaceHumanCart" else 4096)
+    pool = bench.bench_action_pool(n, G.device)
+    pre = bench.bench_preroll_steps(desc) + 20     # bench.py: pre-roll of one horizon (at most 1000 steps), then the default 20 warm-up steps
+    t0 = time.time()
+    for k in range(pre):
+        G.step(pool[k % len(pool)])
+    torch.cuda.synchronize()
+    t_roll = time.time() - t0
+    # the checker's batches: same model, same clips, same global env ids -- and from here on the HIP batch's own state
+    if mixed_tasks:
+        parts = [(eid, b, sl) for eid, b, sl in zip(G.env_ids, G.batches, G.slices)]
+        oracles = []
+        for (eid, kw), sl in zip(mixed.ICRA_TASKS, G.slices):
+            clips = mixed.task_clips(eid, 13)
+            d = hrg.build_model_desc(dict(mixed.task_env_kwargs(eid), **dict(kw, seed=1234)), n_clips=clips.n_clips, env_id=eid)
+            oracles.append(OracleBatch(d, clips, sl.stop - sl.start, env_id0=sl.start))
+    else:
+        parts = [(env, G, slice(0, n))]
+        clips = bench._bench_clips(env, 0)
+        oracles = [OracleBatch(hrg.build_model_desc(W["env_kwargs"], n_clips=clips.n_clips, env_id=env, **W["wrappers"]), clips, n, env_id0=0)]
+    for (eid, b, sl), O in zip(parts, oracles):
+        O.set_states_all(*_hip_states(b, _kinds(eid)))
+    tally = dict(violent=0, flicker=0, compared=0, total=0, rep_slow_path=0, resets=0, contacts=0, unsafe=0)
+    t0 = time.time()
+    for k in range(N_STEPS):
+        a = pool[(pre + k) % len(pool)]
+        G.step(a)
+        torch.cuda.synchronize()
+        a_np = a.cpu().numpy()
+        for (eid, b, sl), O in zip(parts, oracles):
+            post = _compare_part(eid, k, b, O, a_np[sl].copy(), _kinds(eid), tally)
+            _hip_set_states(b, _kinds(eid), *post)      # resynchronise: the next step starts from the oracle's state on both sides
+    live = tally["compared"] / tally["total"]
+    line = dict(test=f"test_bench_state_gpu::{env}_{shield}", n=n, preroll=pre, steps=N_STEPS, live=live, seconds_preroll=round(t_roll, 1), seconds_compare=round(time.time() - t0, 1), **tally)
+    print("[parity]", line)
+    try:
+        import json
+        out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_live.jsonl"), "a") as f:
+            f.write(json.dumps(line) + "\n")
+    except OSError:
+        pass
+    for O in oracles:
+        O.close()
+    G.close()
+    assert live >= 0.9, f"{env}: too many envs left the comparison: {tally}"
+    assert tally["resets"] > 0, "a steady-state batch ends episodes in every step"
+    return tally
+
+
+@pytest.mark.parametrize("shield", ["OFF", "SSM"])
+def test_reach_human_4096_steady_state_matches_oracle(shield):
+    """BASELINE configs[1] / [2]: ReachHuman, 4096 envs, shield OFF / SSM -- the headline's state, every env."""
+    t = _run("ReachHuman", shield)
+    if shield == "SSM":
+        assert t["unsafe"] > 0, "a steady-state SSM batch has envs under fail-safe manoeuvres"
+
+
+def test_pick_place_8192_steady_state_matches_oracle():
+    """BASELINE configs[3]: PickPlaceHumanCart, 8192 envs, SSM (the contact path)."""
+    t = _run("PickPlaceHumanCart")
+    assert t["contacts"] > 0
+
+
+def test_mixed_4096_steady_state_matches_oracle():
+    """BASELINE configs[4] on one GPU: the six ICRA tasks in one 4096-env batch, each task's rows against its own oracle batch."""
+    _run("mixed")

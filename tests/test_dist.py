@@ -111,3 +111,59 @@ def test_sharding_does_not_change_results_for_the_cube_tasks(env_id):
     for k in range(steps):
         for j in range(5):
             np.testing.assert_array_equal(np.concatenate([parts[0][k][j], parts[1][k][j]]), ref[k][j])
+
+
+# ---------------------------------------------------------------------------------------------- bench.py's own launcher (python bench.py --gpus N)
+_STUB = '''
+import json, os, sys, time
+rank = int(os.environ["RANK"])
+keys = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HSA_ENABLE_IPC_MODE_LEGACY")
+with open(os.path.join(sys.argv[1], f"rank{rank}.json"), "w") as f:
+    json.dump({k: os.environ.get(k) for k in keys} | {"argv": sys.argv[2:]}, f)
+mode = sys.argv[2]
+if mode == "fail" and rank == 1:
+    sys.exit(7)            # a rank that dies before the rendezvous
+if mode in ("fail", "hang"):
+    time.sleep(120)        # ... while its siblings wait for it
+print(json.dumps({"metric": "stub", "rank": rank}), flush=True)
+'''
+
+
+def _stub(tmp_path):
+    p = tmp_path / "stub_rank.py"
+    p.write_text(_STUB)
+    return str(p)
+
+
+def test_spawn_ranks_sets_the_launcher_environment_and_passes_rank0_stdout(tmp_path, capfd):
+    """The first real multi-GPU run must not die on plumbing: two children of a stub script see RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and of their
+    standard outputs only rank 0's (the one JSON line) reaches the parent's."""
+    import json
+    import bench
+    rc = bench.spawn_ranks(2, [str(tmp_path), "ok", "--steps", "3"], script=_stub(tmp_path))
+    assert rc == 0
+    out = capfd.readouterr().out.strip().splitlines()
+    assert [json.loads(l) for l in out] == [{"metric": "stub", "rank": 0}]
+    seen = [json.load(open(tmp_path / f"rank{r}.json")) for r in range(2)]
+    for r, d in enumerate(seen):
+        assert d["RANK"] == str(r) and d["LOCAL_RANK"] == str(r) and d["WORLD_SIZE"] == "2" and d["LOCAL_WORLD_SIZE"] == "2"
+        assert d["MASTER_ADDR"] == "127.0.0.1" and d["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and d["argv"] == ["ok", "--steps", "3"]
+    assert seen[0]["MASTER_PORT"] == seen[1]["MASTER_PORT"] and int(seen[0]["MASTER_PORT"]) > 0
+
+
+def test_spawn_ranks_stops_the_siblings_of_a_rank_that_fails(tmp_path):
+    """One of three ranks exits 7 while the others would sleep for two minutes (a sibling stuck in the rendezvous): the launcher returns that code promptly and
+    leaves no child behind."""
+    import time
+    import bench
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(3, [str(tmp_path), "fail"], script=_stub(tmp_path))
+    assert rc == 7 and time.monotonic() - t0 < 30
+
+
+def test_spawn_ranks_has_a_deadline(tmp_path):
+    import time
+    import bench
+    t0 = time.monotonic()
+    rc = bench.spawn_ranks(2, [str(tmp_path), "hang"], script=_stub(tmp_path), deadline_s=1.0)
+    assert rc == 124 and time.monotonic() - t0 < 30

@@ -217,3 +217,22 @@ def test_every_observation_key_of_the_reference_configs_is_served():
     for k in used:
         cols = list(OBS_COLUMNS[k])
         assert cols and all(0 <= c < od for c in cols) and len(set(cols)) == len(cols), k
+
+
+def test_monitor_rows_do_not_depend_on_the_info_dicts(tmp_path):
+    """SB3's Monitor writes one r,l,t row per finished episode whatever the caller does with the info dicts: with info_dicts=False (the fast path) the rows are the
+    same as with them."""
+    import os
+    rows = {}
+    for flag in (True, False):
+        d = tmp_path / f"m{int(flag)}"
+        env = _vec(6, dict(shield_type="OFF", horizon=5, seed=2), info_dicts=flag, monitor_dir=str(d), monitor_kwargs=dict(info_keywords=("n_goal_reached", "timeout")))
+        env.reset()
+        rng = np.random.RandomState(0)
+        for _ in range(11):
+            env.step(rng.uniform(-1, 1, (6, 7)))
+        env.close()
+        lines = open(os.path.join(str(d), "hip_batch_0.monitor.csv")).read().splitlines()
+        assert lines[1] == "r,l,t,n_goal_reached,timeout"
+        rows[flag] = [l.split(",")[:2] + l.split(",")[3:] for l in lines[2:]]   # (without the wall-clock column)
+    assert len(rows[True]) >= 12 and rows[True] == rows[False]
