@@ -67,7 +67,9 @@
 #ifndef HRG_MIN_WAVES
 #define HRG_MIN_WAVES 4
 #endif
+#ifndef HRG_PHASE   // (tools/regs.py builds the phases as real functions to read their register needs one by one)
 #define HRG_PHASE __device__ __forceinline__
+#endif
 #define PH_DYNTERMS HRG_PHASE
 #define PH_HUMAN HRG_PHASE
 #define PH_SHIELD HRG_PHASE
@@ -192,6 +194,8 @@ struct Lds {
   double nail_org[3], nail_axis[3];      // nail_head body origin and the slide axis, world
   double Mb[64], fb[8];                  // mass matrix (8 x 8, pad DoF with a unit diagonal) and applied force of the board + nail subtree
   double Ihw[9], tauh[3];                // the hammer's world-frame rotational inertia and gyroscopic torque
+  double nsG[(9 + 2 * NCON_DYN) * (10 + 2 * NCON_DYN) / 2];   // noslip pass: Gram matrix of its items (9 friction-loss rows + 2 pairs per contact), packed lower triangle
+  double nsC[9 + 2 * NCON_DYN][3];                            // ... per item: 1 / curvature, bound, curvature
   Contact con[NCON_DYN];
 #elif HRG_STACK
   hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)
@@ -208,8 +212,8 @@ struct Lds {
       double rc[HRG_NSHIELD_RCAP][7];
       hrg_ltt cand;
     };
-    struct {  // robot_dynamics_terms
-      double com[NV][3], Iw[NV][6], cI[NV][10], F[NV][6], aw[NV][3], av[NV][3], fn[NV][3], ff[NV][3];
+    struct {  // robot_dynamics_terms: composite inertia of the subtree of body j applied to its joint axis (body lanes -> mass-matrix lanes)
+      double F[NV][6];
     };
     struct {  // human_control + collide + classify (the dynamics step's rows take this space afterwards)
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
@@ -277,6 +281,19 @@ DI ModelPtr uniform_model(const DevModel* dm) {
 }
 
 // ------------------------------------------------------------------------------------------------ math
+// sqrt without the denormal-range scaling and the IEEE fix-ups of the generic lowering (20 instructions): v_rsq_f64, one Goldschmidt step and two residual
+// corrections -- the same iteration, for arguments that are lengths, norms and discriminants of this model (never denormal; zero is handled).  Within an ulp
+// or two of the correctly rounded root; the oracle's sqrt is IEEE, the parity tolerance (1e-5 relative) is eleven orders above the difference.
+DI double fsqrt(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g);
+  h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  g = __builtin_fma(__builtin_fma(-g, g, x), h, g);
+  return x > 0 ? g : 0.0;
+}
 // read-only operands are templated on the pointer type so that LDS / constant / private operands keep their address space
 DI void v3set(double* r, double a, double b, double c) { r[0] = a; r[1] = b; r[2] = c; }
 template <class PA>
@@ -292,7 +309,7 @@ DI void v3madd(double* r, PA a, PB b, double s) { r[0] = a[0] + b[0] * s; r[1] =
 template <class PA, class PB>
 DI double v3dot(PA a, PB b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
 template <class PA>
-DI double v3norm(PA a) { return sqrt(v3dot(a, a)); }
+DI double v3norm(PA a) { return fsqrt(v3dot(a, a)); }
 template <class PA, class PB>
 DI void v3cross(double* r, PA a, PB b) {
   double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
@@ -419,7 +436,7 @@ DI double rng_u01(uint64_t seed, uint64_t env, uint64_t episode, uint64_t stream
 enum { STREAM_NOISE = 0, STREAM_HUMAN = 1, STREAM_ANIM = 2, STREAM_GOAL = 3, STREAM_ACTION = 4, STREAM_OBJECT = 5, STREAM_TARGET = 6, STREAM_LOOP = 7 };
 DI double rng_gauss(uint64_t seed, uint64_t env, uint64_t ep, uint64_t stream, uint64_t idx) {
   double u1 = rng_u01(seed, env, ep, stream, 2 * idx), u2 = rng_u01(seed, env, ep, stream, 2 * idx + 1);
-  return sqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);
+  return fsqrt(-2.0 * log(1.0 - u1)) * cos(2.0 * HRG_PI * u2);
 }
 
 // ------------------------------------------------------------------------------------------------ segments
@@ -524,12 +541,12 @@ DI bool cap_box_two(PA p1, PB p2, PC c, PR R, const double* hb, double r, const 
     }
   }
   if (!ok || !(hi > lo)) return false;
-  if ((hi - lo) * sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 1e-3) return false;
+  if ((hi - lo) * fsqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2]) < 1e-3) return false;
   for (int e = 0; e < 2; e++) {
     const double t = e ? hi : lo;
     double x[3], y[3], e2 = 0;
     for (int k = 0; k < 3; k++) { x[k] = a[k] + t * d[k]; y[k] = clampd(x[k], -hb[k], hb[k]); e2 += (x[k] - y[k]) * (x[k] - y[k]); }
-    const double dd = sqrt(e2);
+    const double dd = fsqrt(e2);
     if (!(dd - r < 0) || !(dd > 1e-9)) return false;
     if (e == which)
       for (int k = 0; k < 3; k++) {
@@ -545,7 +562,7 @@ DI bool cap_box_two(PA p1, PB p2, PC c, PR R, const double* hb, double r, const 
 // ------------------------------------------------------------------------------------------------ profiles
 DI double scurve_time(double dv, double amax, double jmax) {
   double ad = fabs(dv);
-  return ad >= amax * amax / jmax ? ad / amax + amax / jmax : 2 * sqrt(ad / jmax);
+  return ad >= amax * amax / jmax ? ad / amax + amax / jmax : 2 * fsqrt(ad / jmax);
 }
 DI double dist_nocruise(double va, double vc, double amax, double jmax) {
   return 0.5 * (va + vc) * scurve_time(vc - va, amax, jmax) + 0.5 * vc * scurve_time(vc, amax, jmax);
@@ -556,7 +573,7 @@ DI void scurve(double va, double vb, double amax, double jmax, double* dur, doub
     double tj = amax / jmax;
     dur[0] = tj; dur[1] = ad / amax - tj; dur[2] = tj;
   } else {
-    double tj = sqrt(ad / jmax);
+    double tj = fsqrt(ad / jmax);
     dur[0] = tj; dur[1] = 0; dur[2] = tj;
   }
   jerk[0] = sg * jmax; jerk[1] = 0; jerk[2] = -sg * jmax;
@@ -598,7 +615,7 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
     double lo = w_lo, hi = w_hi;
     const double vtri = amax * amax / jmax;
     const double De = Dm + 0.5 * vm * scurve_time(vm, amax, jmax);
-    w = 0.5 * (sqrt(vtri * vtri + 4.0 * amax * De) - vtri);
+    w = 0.5 * (fsqrt(vtri * vtri + 4.0 * amax * De) - vtri);
     if (!(w > lo)) w = lo;
     if (!(w < hi)) w = hi;
     for (int it = 0; it < 80; it++) {
@@ -606,8 +623,8 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
       const double f = 0.5 * (vm + w) * T1 + 0.5 * w * T2 - Dm;
       if (f == 0) break;
       if (f < 0) lo = w; else hi = w;
-      const double T1p = fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / sqrt(jmax * fabs(d1)) : 0.0);
-      const double T2p = fabs(w) >= vtri ? 1.0 / amax : (fabs(w) > 0 ? 1.0 / sqrt(jmax * fabs(w)) : 0.0);
+      const double T1p = fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / fsqrt(jmax * fabs(d1)) : 0.0);
+      const double T2p = fabs(w) >= vtri ? 1.0 / amax : (fabs(w) > 0 ? 1.0 / fsqrt(jmax * fabs(w)) : 0.0);
       const double fp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
       double nw = fp > 0 ? w - f / fp : 0.5 * (lo + hi);
       if (!(nw >= lo && nw <= hi)) nw = 0.5 * (lo + hi);
@@ -768,6 +785,23 @@ DI double chain_prefix(double x, int lane) {
   y += dpp_f64<0x112, 0xf>(y);  // row_shr:2
   y += dpp_f64<0x114, 0xf>(y);  // row_shr:4
   return lane < NARM ? y : y + x;
+}
+// sum over the subtree of body i = lane i of the robot's kinematic tree: bodies i..7 for the arm links 0..5 (the fingers 6, 7 hang off link 5), the body itself for
+// a finger.  DPP row shifts to the left inside row 0; lanes 8..15 contribute 0.
+DI double subtree_sum(double x, int lane) {
+  double y = lane < NV ? x : 0.0;
+  y += dpp_f64<0x101, 0xf>(y);  // row_shl:1
+  y += dpp_f64<0x102, 0xf>(y);  // row_shl:2
+  y += dpp_f64<0x104, 0xf>(y);  // row_shl:4
+  return lane < NARM ? y : x;
+}
+// a wave-uniform double that arrived in a vector register (loaded from the LDS image, computed from such loads): moved to a scalar register pair.  A value that
+// lives across a register-hungry stretch then costs two SGPRs (spilled, if need be, to one lane of a VGPR) instead of two VGPRs of the 128.
+DI double uniform_f64(double v) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readfirstlane((int)(b & 0xffffffffLL));
+  const int hi = __builtin_amdgcn_readfirstlane((int)(b >> 32));
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 // a value of lane K (compile-time) in every lane: two v_readlane into SGPRs instead of an LDS-crossbar shuffle
 template <int K>

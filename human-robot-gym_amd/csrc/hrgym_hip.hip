@@ -24,12 +24,9 @@ DI void impedance(const MD& m, double x0, double* imp) {  // the stiffness / dam
   double y;
   if (x >= 1) y = 1;
   else if (x <= 0) y = 0;
-  else if (power == 2.0) { // MuJoCo's default solimp power: the square, not a libm call
-    if (x <= mid) { const double u = x / mid; y = u * u * mid; }
-    else { const double u = (1 - x) / (1 - mid); y = 1 - u * u * (1 - mid); }
-  }
-  else if (x <= mid) y = pow(x / mid, power) * mid;
-  else y = 1 - pow((1 - x) / (1 - mid), power) * (1 - mid);
+  else if (x <= mid) { const double u = x / mid; y = u * u * mid; }   // solimp power 2 (MuJoCo's default; hrg_batch_create refuses another): the square -- a pow() in
+  else { const double u = (1 - x) / (1 - mid); y = 1 - u * u * (1 - mid); }   // this spot put ~300 instructions and the spills around them into every step kernel
+  (void)power;
   *imp = d0 + y * (dmax - d0);
 }
 
@@ -147,7 +144,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
           double qe[4];
           quatmul(qe, qo, qc);
           if (qe[0] < 0) for (int z = 0; z < 4; z++) qe[z] = -qe[z];
-          const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+          const double sn = fsqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
           pos = sn > 1e-12 ? qe[1 + (a - 3)] / sn * ang : 0.0;
         }
         cand = true; w.type = 2; w.kind = 1;
@@ -327,7 +324,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       {
         const double gl = lane < NVS ? L.g[lane] : 0.0, ml = lane < NVS ? L.Ma0[lane] : 0.0;
         const double gn = wave_sum(gl * gl), sc = wave_sum(ml * ml);
-        if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+        if (fsqrt(gn) <= m.solver_tol * (1.0 + fsqrt(sc))) break;
       }
       STAMP(27);
       // ---- Newton Hessian: M + sum_r h_r J_r' J_r ----
@@ -519,13 +516,13 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     wave_sync();
     if (lane < NCUBE) {
       const double w0 = sk.vel[lane][3], w1 = sk.vel[lane][4], w2 = sk.vel[lane][5];
-      const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+      const double wn = fsqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
       if (wn > 1e-12) {
         const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
         const double qo[4] = {sk.quat[lane][0], sk.quat[lane][1], sk.quat[lane][2], sk.quat[lane][3]};
         double qn[4];
         quatmul(qn, dq, qo);
-        const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        const double nn = fsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
         for (int z = 0; z < 4; z++) sk.quat[lane][z] = qn[z] / nn;
       }
     }
@@ -689,7 +686,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         const double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
         quatmul(qe, qo, qc);
         if (qe[0] < 0) for (int z = 0; z < 4; z++) qe[z] = -qe[z];
-        const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+        const double sn = fsqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
         pos = sn > 1e-12 ? qe[1 + a] / sn * ang : 0.0;
         Jr[HM_OB + 3 + a] = 1.0;
         vel = hm.vel[0][3 + a];
@@ -846,7 +843,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     {
       const double gl = lane < NVS ? L.g[lane] : 0.0, ml = lane < NVS ? L.Ma0[lane] : 0.0;
       const double gn = wave_sum(gl * gl), sc = wave_sum(ml * ml);
-      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      if (fsqrt(gn) <= m.solver_tol * (1.0 + fsqrt(sc))) break;
     }
     STAMP(27);
     // ---- Newton Hessian M + sum_r h_r J_r' J_r as 3 x 3 tiles in registers ----
@@ -947,6 +944,138 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       if (R[k].active) moved = moved || row_zone(R[k].type, R[k].flim, R[k].y) != row_zone(R[k].type, R[k].flim, R[k].y + R[k].p);
     if (al == 1.0 && !__any(moved)) break;
   }
+  STAMP(28);
+  // ---- MuJoCo's noslip post-pass (mj_solNoSlip [UPSTREAM]; collaborative_hammering_cartesian_env.py:1161: noslip_iterations = 20), restated as in oracle/hrg_oracle.c
+  // noslip(): projected Gauss-Seidel sweeps over the friction dimensions only -- the nine friction-loss rows, then each contact's two pairs of opposing pyramid edges
+  // (a pair keeps the sum of its two forces and moves along (1, -1)) -- without the constraint regularisation, every other force held.  The sweeps are sequential by
+  // definition and there are up to 20 of them over up to 49 items, so an item must be cheap: the pass runs in the space of its own unknowns z (item j = lane j: a
+  // friction force or a pair's half difference y).  Once per substep the items' Gram matrix G = U M^-1 U' (U = unit rows / J0 - J1 of a pair) goes to LDS (packed
+  // lower triangle) and every lane takes its item's residual res_j = U_j a - aref_j; an item's update is then  z_i <- clamp(z_i - res_i / G_ii),  res_j += G_ij dz
+  // for all lanes -- broadcasts of lane i's registers and one LDS read, no reduction, no barrier.  The changed forces go back into a = L.qacc at the end.
+  if (m.noslip_iterations > 0) {
+    constexpr int NI0 = HROW_NFRIC + 1;                    // items 0..8: friction loss of the robot tree's joints and of the nail's slide joint
+    const int npair = 2 * nc, nitem = NI0 + npair;         // items 9 + p: pair p = rows 2p, 2p + 1 of the contact block
+    auto tri = [](int i, int j) -> int { return i * (i + 1) / 2 + j; };   // i >= j
+    double Mhinv = 0.0;   // entry (mi, mj) of the hammer block's inverse: 1/m | R diag(1/I) R' | unit pads
+    if (mi < 3 && mj < 3) Mhinv = mi == mj ? 1.0 / m.hm_hammer_mass : 0.0;
+    else if (mi >= 3 && mi < 6 && mj >= 3 && mj < 6) { for (int k = 0; k < 3; k++) Mhinv += L.gR[1][3 * (mi - 3) + k] * L.gR[1][3 * (mj - 3) + k] / m.hm_hammer_inertia[k]; }
+    else if (mi == mj && mi >= 6) Mhinv = 1.0;
+    double fsum = 0, f_own = 0;
+#pragma unroll
+    for (int k = 0; k < 2; k++) {   // forces of the primal solution: f = -s'(J a - aref)
+      const int r = lane + 64 * k;
+      double c_, g_ = 0, h_;
+      if (R[k].active) row_cost(R[k].type, R[k].D, R[k].floss, R[k].flim, rowdot(R[k], L.qacc) - R[k].aref, &c_, &g_, &h_);
+      L.rg[r] = -g_;
+      if (k == 0) f_own = -g_;
+      if (R[k].active) fsum += 0.5 * g_ * g_ / R[k].D;
+    }
+    const uint64_t act0 = __ballot(R[0].active), act1 = __ballot(R[1].active);
+    auto row_active = [&](int r) -> bool { return r < 64 ? ((act0 >> r) & 1ull) != 0 : ((act1 >> (r - 64)) & 1ull) != 0; };
+#pragma unroll
+    for (int k = 0; k < 2; k++) { const int r = lane + 64 * k; if (r >= HROW_CON0 && r < HROW_CON0 + 4 * NCON_DYN) L.Jc[r - HROW_CON0][NVS] = R[k].aref; }
+    const double imp0 = wave_sum(fsum);   // the first sweep also counts the removed regularisation cost, sum 1/2 R f^2
+    wave_sync();
+    // row 2p + 1 of a pair <- J0 - J1 (and aref0 - aref1 in the pad column): the rows themselves are not needed again
+    if (lane <= NVS)
+      for (int p = 0; p < npair; p++) L.Jc[2 * p + 1][lane] = L.Jc[2 * p][lane] - L.Jc[2 * p + 1][lane];
+    wave_sync();
+    // ---- this lane's item ----
+    bool item = false;
+    double z = 0, bnd = 0, res = 0;
+    if (lane < NI0) {
+      item = R[0].active;
+      const int dof = lane == HROW_NFRIC ? HM_ON : lane;
+      z = f_own; bnd = R[0].floss; res = L.qacc[dof] - R[0].aref;
+    } else if (lane < nitem) {
+      const int p = lane - NI0;
+      item = row_active(HROW_CON0 + 2 * p) && row_active(HROW_CON0 + 2 * p + 1);
+      const double f0 = L.rg[HROW_CON0 + 2 * p], f1 = L.rg[HROW_CON0 + 2 * p + 1];
+      const double* dJ = L.Jc[2 * p + 1];
+      z = 0.5 * (f0 - f1); bnd = 0.5 * (f0 + f1);
+      if (bnd < 0) bnd = 0;
+      double t = -dJ[NVS];
+      for (int k = 0; k < NVS; k++) t += dJ[k] * L.qacc[k];
+      res = t;
+    }
+    const double z0 = z;
+    const uint64_t imask = __ballot(item);
+    // ---- Gram matrix: friction x friction from the block inverses in registers ... ----
+    if (mj <= mi) L.nsG[tri(mi, mj)] = Minv;                                   // items 0..7 = robot DoF 0..7
+    if (lane < NI0) L.nsG[tri(HROW_NFRIC, lane)] = lane == HROW_NFRIC ? lane_value<6 * 9>(Mbinv) : 0.0;   // the nail's row: another block of M
+    if (lane == HROW_NFRIC) L.nsG[tri(HROW_NFRIC, HROW_NFRIC)] = lane_value<6 * 9>(Mbinv);
+    // ... and one row per pair: w = M^-1 (J0 - J1)' through L.d, then lanes = items take their entry
+#pragma unroll 1
+    for (int p = 0; p < npair; p++) {
+      if (!((imask >> (NI0 + p)) & 1ull)) continue;
+      const double* dJ = L.Jc[2 * p + 1];
+      const double t0 = row8_sum(Minv * dJ[mj]), t1 = row8_sum(Mbinv * dJ[8 + mj]), t2 = row8_sum(Mhinv * dJ[16 + mj]);
+      wave_sync();
+      if (mj == 0) { L.d[mi] = t0; L.d[8 + mi] = t1; L.d[16 + mi] = t2; }
+      wave_sync();
+      if (lane <= NI0 + p) {
+        double g_;
+        if (lane < NI0) g_ = L.d[lane == HROW_NFRIC ? HM_ON : lane];
+        else {
+          const double* dQ = L.Jc[2 * (lane - NI0) + 1];
+          g_ = 0;
+          for (int k = 0; k < NVS; k++) g_ += dQ[k] * L.d[k];
+        }
+        L.nsG[tri(NI0 + p, lane)] = g_;
+      }
+    }
+    wave_sync();
+    // per item: curvature, its reciprocal and the bound, read back by every lane at a uniform LDS address while the previous item is still being worked on.  A
+    // pair without curvature (both edges then go to the mean) is a zero bound with a zero step.
+    double Gjj = lane < nitem ? L.nsG[tri(lane, lane)] : 0.0;
+    {
+      const bool flat = lane >= NI0 && !(Gjj >= 1e-15);
+      const double inv = flat ? 0.0 : 1.0 / (Gjj > 1e-15 ? Gjj : 1e-15);
+      if (lane < nitem) { L.nsC[lane][0] = inv; L.nsC[lane][1] = flat ? 0.0 : bnd; L.nsC[lane][2] = Gjj; }
+    }
+    wave_sync();
+    const int tri_lane = lane * (lane + 1) / 2;
+#pragma unroll 1
+    for (int it = 0; it < m.noslip_iterations; it++) {
+      COUNT(30, 1);   // noslip sweeps
+      double imp = it == 0 ? imp0 : 0.0;
+#pragma unroll 1
+      for (int i = 0; i < nitem; i++) {
+        if (!((imask >> i) & 1ull)) continue;
+        const int tri_i = i * (i + 1) / 2;
+        const double gij = item ? L.nsG[lane <= i ? tri_i + lane : tri_lane + i] : 0.0;
+        const double invi = L.nsC[i][0], bi = L.nsC[i][1], Gii = L.nsC[i][2];
+        const double ri = lane_value_dyn(res, i), zi = lane_value_dyn(z, i);
+        const double zn = fmin(fmax(zi - ri * invi, -bi), bi);
+        const double dl = zn - zi;
+        z = lane == i ? zn : z;
+        res += gij * dl;
+        imp -= dl * (ri + 0.5 * Gii * dl);
+      }
+      if (imp * m.noslip_scale < m.noslip_tolerance) break;
+    }
+    // ---- the changed forces back into the acceleration: a += M^-1 U' dz ----
+    const double dz = item ? z - z0 : 0.0;
+    double u = 0;
+    if (lane < NV) u = dz;                                            // item r = friction row of robot DoF r = lane r
+    const double dz_nail = lane_value<HROW_NFRIC>(dz);
+    if (lane == HM_ON) u = dz_nail;
+    for (uint64_t mm = imask >> NI0; mm;) {
+      const int p = __ffsll((long long)mm) - 1;
+      mm &= mm - 1;
+      const double dzp = lane_value_dyn(dz, NI0 + p);
+      if (lane < NVS) u += L.Jc[2 * p + 1][lane] * dzp;
+    }
+    wave_sync();
+    if (lane < NVS) L.d[lane] = u;
+    wave_sync();
+    {
+      const double t0 = row8_sum(Minv * L.d[mj]), t1 = row8_sum(Mbinv * L.d[8 + mj]), t2 = row8_sum(Mhinv * L.d[16 + mj]);
+      if (mj == 0) { L.qacc[mi] += t0; L.qacc[8 + mi] += t1; L.qacc[16 + mi] += t2; }
+    }
+    wave_sync();
+  }
+  STAMP(29);
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping for the robot tree
@@ -983,13 +1112,13 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     wave_sync();
     if (lane < 2) {
       const double w0 = hm.vel[lane][3], w1 = hm.vel[lane][4], w2 = hm.vel[lane][5];
-      const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+      const double wn = fsqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
       if (wn > 1e-12) {
         const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
         const double qo[4] = {hm.quat[lane][0], hm.quat[lane][1], hm.quat[lane][2], hm.quat[lane][3]};
         double qn[4];
         quatmul(qn, dq, qo);
-        const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+        const double nn = fsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
         for (int z = 0; z < 4; z++) hm.quat[lane][z] = qn[z] / nn;
       }
     }
@@ -1161,7 +1290,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       const double qc[4] = {qt[0], -qt[1], -qt[2], -qt[3]};
       quatmul(qe, qo, qc);
       if (qe[0] < 0) for (int k = 0; k < 4; k++) qe[k] = -qe[k];
-      const double sn = sqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
+      const double sn = fsqrt(qe[1] * qe[1] + qe[2] * qe[2] + qe[3] * qe[3]), ang = 2.0 * atan2(sn, qe[0]);
       pos = sn > 1e-12 ? qe[1 + (a - 3)] / sn * ang : 0.0;
     }
     cand = true; type = 2; rpart = false;
@@ -1281,7 +1410,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       double gn = 0, sc = 0;
 #pragma unroll
       for (int i = 0; i < NVT; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
-      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      if (fsqrt(gn) <= m.solver_tol * (1.0 + fsqrt(sc))) break;
       if (!coupled) {
         // robot block (as in the ReachHuman solver) and cube block (6x6 padded to 8x8 with a unit diagonal), lanes = (mi, mj)
         double hval = Mij;
@@ -1378,7 +1507,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       double gn = 0, sc = 0;
 #pragma unroll
       for (int i = 0; i < NV; i++) { gn += L.g[i] * L.g[i]; sc += L.Ma0[i] * L.Ma0[i]; }
-      if (sqrt(gn) <= m.solver_tol * (1.0 + sqrt(sc))) break;
+      if (fsqrt(gn) <= m.solver_tol * (1.0 + fsqrt(sc))) break;
       COUNT(18, (__any(hh != 0) || !h_is_m) ? 1 : 0);  // Hessian factorizations
       if (__any(hh != 0) || !h_is_m) {  // a row has curvature: invert the Hessian (until then H == M, whose inverse is already held)
         Minv = spd_inverse1(hval, lane, &ok);
@@ -1454,12 +1583,12 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
     }
     if (lane < 3) { const double p0 = bx.pos[lane]; bx.obs_pos[lane] = p0; bx.pos[lane] = p0 + h * vnew; }  // obs_pos: body_xpos of the forward pass inside mj_step
     const double w0 = __shfl(vnew, 3, 64), w1 = __shfl(vnew, 4, 64), w2 = __shfl(vnew, 5, 64);
-    const double wn = sqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
+    const double wn = fsqrt(w0 * w0 + w1 * w1 + w2 * w2), ang = h * wn;
     if (wn > 1e-12) {
       const double sh = sin(0.5 * ang) / wn, dq[4] = {cos(0.5 * ang), w0 * sh, w1 * sh, w2 * sh};
       double qo[4] = {bx.quat[0], bx.quat[1], bx.quat[2], bx.quat[3]}, qn[4];
       quatmul(qn, dq, qo);
-      const double nn = sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+      const double nn = fsqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
       wave_sync();
       if (lane < 4) bx.quat[lane] = qn[lane] / nn;
     }
@@ -1509,12 +1638,12 @@ DI bool config_collides(const DevModel* __restrict__ dm_, int lane) {
     const double r = c == NCAP_CHECK - 1 ? m.scap_r[HRG_NSHIELD_RCAP - 1] : m.rcap_r[c], mg = m.obstacle_margin;
     if (p[2] - r < m.table_top_z + mg && fabs(p[0]) <= m.table_half[0] + 0.5 * mg + r && fabs(p[1]) <= m.table_half[1] + 0.5 * mg + r) hit = true;
     const double dx = p[0] - m.base_pos[0], dy = p[1] - m.base_pos[1];
-    if (p[2] - r < m.base_cyl_z && sqrt(dx * dx + dy * dy) < m.base_cyl_r + mg + r) hit = true;
+    if (p[2] - r < m.base_cyl_z && fsqrt(dx * dx + dy * dy) < m.base_cyl_r + mg + r) hit = true;
   } else if (lane >= 16 && lane - 16 < dm->n_chk) {
     const int i = dm->chk_i[lane - 16], j = dm->chk_j[lane - 16];
     double x1[3], x2[3];
     const double rj = j == NCAP_CHECK - 1 ? m.scap_r[HRG_NSHIELD_RCAP - 1] : m.rcap_r[j];
-    if (sqrt(seg_seg(cc + 6 * i, cc + 6 * i + 3, cc + 6 * j, cc + 6 * j + 3, x1, x2)) - m.rcap_r[i] - rj < m.self_collision_safety) hit = true;
+    if (fsqrt(seg_seg(cc + 6 * i, cc + 6 * i + 3, cc + 6 * j, cc + 6 * j + 3, x1, x2)) - m.rcap_r[i] - rj < m.self_collision_safety) hit = true;
   }
   const bool any = __any(hit);
   wave_sync();
@@ -1562,7 +1691,7 @@ DI void action_goal(ModelPtr dm, int lane, const double* act) {
 // Damped least squares on [position; orientation] of the end-effector link (orientation held at the initial one).  Lane 0 runs
 // the chain kinematics, lanes = joints build the Jacobian columns, lanes = (i, j) build and factor J J' + lambda^2 I (6x6 padded
 // into the 8x8 lane Cholesky), lanes = joints apply the step.  Scratch: the shield's part of the LDS union (idle here).
-DI void ik_action(const DevModel* __restrict__ dm_, int lane) {
+__device__ __noinline__ void ik_action(const DevModel* __restrict__ dm_, int lane) {   // a real function: its atan2 and its 6 x 6 factorisation stay out of the step kernel's register allocation (they cost it 19 spill stores per step, used or not)
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -1606,7 +1735,7 @@ DI void ik_action(const DevModel* __restrict__ dm_, int lane) {
     }
     const double dl = lane < 3 ? target - pee[lane] : 0.0;
     const double d0 = __shfl(dl, 0, 64), d1 = __shfl(dl, 1, 64), d2 = __shfl(dl, 2, 64);
-    if (it > 0 && sqrt(d0 * d0 + d1 * d1 + d2 * d2) <= m.ik_residual_threshold) break;
+    if (it > 0 && fsqrt(d0 * d0 + d1 * d1 + d2 * d2) <= m.ik_residual_threshold) break;
     if (it >= m.ik_max_iter) break;
     if (lane == 0) {  // error vector: position, rotation vector of R_target R6'
       double E[9], v[3];
@@ -1654,7 +1783,7 @@ DI void ik_action(const DevModel* __restrict__ dm_, int lane) {
 }
 
 // CollisionPreventionWrapper.action (wrappers/collision_prevention_wrapper.py:46-103) on L.act
-DI void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
+__device__ __noinline__ void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {   // (a real function, like ik_action)
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -1693,10 +1822,10 @@ DI void screen_action(const DevModel* __restrict__ dm_, int lane, int64_t gid) {
 // rotation matrix (row-major) -> unit quaternion (w, x, y, z), largest-component branch
 DI void mat2quat(double* q, const double* R) {
   const double tr = R[0] + R[4] + R[8];
-  if (tr > 0) { const double s_ = sqrt(tr + 1.0) * 2; q[0] = 0.25 * s_; q[1] = (R[7] - R[5]) / s_; q[2] = (R[2] - R[6]) / s_; q[3] = (R[3] - R[1]) / s_; }
-  else if (R[0] > R[4] && R[0] > R[8]) { const double s_ = sqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s_; q[1] = 0.25 * s_; q[2] = (R[1] + R[3]) / s_; q[3] = (R[2] + R[6]) / s_; }
-  else if (R[4] > R[8]) { const double s_ = sqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s_; q[1] = (R[1] + R[3]) / s_; q[2] = 0.25 * s_; q[3] = (R[5] + R[7]) / s_; }
-  else { const double s_ = sqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s_; q[1] = (R[2] + R[6]) / s_; q[2] = (R[5] + R[7]) / s_; q[3] = 0.25 * s_; }
+  if (tr > 0) { const double s_ = fsqrt(tr + 1.0) * 2; q[0] = 0.25 * s_; q[1] = (R[7] - R[5]) / s_; q[2] = (R[2] - R[6]) / s_; q[3] = (R[3] - R[1]) / s_; }
+  else if (R[0] > R[4] && R[0] > R[8]) { const double s_ = fsqrt(1.0 + R[0] - R[4] - R[8]) * 2; q[0] = (R[7] - R[5]) / s_; q[1] = 0.25 * s_; q[2] = (R[1] + R[3]) / s_; q[3] = (R[2] + R[6]) / s_; }
+  else if (R[4] > R[8]) { const double s_ = fsqrt(1.0 + R[4] - R[0] - R[8]) * 2; q[0] = (R[2] - R[6]) / s_; q[1] = (R[1] + R[3]) / s_; q[2] = 0.25 * s_; q[3] = (R[5] + R[7]) / s_; }
+  else { const double s_ = fsqrt(1.0 + R[8] - R[0] - R[4]) * 2; q[0] = (R[3] - R[1]) / s_; q[1] = (R[2] + R[6]) / s_; q[2] = (R[5] + R[7]) / s_; q[3] = 0.25 * s_; }
 }
 #endif
 // observation: object-state (vec/dist eef -> L hand, R hand, head; human_env.py:1536-1590) + goal_difference
@@ -1990,7 +2119,8 @@ DI void lifting_place_board(const DevModel* __restrict__ dm_, int lane) {
 
 // HumanEnv._reset_internal (human_env.py:1604-1673) + ReachHuman._reset_internal (reach_human_env.py:509-523)
 // + FailsafeController.reset (failsafe_controller.py:204-250)
-HRG_PHASE void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid, float* obs_out) {
+// (a real function: an episode ends once in ~100 steps; its draws -- log, cos -- and goal sampling stay out of the step kernel's register allocation)
+__device__ __noinline__ void env_reset(const DevModel* __restrict__ dm_, int lane, int64_t gid, float* obs_out) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
   const auto& m = dm->m;
@@ -2328,7 +2458,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
   if (lane < NV) L.act[lane] = lane < HRG_ACT_DIM ? action[lane] : 0.0;
   wave_sync();
   if (m.ik_enabled) ik_action(dm_, lane);  // IKPositionDeltaWrapper is the outermost action wrapper (utils/training_utils.py:358-373)
-  screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
+  if (m.cp_enabled) screen_action(dm_, lane, gid);  // CollisionPreventionWrapper.step wraps env.step: uses the pre-step state
 #if HRG_LIFT
   if (m.task == HRG_TASK_LIFTING) { wave_sync(); if (lane == 0) L.act[NARM] = 1.0; wave_sync(); }   // CollaborativeLiftingCart.step (368-391): the gripper action is replaced by 'close'
 #endif
@@ -2408,7 +2538,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
   hrg_box_state& bx = L.bx;
   double e2o = 0, o2t = 0;
   for (int a = 0; a < 3; a++) { e2o += (bx.obs_pos[a] - s.eef_pos[a]) * (bx.obs_pos[a] - s.eef_pos[a]); o2t += (bx.target[a] - bx.obs_pos[a]) * (bx.target[a] - bx.obs_pos[a]); }
-  const int in_zone = sqrt(o2t) <= m.goal_dist;
+  const int in_zone = fsqrt(o2t) <= m.goal_dist;
   // HumanObjectInspectionCart: success = the inspection animation ran to its end (human_object_inspection_cartesian_env.py:553-600)
   const int inspection = m.task == HRG_TASK_INSPECTION || m.task == HRG_TASK_HANDOVER_H2R;   // success = the task's animation ran to its end
   int goal_reached = !crash && (m.task == HRG_TASK_HANDOVER_R2H ? bx.task_phase == HRG_R2H_COMPLETE : ((inspection || m.task == HRG_TASK_LIFTING) ? bx.task_phase == HRG_PHASE_COMPLETE : in_zone));
@@ -2418,7 +2548,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
   if (m.task == HRG_TASK_REACH_BOX) {   // ReachHuman with its smallBox: the task logic of ReachHuman (reach_human_env.py:437-475; human_env.py:666-691)
     double dist2 = 0;
     for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
-    reach_dist = sqrt(dist2);
+    reach_dist = fsqrt(dist2);
     goal_reached = !crash && reach_dist <= m.goal_dist;
     r = goal_reached ? m.task_reward : -1.0;
   }
@@ -2427,7 +2557,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
   if (m.task == HRG_TASK_HANDOVER_R2H)   // robot_human_handover_cartesian_env.py:507-555
     r = goal_reached ? m.task_reward : (bx.task_phase == HRG_R2H_RETREAT ? m.object_in_human_hand_reward : (bx.gripped ? m.object_gripped_reward : -1.0));
 #endif
-  double dense = -(sqrt(e2o) * 0.2 + sqrt(o2t)) * 0.1;
+  double dense = -(fsqrt(e2o) * 0.2 + fsqrt(o2t)) * 0.1;
 #if !HRG_HANDOVER && !HRG_LIFT
   if (m.task == HRG_TASK_REACH_BOX) dense = -0.1 * reach_dist;
 #endif
@@ -2446,7 +2576,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
 #else
   double dist2 = 0;
   for (int j = 0; j < NARM; j++) dist2 += (s.qpos[j] - goal[j]) * (s.qpos[j] - goal[j]);
-  const double dist = sqrt(dist2);
+  const double dist = fsqrt(dist2);
   const int goal_reached = !crash && dist <= m.goal_dist;
   double r = goal_reached ? m.task_reward : -1.0;
   const double dense = -0.1 * dist;
@@ -2609,7 +2739,7 @@ DI int env_step(const DevModel* __restrict__ dm_, int lane, int e, int64_t own_g
     const int ph = bx.task_phase;
     int nph = ph;
     if (ph == HRG_PHASE_READY && in_zone) nph = HRG_PHASE_INSPECTION;
-    else if (ph == HRG_PHASE_INSPECTION && !(sqrt(o2t) - m.goal_exit_tolerance <= m.goal_dist)) nph = HRG_PHASE_READY;
+    else if (ph == HRG_PHASE_INSPECTION && !(fsqrt(o2t) - m.goal_exit_tolerance <= m.goal_dist)) nph = HRG_PHASE_READY;
     wave_sync();
     bx.task_phase = nph;
     wave_sync();
@@ -3066,6 +3196,7 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     if (!(desc->pfl_v_safe > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_v_safe must be positive");
     for (int j = 0; j < NARM; j++) if (!(desc->pfl_reach[j] > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_reach must be positive");
   }
+  if (desc->solimp[4] != 2.0) return fail(HRG_ERR_UNSUPPORTED, "solimp power must be 2 (MuJoCo's default): the HIP stepper evaluates the impedance sigmoid as a square");
   if (clips->n_clips < 1 || clips->n_clips > HRG_MAX_CLIPS || clips->n_clips != desc->n_clips) return fail(HRG_ERR_INVALID, "clip table / desc.n_clips mismatch");
   for (int i = 0; i < NV; i++) {
     if ((i < NARM) != (desc->jnt_type[i] == 0)) return fail(HRG_ERR_INVALID, "expected 6 hinges followed by 2 slides");

@@ -10,6 +10,17 @@
 DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_on) {
   const ModelPtr dm = uniform_model(dm_);
   Lds& L = g_L;
+  // the 18 joint angles (3 configurations x 6 hinges) take their sine and cosine on 18 lanes at once; the walk along the chain below reads them back (scratch:
+  // the robot reach capsules L.rc, which the shield fills only after this call)
+  double* sc = &L.rc[0][0];
+  if (lane < 3 * NARM && (lane >= 2 * NARM || shield_on)) {
+    const int cfg = lane / NARM, i = lane - NARM * cfg;
+    const double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
+    double sn, cs;
+    sincos_small(q, &sn, &cs);
+    sc[2 * lane] = sn; sc[2 * lane + 1] = cs;
+  }
+  wave_sync();
   // lanes = (configuration, row): row r of a product R A is (row r of R) A and component r of R v is (row r of R) . v, so a
   // lane that carries one row of the running rotation and one component of the running position needs nothing from the
   // other rows; 9 lanes walk the chain with a third of the serial work and no hand-offs
@@ -20,11 +31,9 @@ DI void robot_chain_fk(const DevModel* __restrict__ dm_, int lane, bool shield_o
     double p = m.base_pos[row];
 #pragma unroll 1
     for (int i = 0; i < NARM; i++) {
-      const double q = cfg == 0 ? L.cq[i] : (cfg == 1 ? L.qe[i] : L.st.qpos[i]);
-      double sn, cs;
+      const double sn = sc[2 * (NARM * cfg + i)], cs = sc[2 * (NARM * cfg + i) + 1];
       p += r0 * m.body_pos[i][0] + r1 * m.body_pos[i][1] + r2 * m.body_pos[i][2];
       // arm hinges turn about the local z axis (robot.xml:33-58, checked at create): Rq Rz(q) mixes the first two columns
-      sincos_small(q, &sn, &cs);
       double n0 = 0, n1 = 0, n2 = 0;
       {
         const double ra[3] = {r0, r1, r2};
@@ -84,74 +93,82 @@ PH_DYNTERMS void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane
   Lds& L = g_L;
   const auto& m = dm->m;
   double bI[10];  // this body's spatial inertia about the world origin (m, h, I)
+  double Sw[3] = {0, 0, 0}, Sv[3] = {0, 0, 0};
   if (lane < NV) {
     const int i = lane;
     const double* R = L.kR[i];
     double axw[3], t[3], c[3];
     m3mulv(axw, R, m.jnt_axis[i]);
-    if (i < NARM) { v3cpy(L.Sw[i], axw); v3cross(L.Sv[i], L.kp[i], axw); }
-    else { v3set(L.Sw[i], 0, 0, 0); v3cpy(L.Sv[i], axw); }
+    if (i < NARM) { v3cpy(Sw, axw); v3cross(Sv, L.kp[i], axw); }
+    else v3cpy(Sv, axw);
+    v3cpy(L.Sw[i], Sw); v3cpy(L.Sv[i], Sv);
     m3mulv(t, R, m.body_com[i]);
     v3add(c, L.kp[i], t);
+    // world-frame rotational inertia R Ib R' (symmetric: six entries): T = R Ib, then W_ab = T_a . R_b for a <= b
     const auto* I = m.body_inertia[i];
-    double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]}, T[9], Rt[9], W[9];
-#pragma unroll
-    for (int a = 0; a < 3; a++)
-#pragma unroll
-      for (int b = 0; b < 3; b++) Rt[3 * a + b] = R[3 * b + a];
+    const double Ib[9] = {I[0], I[3], I[4], I[3], I[1], I[5], I[4], I[5], I[2]};
+    double T[9];
     m3mul(T, R, Ib);
-    m3mul(W, T, Rt);
-    const double Iw[6] = {W[0], W[4], W[8], W[1], W[2], W[5]};
+    const double Iw[6] = {v3dot(T, R), v3dot(T + 3, R + 3), v3dot(T + 6, R + 6), v3dot(T, R + 3), v3dot(T, R + 6), v3dot(T + 3, R + 6)};
     sinertia_body(bI, m.body_mass[i], c, Iw);
+  } else {
 #pragma unroll
-    for (int a = 0; a < 10; a++) L.cI[i][a] = bI[a];
+    for (int a = 0; a < 10; a++) bI[a] = 0.0;
   }
-  wave_sync();
-  if (lane < NV) {
-    const int i = lane;
+  const int i = lane < NV ? lane : 0;
+  // ---- composite inertia of the subtree rooted at i, applied to the joint axis: subtree sums as suffix scans along the chain (DPP row shifts), no hand-off through
+  //      LDS.  (Stage by stage with scheduling barriers in between: interleaving the stages for instruction-level parallelism costs more registers than the
+  //      128 this kernel has.) ----
+  {
+    double cc[10];
+#pragma unroll
+    for (int a = 0; a < 10; a++) cc[a] = subtree_sum(bI[a], lane);
+    double n[3], f[3];
+    sinertia_mul(n, f, cc, Sw, Sv);
+    if (lane < NV) {
+#pragma unroll
+      for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  {
     // ---- velocity / acceleration of body i: accumulate along the ancestor path (ancestors have smaller indices) ----
     // The arm is a serial chain and the fingers hang off its last link (checked at create), so the running sums along the
     // ancestor path are prefix sums over lanes 0..5 (+ the finger's own term): three DPP row-shift steps per component
     // instead of a loop over up to 7 ancestors.  vw_k, vv_k = body velocity, term_k = the Coriolis terms joint k adds.
-    double vw[3], vv[3], aw[3], av[3], jw[3], jv[3];
+    double vw[3], vv[3], aw[3], av[3];
     {
-      const double qd = L.st.qvel[i];
-      v3scl(jw, L.Sw[i], qd);
-      v3scl(jv, L.Sv[i], qd);
-    }
-    for (int a = 0; a < 3; a++) { vw[a] = chain_prefix(jw[a], lane); vv[a] = chain_prefix(jv[a], lane); }
-    {
+      double jw[3], jv[3];
+      const double qd = lane < NV ? L.st.qvel[i] : 0.0;
+      v3scl(jw, Sw, qd);
+      v3scl(jv, Sv, qd);
+      for (int a = 0; a < 3; a++) { vw[a] = chain_prefix(jw[a], lane); vv[a] = chain_prefix(jv[a], lane); }
       double t1[3], t2[3], t3[3];
       v3cross(t1, vw, jw);
       v3cross(t2, vw, jv);
       v3cross(t3, vv, jw);
       for (int a = 0; a < 3; a++) { aw[a] = chain_prefix(t1[a], lane); av[a] = chain_prefix(t2[a] + t3[a], lane) - m.gravity[a]; }
     }
-    v3cpy(L.vw[i], vw);
-    v3cpy(L.vv[i], vv);
-    // ---- force of body i: f = I a + v x* (I v) ----
-    double n1[3], f1[3], n2[3], f2[3], t1[3], t2[3], t3[3];
-    sinertia_mul(n1, f1, bI, aw, av);
-    sinertia_mul(n2, f2, bI, vw, vv);
-    v3cross(t1, vw, n2);
-    v3cross(t2, vv, f2);
-    v3cross(t3, vw, f2);
+    if (lane < NV) { v3cpy(L.vw[i], vw); v3cpy(L.vv[i], vv); }
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- force of body i: f = I a + v x* (I v); the joint force of the bias term is S_k . (sum of the forces of the bodies in the subtree of k) ----
+    double fn[3], ff[3];
+    {
+      double n1[3], f1[3];
+      sinertia_mul(n1, f1, bI, aw, av);
+      double n2[3], f2[3], t1[3], t2[3], t3[3];
+      sinertia_mul(n2, f2, bI, vw, vv);
+      v3cross(t1, vw, n2);
+      v3cross(t2, vv, f2);
+      v3cross(t3, vw, f2);
 #pragma unroll
-    for (int a = 0; a < 3; a++) { L.fn[i][a] = n1[a] + t1[a] + t2[a]; L.ff[i][a] = f1[a] + t3[a]; }
-    // ---- composite inertia of the subtree rooted at i, applied to the joint axis ----
-    double cc[10];
-#pragma unroll
-    for (int a = 0; a < 10; a++) cc[a] = bI[a];
-#pragma unroll 1
-    for (int k = i + 1; k < NV; k++) {
-      if (!((dm->anc_mask[k] >> i) & 1)) continue;
-#pragma unroll
-      for (int a = 0; a < 10; a++) cc[a] += L.cI[k][a];
+      for (int a = 0; a < 3; a++) { fn[a] = n1[a] + t1[a] + t2[a]; ff[a] = f1[a] + t3[a]; }
     }
-    double n[3], f[3];
-    sinertia_mul(n, f, cc, L.Sw[i], L.Sv[i]);
+    __builtin_amdgcn_sched_barrier(0);
+    double gm = 0;
 #pragma unroll
-    for (int a = 0; a < 3; a++) { L.F[i][a] = n[a]; L.F[i][3 + a] = f[a]; }
+    for (int a = 0; a < 3; a++) gm += Sw[a] * subtree_sum(fn[a], lane) + Sv[a] * subtree_sum(ff[a], lane);
+    if (lane < NV) L.bias[i] = gm;
   }
   wave_sync();
   { // mass matrix: lane (i,j)
@@ -161,19 +178,6 @@ PH_DYNTERMS void robot_dynamics_terms(const DevModel* __restrict__ dm_, int lane
     else if ((dm->anc_mask[i] >> j) & 1) v = v3dot(L.Sw[j], &L.F[i][0]) + v3dot(L.Sv[j], &L.F[i][3]);
     if (i == j) v += m.jnt_armature[i];
     L.M[lane] = v;
-  }
-  if (lane < NV) { // bias force of joint k = S_k . (sum of the forces of the bodies in its subtree)
-    const int k = lane;
-    double sn[3], sf[3];
-    v3cpy(sn, L.fn[k]);
-    v3cpy(sf, L.ff[k]);
-#pragma unroll 1
-    for (int i = k + 1; i < NV; i++) {
-      if (!((dm->anc_mask[i] >> k) & 1)) continue;
-      v3add(sn, sn, L.fn[i]);
-      v3add(sf, sf, L.ff[i]);
-    }
-    L.bias[k] = v3dot(L.Sw[k], sn) + v3dot(L.Sv[k], sf);
   }
   wave_sync();
 }
@@ -216,13 +220,15 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     double qz = 0, qy = 0, qx = 0, anchor[3], t[3];
     v3cpy(anchor, m.hb_anchor[b]);
     if (qh) { qz = qh[3 * (b - 1)]; qy = qh[3 * (b - 1) + 1]; qx = qh[3 * (b - 1) + 2]; }
-    const double ez[3] = {0, 0, 1}, ey[3] = {0, 1, 0}, ex[3] = {1, 0, 0};
-    double Rz[9], Ry[9], Rx[9];
-    axisangle2mat(Rz, ez, qz);
-    axisangle2mat(Ry, ey, qy);
-    axisangle2mat(Rx, ex, qx);
-    m3mul(R, Rz, Ry);
-    m3mul(R, R, Rx);
+    // Rz(qz) Ry(qy) Rx(qx) in closed form (the oracle multiplies the three axis-angle matrices: the same rotation, a third of the products)
+    double sz, cz, sy, cy, sx, cx;
+    sincos_small(qz, &sz, &cz);
+    sincos_small(qy, &sy, &cy);
+    sincos_small(qx, &sx, &cx);
+    const double czsy = cz * sy, szsy = sz * sy;
+    R[0] = cz * cy; R[1] = czsy * sx - sz * cx; R[2] = czsy * cx + sz * sx;
+    R[3] = sz * cy; R[4] = szsy * sx + cz * cx; R[5] = szsy * cx - cz * sx;
+    R[6] = -sy;     R[7] = cy * sx;             R[8] = cy * cx;
     m3mulv(t, R, anchor);
     v3sub(p, anchor, t);
   }
@@ -255,10 +261,10 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
     double Rm[9], q[4];
     m3mul(Rm, R, Ry);
     const double tr = Rm[0] + Rm[4] + Rm[8];
-    if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
-    else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
-    else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
-    else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+    if (tr > 0) { const double S = fsqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+    else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = fsqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+    else if (Rm[4] > Rm[8]) { const double S = fsqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+    else { const double S = fsqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
     for (int a = 0; a < 4; a++) L.hand_q[a] = q[a];
     const double off[3] = {r2h ? (hold_left ? 0.02 : -0.02) : 0.0, r2h ? -0.03 : 0.0, r2h ? -0.03 : 0.0};
     double to[3];
@@ -276,10 +282,10 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
       double Rm[9], q[4], site[3], t[3];
       for (int a = 0; a < 3; a++) { Rm[3 * a] = -sn * R[3 * a + 2]; Rm[3 * a + 1] = R[3 * a + 1]; Rm[3 * a + 2] = sn * R[3 * a]; }
       const double tr = Rm[0] + Rm[4] + Rm[8];
-      if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
-      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
-      else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
-      else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+      if (tr > 0) { const double S = fsqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = fsqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+      else if (Rm[4] > Rm[8]) { const double S = fsqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+      else { const double S = fsqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
       m3mulv(t, R, m.hb_anchor[b]);
       v3add(site, p, t);
       for (int a = 0; a < 4; a++) L.sk.mocap_quat[hd][a] = q[a];
@@ -297,10 +303,10 @@ DI void human_fk_lanes(const DevModel* __restrict__ dm_, int lane, const double*
       double Rm[9], q[4], site[3], t[3];
       for (int a = 0; a < 3; a++) { Rm[3 * a] = -sn * R[3 * a + 2]; Rm[3 * a + 1] = R[3 * a + 1]; Rm[3 * a + 2] = sn * R[3 * a]; }
       const double tr = Rm[0] + Rm[4] + Rm[8];
-      if (tr > 0) { const double S = sqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
-      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = sqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
-      else if (Rm[4] > Rm[8]) { const double S = sqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
-      else { const double S = sqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
+      if (tr > 0) { const double S = fsqrt(tr + 1.0) * 2; q[0] = 0.25 * S; q[1] = (Rm[7] - Rm[5]) / S; q[2] = (Rm[2] - Rm[6]) / S; q[3] = (Rm[3] - Rm[1]) / S; }
+      else if (Rm[0] > Rm[4] && Rm[0] > Rm[8]) { const double S = fsqrt(1.0 + Rm[0] - Rm[4] - Rm[8]) * 2; q[0] = (Rm[7] - Rm[5]) / S; q[1] = 0.25 * S; q[2] = (Rm[1] + Rm[3]) / S; q[3] = (Rm[2] + Rm[6]) / S; }
+      else if (Rm[4] > Rm[8]) { const double S = fsqrt(1.0 + Rm[4] - Rm[0] - Rm[8]) * 2; q[0] = (Rm[2] - Rm[6]) / S; q[1] = (Rm[1] + Rm[3]) / S; q[2] = 0.25 * S; q[3] = (Rm[5] + Rm[7]) / S; }
+      else { const double S = fsqrt(1.0 + Rm[8] - Rm[0] - Rm[4]) * 2; q[0] = (Rm[3] - Rm[1]) / S; q[1] = (Rm[2] + Rm[6]) / S; q[2] = (Rm[5] + Rm[7]) / S; q[3] = 0.25 * S; }
       m3mulv(t, R, m.hb_anchor[b]);
       v3add(site, p, t);
       for (int a = 0; a < 4; a++) L.hm.mocap_quat[hd][a] = q[a];
@@ -575,6 +581,10 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     Tb = path_total(&fs2);
     path_eval(&fs2, Tb, ve_fs, &se, &ve_, &ae);
   }
+  // the path state of this cycle is wave-uniform and lives across the reach-capsule verification below: into scalar registers
+  s1 = uniform_f64(s1); v1 = uniform_f64(v1); a1 = uniform_f64(a1); se = uniform_f64(se); Tb = uniform_f64(Tb);
+  fs2.s0 = uniform_f64(fs2.s0); fs2.v0 = uniform_f64(fs2.v0); fs2.a0 = uniform_f64(fs2.a0); fs2.k = uniform_f64(fs2.k);
+  for (int a = 0; a < 3; a++) { fs2.dur[a] = uniform_f64(fs2.dur[a]); fs2.jerk[a] = uniform_f64(fs2.jerk[a]); }
   STAMP(11);
   if (shield_on && lane < NARM) {
     // configuration at the end of the brake, and in the same walk the Motion of the next cycle for the (usual) case that the
@@ -601,7 +611,7 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
       L.rc[c][6] = m.scap_r[c] + m.secure_radius + 0.5 * (l1 > l2 ? l1 : l2) + m.scap_alpha[c] * sdiff * sdiff / 8.0;
       double hv[3];
       for (int a = 0; a < 3; a++) hv[a] = 0.5 * (L.rc[c][3 + a] - L.rc[c][a]);
-      rc_hl = sqrt(v3dot(hv, hv));
+      rc_hl = fsqrt(v3dot(hv, hv));
       L.scap[0][c][0] = rc_hl;   // (this lane's own chain-kinematics entry, dead from here on: the verification loop reads the half length from LDS)
       if (dbg_r) for (int a = 0; a < 7; a++) dbg_r[((size_t)e * HRG_NSHIELD_RCAP + c) * 7 + a] = L.rc[c][a];
     }
@@ -613,7 +623,7 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
         const double rr = L.rc[lane][6];
         for (int a = 0; a < 3; a++) { const double p1 = L.rc[lane][a], p2 = L.rc[lane][3 + a]; bl[a] = (p1 < p2 ? p1 : p2) - rr; bh[a] = (p1 > p2 ? p1 : p2) + rr; }
       } else for (int a = 0; a < 3; a++) { bl[a] = 1e300; bh[a] = -1e300; }
-      for (int a = 0; a < 3; a++) { rbh[a] = __shfl(row16_max(bh[a]), 0, 64); rbl[a] = -__shfl(row16_max(-bl[a]), 0, 64); }
+      for (int a = 0; a < 3; a++) { rbh[a] = lane_value<0>(row16_max(bh[a])); rbl[a] = -lane_value<0>(row16_max(-bl[a])); }
     }
     // lanes = human reach capsules
     const int nh = dm->hc_n;
@@ -649,7 +659,7 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
       }
       double hc[3], hh[3];
       for (int a = 0; a < 3; a++) { hc[a] = 0.5 * (c1[a] + c2[a]); hh[a] = 0.5 * (c2[a] - c1[a]); }
-      const double hl = sqrt(v3dot(hh, hh));
+      const double hl = fsqrt(v3dot(hh, hh));
       // whole-robot cull: the box around the seven robot reach capsules against this capsule's bounding sphere (conservative: a culled lane cannot intersect
       // any of them); the seven pair tests below run only for the lanes that come near
       double d2b = 0;
@@ -768,7 +778,7 @@ DI int box_box2(const double* pa, const double* Ra, const double* ha, const doub
     const int i = ij / 3, j = ij - 3 * i, i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
     const double l2 = 1.0 - C[i][j] * C[i][j];
     if (l2 < 1e-12) continue;
-    const double l = sqrt(l2);
+    const double l = fsqrt(l2);
     const double tl = ta[i2] * C[i1][j] - ta[i1] * C[i2][j];
     const double s_ = (fabs(tl) - (ha[i1] * AC[i2][j] + ha[i2] * AC[i1][j] + hb[j1] * AC[i][j2] + hb[j2] * AC[i][j1])) / l;
     if (s_ > 0) return 0;
@@ -883,7 +893,7 @@ DI int box_box2(const double* pa, const double* Ra, const double* ha, const doub
     if (arg >= 0) pick[np_++] = arg;
   }
   if (np_ == 2) {
-    const double u0 = T[pick[0]], v0 = T[24 + pick[0]], lu = T[pick[1]] - u0, lv = T[24 + pick[1]] - v0, epsc = sqrt(eps2 * (lu * lu + lv * lv));
+    const double u0 = T[pick[0]], v0 = T[24 + pick[0]], lu = T[pick[1]] - u0, lv = T[24 + pick[1]] - v0, epsc = fsqrt(eps2 * (lu * lu + lv * lv));
     int argp = -1, argn = -1;
     double bp = epsc, bn = epsc;
 #pragma unroll 1
@@ -936,13 +946,13 @@ DI void collide_cubes(const DevModel* __restrict__ dm_, int lane, int* base_io) 
       if (lane < NCUBE * HRG_NRCAP && m.rcap_body[i] >= 0) {
         double dc[3];
         for (int a = 0; a < 3; a++) dc[a] = 0.5 * (L.rcapw[i][a] + L.rcapw[i][3 + a]) - sk.pos[cb][a];
-        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + sqrt(circ2) + 1e-9;
+        const double reach = dm->rcap_hl[i] + m.rcap_r[i] + fsqrt(circ2) + 1e-9;
         near = v3dot(dc, dc) <= reach * reach;
       }
       if (__any(near) && near) {
         double cs[3], cbp[3];
         const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], sk.pos[cb], L.cR[cb], hb, cs, cbp);
-        double dd = sqrt(e2), dist = dd - m.rcap_r[i];
+        double dd = fsqrt(e2), dist = dd - m.rcap_r[i];
         if (dist < 0) {
           double s2[3], b2[3];
           const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], sk.pos[cb], L.cR[cb], hb, m.rcap_r[i], cs, cbp, second ? 1 : 0, s2, b2);
@@ -1106,7 +1116,7 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
       if (__any(near) && near) {
         double cs[3], cbp[3];
         const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], L.gc[g], L.gR[fb], hb, cs, cbp);
-        double dd = sqrt(e2), dist = dd - m.rcap_r[i];
+        double dd = fsqrt(e2), dist = dd - m.rcap_r[i];
         if (dist < 0) {
           double s2[3], b2[3];
           const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], L.gc[g], L.gR[fb], hb, m.rcap_r[i], cs, cbp, second ? 1 : 0, s2, b2);
@@ -1176,7 +1186,7 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
           const double la = fabs(L.gR[0][a] * d[0] + L.gR[0][3 + a] * d[1] + L.gR[0][6 + a] * d[2]) - hb[a];
           if (la > 0) d2 += la * la;
         }
-        const double ra = sqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]) + 1e-9;
+        const double ra = fsqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]) + 1e-9;
         // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
         if (!(d2 > ra * ra)) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + 72 * lane);
       }
@@ -1279,7 +1289,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
       }
       if (__any(near) && valid && near) {
         double c1[3], c2[3], d[3];
-        const double d2 = seg_seg(&L.rcapw[i][0], &L.rcapw[i][3], a1, a2, c1, c2), dd = sqrt(d2), dist = dd - m.rcap_r[i] - r2;
+        const double d2 = seg_seg(&L.rcapw[i][0], &L.rcapw[i][3], a1, a2, c1, c2), dd = fsqrt(d2), dist = dd - m.rcap_r[i] - r2;
         if (dist < margin) {
           hit = true;
           v3sub(d, c2, c1);
@@ -1326,7 +1336,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
       if (m.rcap_body[i] >= 0) {
         double cs[3], cb[3];
         const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, cs, cb);
-        double dd = sqrt(e2);
+        double dd = fsqrt(e2);
         double dist = dd - m.rcap_r[i];
         if (dist < 0) {
           double s2[3], b2[3];
@@ -1370,7 +1380,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         const int hl = dm->clips.clip_holding_hand[clip_of(dm, (int64_t)L.st.stream_id, L.st.episode, L.st.anim_index)];
         const int body = m.meas_body[hl ? m.site_lhand : m.site_rhand];
         double cs[3], cb[3];
-        palm = sqrt(seg_box(&L.hcap[body][0], &L.hcap[body][3], bx.pos, L.bR, hb, cs, cb)) - m.hcap_r[body] < 0;
+        palm = fsqrt(seg_box(&L.hcap[body][0], &L.hcap[body][3], bx.pos, L.bR, hb, cs, cb)) - m.hcap_r[body] < 0;
       }
       L.palm_hit = __any(palm);
     }

@@ -153,6 +153,13 @@ STACKING_ENV_KWARGS = dict(
     done_at_success=True,
     stack_weld_relpos=[0.0, 0.045, 0.0],   # relpose of lh_weld_eq / rh_weld_eq (1263-1281)
 )
+# Stand-in for robosuite 1.3.2's composite HammerObject (absent; its dimensions are drawn at random per instance): a box handle at the middle of the
+# reference's ranges (handle_radius 0.015-0.02, handle_length 0.1-0.25, handle_density 100-250) and ONE box for head + neck + face
+# (head_halfsize between 1 and 1.2 handle radii, head_density_ratio 2); no claw.  Body frame: origin = middle of the handle, handle along z, head along x.
+HAMMER = dict(handle_half=[0.0175, 0.0175, 0.0875], handle_density=175.0, head_half=[0.0616, 0.01925, 0.01925], head_density=350.0)
+# models/assets/objects/nail.xml: nail_head body 0.06 above nail_base, collision cylinder r 0.02 / half height 0.002 at +0.001 (stand-in: a box of the same
+# extents), slide joint along -z, range [0, 0.06], frictionloss 10000, solreffriction (-100, -100)
+NAIL = dict(head_half=[0.02, 0.02, 0.002], head_dz=0.001, stem=0.06, range=0.06, frictionloss=10000.0, fric_damping=100.0, dummy_half=0.01)
 # CollaborativeHammeringCart constructor defaults (collaborative_hammering_cartesian_env.py:291-367) overlaid with training/config/environment/default/
 # collaborative_hammering_cart.yaml (table / board sizes, sampling rates) and, on top, the TOP-LEVEL training/config/environment/collaborative_hammering_cart.yaml
 # -- the convention of every other task here (what make_vec_env(env_id) steps is what the reference's training config for that env would step).  The top-level
@@ -175,16 +182,12 @@ HAMMERING_ENV_KWARGS = dict(
     human_rand=[0.0, 0.0, 0.0],
     n_animations_sampled_per_100_steps=1,
     gripper_controllable=False,
+    noslip_iterations=20,       # self.sim.model.opt.noslip_iterations = 20 (_setup_references, 1161); 0 switches the pass off (round 2's model: the nail creeps)
+    noslip_tolerance=1e-6,      # MuJoCo's default opt.noslip_tolerance
+    nail_frictionloss=NAIL["frictionloss"],   # nail.xml:7 (10 000 N); a model parameter so that tests can show a nail yielding to a force above it
     hammer_anchors=[[-0.1, 0.2, 0.0], [-0.5, -0.2, 0.0]],   # l_anchor / r_anchor of _postprocess_model (1001-1002)
     hammer_weld_relquat=[0.0, 0.0, 0.0, 1.0],               # relpose of rh_eq: "0 0 0 0 0 0 1" (1123-1131)
 )
-# Stand-in for robosuite 1.3.2's composite HammerObject (absent; its dimensions are drawn at random per instance): a box handle at the middle of the
-# reference's ranges (handle_radius 0.015-0.02, handle_length 0.1-0.25, handle_density 100-250) and ONE box for head + neck + face
-# (head_halfsize between 1 and 1.2 handle radii, head_density_ratio 2); no claw.  Body frame: origin = middle of the handle, handle along z, head along x.
-HAMMER = dict(handle_half=[0.0175, 0.0175, 0.0875], handle_density=175.0, head_half=[0.0616, 0.01925, 0.01925], head_density=350.0)
-# models/assets/objects/nail.xml: nail_head body 0.06 above nail_base, collision cylinder r 0.02 / half height 0.002 at +0.001 (stand-in: a box of the same
-# extents), slide joint along -z, range [0, 0.06], frictionloss 10000, solreffriction (-100, -100)
-NAIL = dict(head_half=[0.02, 0.02, 0.002], head_dz=0.001, stem=0.06, range=0.06, frictionloss=10000.0, fric_damping=100.0, dummy_half=0.01)
 ENV_DEFAULTS = {"CollaborativeHammeringCart": HAMMERING_ENV_KWARGS, "CollaborativeStackingCart": STACKING_ENV_KWARGS, "CollaborativeLiftingCart": LIFTING_ENV_KWARGS, "ReachHuman": DEFAULT_ENV_KWARGS, "PickPlaceHumanCart": PICK_PLACE_ENV_KWARGS, "HumanRobotHandoverCart": HANDOVER_H2R_ENV_KWARGS,
                 "RobotHumanHandoverCart": HANDOVER_R2H_ENV_KWARGS,
                 "PickPlaceCloseHumanCart": PICK_PLACE_CLOSE_ENV_KWARGS, "PickPlacePointingHumanCart": POINTING_ENV_KWARGS,
@@ -679,7 +682,17 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
         d.n_targets = max(int(kw["horizon"] * kw["n_targets_sampled_per_100_steps"] / 100), 1)
         d.object_gripped_reward = float(kw["object_gripped_reward"])
     if env_id == "CollaborativeHammeringCart":
-        _fill_hammering(d, kw)
+        # diagonal of M at qpos0 over the human's 69 hinges (they are dynamic DoF of the reference's model: stat.meaninertia counts them): every body has mass 1,
+        # inertia diag(1, 1, 1) and its inertial frame at the common origin (human.xml:46); a hinge carries the bodies of its subtree
+        n_sub = [1] * len(HB)
+        for i in range(len(HB) - 1, 0, -1):
+            n_sub[HB[i]["parent"]] += n_sub[i]
+        human_diag = []
+        for i, b in enumerate(HB):
+            for ax in b["joint_axes"]:
+                lever = np.cross(np.asarray(ax, float), -np.asarray(b["anchor"], float))
+                human_diag.append(n_sub[i] * (1.0 + float(lever @ lever)) + float(A["human"]["armature"]))
+        _fill_hammering(d, kw, list(np.diag(M0)) + human_diag)
     # ---- Cartesian action front-end (wrappers/ik_position_delta_wrapper.py)
     d.ik_enabled = int(ik_position_delta is not None)
     ik = dict(IK_DEFAULTS)
@@ -703,7 +716,7 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     return d
 
 
-def _fill_hammering(d, kw):
+def _fill_hammering(d, kw, tree_M0_diag):
     """CollaborativeHammeringCart (collaborative_hammering_cartesian_env.py): board, hammer stand-in, nail, the two hand equalities, task parameters."""
     NARM, NF = CONST["HRG_NARM"], CONST["HRG_NFINGER"]
     d.task = CONST["HRG_TASK_HAMMERING"]
@@ -755,7 +768,7 @@ def _fill_hammering(d, kw):
     # NailSampler (946-960): z_offset = half board thickness + 0.001, on top of that the dummy's half height [UPSTREAM UniformRandomSampler]; nail_head 0.06 above
     d.hm_nail_z0 = half[2] + 0.001 + NAIL["dummy_half"] + NAIL["stem"]
     d.hm_nail_range = NAIL["range"]
-    d.hm_nail_frictionloss = NAIL["frictionloss"]
+    d.hm_nail_frictionloss = float(kw["nail_frictionloss"])
     d.hm_nail_fric_damping = NAIL["fric_damping"]
     d.hm_nail_invweight = 1.0 / d.hm_nail_mass + 1.0 / d.hm_board_mass
     d.hm_nail_bin[:] = [half[0] * 0.1, half[0] * 0.9, -half[1] * 0.9, half[1] * 0.9]         # _get_default_nail_sample_space_boundaries (838-853)
@@ -765,6 +778,13 @@ def _fill_hammering(d, kw):
     d.gripper_controllable = int(bool(kw["gripper_controllable"]))
     d.n_obj_placements = max(int(kw["horizon"] * kw["n_nail_placements_sampled_per_100_steps"] / 100), 1)   # 370-373
     d.n_targets = 1
+    # MuJoCo's noslip post-pass: sim.model.opt.noslip_iterations = 20 in _setup_references (1161); opt.noslip_tolerance stays at MuJoCo's default 1e-6.  Its
+    # convergence measure is scaled by 1 / (stat.meaninertia * nv) = 1 / trace(M(qpos0)) over the reference model's 90 DoF: robot tree 8, human hinges 69 (dynamic
+    # DoF there although the stepper plays them back), board 6, nail 1, hammer 6
+    d.noslip_iterations = int(kw["noslip_iterations"])
+    d.noslip_tolerance = float(kw["noslip_tolerance"])
+    diag = list(tree_M0_diag) + [d.hm_board_mass + d.hm_nail_mass] * 3 + list(d.hm_board_inertia[:]) + [d.hm_nail_mass] + [d.hm_hammer_mass] * 3 + list(d.hm_hammer_inertia[:])
+    d.noslip_scale = 1.0 / float(np.sum(diag))
 
 
 def robot_fk_numpy(d, q):

@@ -320,8 +320,11 @@ typedef struct hrg_model_desc {
   double hm_nail_bin[4];          /* xmin xmax ymin ymax of the nail placements on the board (838-853) */
   double hm_goal_tolerance;       /* nail counts as hammered in when 1 - progress < goal_tolerance (505-520) */
   double hammer_gripped_reward_bonus, nail_hammered_in_reward; /* _sparse_reward (522-556) */
+  /* ---- MuJoCo's noslip post-pass (mj_solNoSlip [UPSTREAM]); collaborative_hammering_cartesian_env.py:1161 sets noslip_iterations = 20, no other task does ---- */
+  double noslip_tolerance;        /* opt.noslip_tolerance (MuJoCo default 1e-6): the pass ends when the scaled cost improvement of a sweep falls below it */
+  double noslip_scale;            /* 1 / (stat.meaninertia * nv): the scale of that improvement (mean diagonal of M at qpos0 over the stepper's real DoF) */
   int32_t gripper_controllable;   /* False: the gripper action is replaced by 'close' (486-487) */
-  int32_t hm_pad;
+  int32_t noslip_iterations;      /* opt.noslip_iterations: sweeps of the pass at most; 0 = off (every task but CollaborativeHammeringCart) */
   uint64_t seed;
 } hrg_model_desc;
 

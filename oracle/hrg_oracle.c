@@ -1114,6 +1114,7 @@ typedef struct {
   int n;
   int type[NEFC_MAX];
   int nv; /* DoF of the system the rows act on: NV, or NVT with the manipulation object */
+  int grp[NEFC_MAX]; /* contact rows: 4 * contact + pyramid edge (the noslip pass pairs opposing edges); -1: not a contact row */
   double J[NEFC_MAX][NVMAX], aref[NEFC_MAX], D[NEFC_MAX], floss[NEFC_MAX];
 } efc_t;
 
@@ -1153,6 +1154,7 @@ static void efc_add_b(const hrg_model_desc* m, efc_t* E, const double* J, const 
   int r = E->n++;
   memcpy(E->J[r], J, sizeof(double) * E->nv);
   E->type[r] = type;
+  E->grp[r] = -1;
   E->aref[r] = -Bd * vel - K * imp * (pos - margin);
   E->D[r] = 1.0 / ((1 - imp) / imp * diag);
   E->floss[r] = floss;
@@ -1266,6 +1268,77 @@ static void solve(const hrg_model_desc* m, const double* M, const double* a0, co
     for (int i = 0; i < nv; i++) a[i] += al * d[i];
     if (exact) break;
   }
+}
+
+/* MuJoCo's noslip post-pass (mj_solNoSlip [UPSTREAM]; switched on by collaborative_hammering_cartesian_env.py:1161, noslip_iterations = 20), restated from MuJoCo's
+ * documentation of it: a projected Gauss-Seidel pass AFTER the main solver that updates only the friction dimensions -- dry friction (friction-loss rows) and contact
+ * friction -- with the constraint regularisation removed (R = 0), every other constraint force held at the main solver's value:
+ *   dry friction row i:  f_i <- clamp(f_i - res_i / A_ii, +-frictionloss),  res = J a - aref (the row's acceleration residual without R f), A = J M^-1 J';
+ *   pyramidal contact:   each pair of opposing pyramid edges (n + mu t, n - mu t) keeps the sum of its two forces (the normal force) and moves along (1, -1) to the
+ *                        exact minimiser of the unregularised dual cost, both forces kept >= 0:  y <- clamp(y - (res_0 - res_1) / (A_00 + A_11 - 2 A_01), +-mid);
+ *   a sweep's cost improvement, scaled by 1 / (meaninertia nv), below noslip_tolerance ends the pass (the first sweep also counts the removed sum 1/2 R f^2).
+ * Here in acceleration space: a = a_smooth + M^-1 J' f is updated with W_r = M^-1 J_r' whenever a force changes, so res_r = J_r a - aref_r.  The forces the pass
+ * starts from are those of the primal solution, f_r = -s_r'(J_r a - aref_r).  With soft rows alone the nail of the hammering task creeps in under its own weight
+ * (the friction row cancels 90 % of the free acceleration); with the pass its acceleration is the row's reference -b v exactly while |f| < frictionloss. */
+static void noslip(const hrg_model_desc* m, const double* M, const efc_t* E, double* a) {
+  const int nv = E->nv, n = E->n;
+  if (m->noslip_iterations <= 0 || n == 0) return;
+  double* L = (double*)malloc(sizeof(double) * nv * nv);
+  double (*W)[NVMAX] = malloc(sizeof(double[NVMAX]) * (size_t)n);
+  double f[NEFC_MAX], Ad[NEFC_MAX];
+  int part[NEFC_MAX]; /* contact rows: index of the opposing edge's row (-1: none) */
+  memcpy(L, M, sizeof(double) * nv * nv);
+  if (!chol(L, nv)) { free(L); free(W); return; }
+  for (int r = 0; r < n; r++) {
+    double y = -E->aref[r], c, g, h;
+    for (int i = 0; i < nv; i++) y += E->J[r][i] * a[i];
+    row_cost(E, r, y, &c, &g, &h);
+    f[r] = -g;
+    part[r] = -1;
+    if (E->grp[r] >= 0 && (E->grp[r] & 1) == 0 && r + 1 < n && E->grp[r + 1] == E->grp[r] + 1) part[r] = r + 1;
+    const int fric = E->type[r] == ROW_FRICTION || part[r] >= 0 || (r > 0 && part[r - 1] == r);
+    if (!fric) continue;
+    memcpy(W[r], E->J[r], sizeof(double) * nv);
+    chol_solve(L, nv, W[r]);
+    double t = 0;
+    for (int i = 0; i < nv; i++) t += E->J[r][i] * W[r][i];
+    Ad[r] = t;
+  }
+  for (int it = 0; it < m->noslip_iterations; it++) {
+    double imp = 0;
+    if (it == 0) for (int r = 0; r < n; r++) imp += 0.5 * f[r] * f[r] / E->D[r];
+    for (int r = 0; r < n; r++) { /* dry friction */
+      if (E->type[r] != ROW_FRICTION) continue;
+      double res = -E->aref[r];
+      for (int i = 0; i < nv; i++) res += E->J[r][i] * a[i];
+      const double A = Ad[r] > 1e-15 ? Ad[r] : 1e-15, old = f[r];
+      f[r] = clampd(old - res / A, -E->floss[r], E->floss[r]);
+      const double dl = f[r] - old;
+      for (int i = 0; i < nv; i++) a[i] += W[r][i] * dl;
+      imp -= dl * res + 0.5 * Ad[r] * dl * dl;
+    }
+    for (int r = 0; r < n; r++) { /* contact friction: pairs of opposing pyramid edges */
+      if (part[r] < 0) continue;
+      const int q = part[r];
+      double res0 = -E->aref[r], res1 = -E->aref[q], A01 = 0;
+      for (int i = 0; i < nv; i++) { res0 += E->J[r][i] * a[i]; res1 += E->J[q][i] * a[i]; A01 += E->J[q][i] * W[r][i]; }
+      const double mid = 0.5 * (f[r] + f[q]), y0 = 0.5 * (f[r] - f[q]), K1 = Ad[r] + Ad[q] - 2.0 * A01;
+      double y = 0;
+      if (K1 >= 1e-15) y = clampd(y0 - (res0 - res1) / K1, -mid, mid);
+      if (mid < 0) y = 0; /* (cannot happen: unilateral forces are >= 0) */
+      const double dy = y - y0;
+      f[r] = mid + y; f[q] = mid - y;
+      for (int i = 0; i < nv; i++) a[i] += (W[r][i] - W[q][i]) * dy;
+      imp -= dy * (res0 - res1) + 0.5 * K1 * dy * dy;
+    }
+    if (g_debug > 2) {
+      fprintf(stderr, "[noslip] it %d imp %.3e scaled %.3e |", it, imp, imp * m->noslip_scale);
+      for (int r = 0; r < n; r++) if (E->type[r] == ROW_FRICTION && E->floss[r] > 1) { double res = -E->aref[r]; for (int i = 0; i < nv; i++) res += E->J[r][i] * a[i]; fprintf(stderr, " nail f %.4g res %.3e aref %.3e", f[r], res, E->aref[r]); }
+      fprintf(stderr, "\n");
+    }
+    if (imp * m->noslip_scale < m->noslip_tolerance) break;
+  }
+  free(L); free(W);
 }
 
 /* =============================================================================================== env */
@@ -2810,7 +2883,7 @@ static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, flo
  * the nail in while the human presents the board; three-phase animation machine.  Constrained system: 24 DoF in three blocks of eight --
  * robot tree 0..7 | board 8..13 + the nail's slide joint 14 (+ pad) | hammer 16..21 (+ 2 pads); a pad DoF has unit mass, no force and no constraint row.
  * Stand-ins: the hammer is two boxes (robosuite's composite HammerObject is absent), the nail head a box, box-box contacts by box_box2 (D13),
- * capsule-box contacts as for the single cube (D8); MuJoCo's noslip post-pass (noslip_iterations = 20, 1149) is not restated. */
+ * capsule-box contacts as for the single cube (D8); MuJoCo's noslip post-pass (noslip_iterations = 20, 1161): noslip() above. */
 #define NVH HRG_NV_HAMMER
 #define HM_OB NV        /* board DoF */
 #define HM_ON (NV + 6)  /* nail slide joint */
@@ -3224,7 +3297,9 @@ static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, fl
           if (fb == HRG_HM_NAIL) { J[HM_ON] = sgn * v3dot(dir, G.axis); diag += m->hm_nail_invweight; }
           else diag += 1.0 / (fb == HRG_HM_HAMMER ? m->hm_hammer_mass : m->hm_board_mass);
         }
+        const int n_before = E->n;
         efc_add(m, E, J, qd, ROW_UNILATERAL, con[c].dist, margin, 0, diag * (1.0 + m->friction_static * m->friction_static));
+        if (E->n > n_before) E->grp[n_before] = 4 * c + d;
       }
     }
     { /* lh_eq: connect(lh_grip, lh_mocap); rh_eq: weld(rh_grip, rh_mocap) (1100-1145); both stay active (the switch to rh_backup_eq is commented out, 650) */
@@ -3256,6 +3331,7 @@ static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, fl
     for (int a = 0; a < 6; a++) { qacc[HM_OB + a] = hm->acc_warmstart[0][a]; qacc[HM_OH + a] = hm->acc_warmstart[1][a]; }
     qacc[HM_ON] = hm->nail_acc_warmstart;
     solve(m, Mt, a0, E, qacc);
+    noslip(m, Mt, E, qacc); /* opt.noslip_iterations = 20 (1161) */
     if (g_debug && (ncon > 0 || g_debug > 1)) {
       double mx = 0; for (int i = 0; i < NVH; i++) if (fabs(qacc[i]) > mx) mx = fabs(qacc[i]);
       fprintf(stderr, "[oracle hammer] env %d cyc %d ncon %d nefc %d max|qacc| %.3e", e, cyc, ncon, E->n, mx);
@@ -3285,6 +3361,7 @@ static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, fl
         for (int a = 0; a < 4; a++) hm->quat[fb][a] = qn[a] / nn;
       }
     }
+    if (g_debug > 2) fprintf(stderr, "[nail] cyc %d qacc %.4e v %.4e q %.4e ncon %d nefc %d\n", cyc, qacc[HM_ON], hm->nail_v, hm->nail_q, ncon, 0);
     hm->nail_acc_warmstart = qacc[HM_ON];
     hm->nail_v += h * qacc[HM_ON];
     hm->nail_q += h * hm->nail_v;

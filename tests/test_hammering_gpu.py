@@ -27,20 +27,37 @@ def _quat2mat(q):
                      [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
 
 
-def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, act_scale=1.0):
+def _bodies(B, e):
+    hm = B.get_hammer(e)
+    return np.array([x for b in range(2) for x in list(hm.pos[b]) + list(hm.quat[b])] + [hm.nail_q])
+
+
+def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, act_scale=1.0, twin=None):
+    """`twin` (resynchronised runs): a second oracle batch that takes every step from the first one's state with the hammer moved by 1e-12 m.  An env whose two oracle
+    results then differ by more than 1e-7 sits on a knife edge of the step itself (a box-box reference face or a noslip bound that flips within the 25 substeps: the
+    fuzz scenario throws the hammer into the board at random poses) -- no implementation can be expected to land on the oracle's side of it.  Such env-steps leave the
+    comparison, counted in `knife` and bounded."""
     import torch
     oo, og = O.reset(), G.reset().cpu().numpy()
+    if twin is not None:
+        twin.reset()
     np.testing.assert_allclose(og, oo, rtol=RTOL, atol=ATOL)
     for e in range(n):
         assert_state_close(O.get_hammer(e), G.get_hammer(e), f"reset env {e} objects")
         assert_state_close(O.get_state(e), G.get_state(e), f"reset env {e}")
     rng = np.random.RandomState(seed)
     live = np.ones(n, bool)
-    stats = dict(hammer_contacts=0, box_box=0, nail_contacts=0, phases=set(), max_ncon=0, gripped=0, static=0)
+    stats = dict(hammer_contacts=0, box_box=0, nail_contacts=0, phases=set(), max_ncon=0, gripped=0, static=0, flicker=0, knife=0)
     for k in range(n_steps):
         if scenario is not None:
             scenario(k, [O, G])
         a = rng.uniform(-1, 1, (n, 7)) * act_scale
+        if twin is not None:
+            for e in range(n):
+                hm = O.get_hammer(e)
+                hm.pos[1][0] += 1e-12
+                twin.set_state(e, O.get_state(e)); twin.set_hammer(e, hm)
+            twin.step(a.copy())
         o_o, r_o, d_o, i_o = O.step(a)
         o_g, r_g, d_g, i_g = G.step(torch.from_numpy(np.ascontiguousarray(a)).cuda())
         torch.cuda.synchronize()
@@ -53,14 +70,21 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
         if not resync:
             live &= ~violent
         chk = live & ~violent if resync else live
+        if twin is not None:
+            knife = np.array([np.abs(_bodies(O, e) - _bodies(twin, e)).max() > 1e-7 for e in range(n)])
+            stats["knife"] += int((chk & knife).sum())
+            chk &= ~knife
         pg, ng = G.contacts()
-        if not resync:
-            # a resting contact that carries no load sits at distance zero: whether it is listed is decided by rounding-level state differences.  Such an env leaves
-            # the comparison (counted in the dropped fraction) -- but only while its bodies still agree to 1e-7
-            for e in np.nonzero(chk & ((ng != no) | (pg != po).any((1, 2))))[0]:
-                fo, fg = (np.array([x for b in range(2) for x in list(B.get_hammer(e).pos[b]) + list(B.get_hammer(e).quat[b])] + [B.get_hammer(e).nail_q]) for B in (O, G))
-                assert np.abs(fo - fg).max() < 1e-7, f"{msg} env {e}: contact lists differ and so do the bodies ({np.abs(fo - fg).max():.2e})"
-                live[e] = chk[e] = False
+        # a resting contact that carries no load sits at distance zero: whether it is listed is decided by rounding-level state differences.  Such an env leaves
+        # the comparison (free-running: for good, counted in the dropped fraction; resynchronised: for this step, counted in `flicker`) -- but only while its bodies
+        # still agree to 1e-7
+        for e in np.nonzero(chk & ((ng != no) | (pg != po).any((1, 2))))[0]:
+            fo, fg = (np.array([x for b in range(2) for x in list(B.get_hammer(e).pos[b]) + list(B.get_hammer(e).quat[b])] + [B.get_hammer(e).nail_q]) for B in (O, G))
+            assert np.abs(fo - fg).max() < 1e-7, f"{msg} env {e}: contact lists differ and so do the bodies ({np.abs(fo - fg).max():.2e})"
+            chk[e] = False
+            stats["flicker"] += 1
+            if not resync:
+                live[e] = False
         np.testing.assert_array_equal(ng[chk], no[chk], err_msg=msg)
         np.testing.assert_array_equal(pg[chk], po[chk], err_msg=msg)
         np.testing.assert_array_equal(i_g.cpu().numpy()[chk], i_o[chk], err_msg=msg)
@@ -82,6 +106,11 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
                 G.set_state(e, post[e])
                 G.set_hammer(e, phm[e])
     record_live(f"test_hammering_gpu::{name}", live, min_live)
+    assert stats["flicker"] <= max(2, (n * n_steps) // 100), f"{name}: {stats['flicker']} env-steps with a contact list that differs at agreeing bodies"
+    assert stats["knife"] <= max(2, (n * n_steps) // 50), f"{name}: {stats['knife']} env-steps on a knife edge of the oracle itself"
+    if twin is not None:
+        print(f"[parity] {name}: {stats['knife']} of {n * n_steps} env-steps on a knife edge of the oracle (left out), {stats['flicker']} contact-list flickers")
+        twin.close()
     O.close(); G.close()
     return stats
 
@@ -89,7 +118,7 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
 @pytest.mark.parametrize("shield", ["OFF", "SSM"])
 def test_random_actions_parity_resync(shield):
     """Per-step parity with the GPU state re-synchronised after every step: the board carried in by the human (weld + connect), the hammer pinched by the
-    fingers and swinging down on its line contacts, the nail creeping on its soft friction row, APPROACH -> PRESENT."""
+    fingers, its grip contacts and the nail's friction row through the noslip pass, APPROACH -> PRESENT."""
     O, G, _ = _pair(12, dict(shield_type=shield, horizon=60, seed=2))
     st = _rollout(O, G, 12, 40, 1, True, f"random_{shield}", act_scale=0.3)
     assert st["hammer_contacts"] > 0 and st["gripped"] > 0 and {0, 1} <= st["phases"]
@@ -155,6 +184,30 @@ def test_hammer_on_nail_and_board_parity():
     _rollout(O, G, 4, 20, 3, False, "on_nail_free", scenario=_on_the_nail, act_scale=0.0, min_live=0.75)
 
 
+def _strikes(k, Bs):
+    """Step 12: the hammer is laid onto the nail head (env 0), dropped onto it at 1.5 m/s (env 1) and at 3 m/s (env 2), laid onto the board (env 3)."""
+    if k != 12:
+        return
+    _on_the_nail(k, Bs)
+    for B in Bs:
+        for e, v in ((1, 1.5), (2, 3.0)):
+            hm = B.get_hammer(e)
+            hm.pos[1][2] += 0.01
+            hm.vel[1][2] = -v
+            B.set_hammer(e, hm)
+
+
+@pytest.mark.parametrize("floss", [5.0, 0.5])
+def test_noslip_pass_with_a_yielding_nail_parity(floss):
+    """MuJoCo's noslip post-pass (1161) with the friction bound in play: a nail with a friction loss of 5 N / 0.5 N under a resting hammer (1 N) and under blows --
+    holding, yielding, driven to its range limit -- step by step against the oracle, then free-running."""
+    O, G, d = _pair(4, dict(shield_type="OFF", horizon=100, seed=4, nail_frictionloss=floss))
+    st = _rollout(O, G, 4, 24, 3, True, f"noslip_{floss}", scenario=_strikes, act_scale=0.0)
+    assert st["nail_contacts"] > 0
+    O, G, d = _pair(4, dict(shield_type="OFF", horizon=100, seed=4, nail_frictionloss=floss))
+    _rollout(O, G, 4, 20, 3, False, f"noslip_{floss}_free", scenario=_strikes, act_scale=0.0, min_live=0.75)
+
+
 def test_scripted_episode_through_success_parity():
     """The whole phase machine on both steppers: the nail is pushed in by hand once the board is presented; RETREAT, COMPLETE, _on_goal_reached, next animation."""
     clips = task_clips(ENV, 2, min_frames=300, max_frames=340)
@@ -209,5 +262,8 @@ def test_box_box_fuzz_parity():
                 hm.pos[1][:] = poses[e][0].tolist(); hm.quat[1][:] = poses[e][1].tolist()
                 hm.vel[1][:] = [0.0] * 6; hm.acc_warmstart[1][:] = [0.0] * 6
                 B.set_hammer(e, hm)
-    st = _rollout(O, G, n, 16, 8, True, "boxbox_fuzz", scenario=scenario, act_scale=0.0)
+    from oracle.oracle import OracleBatch
+    clips = task_clips(ENV, 3, min_frames=300, max_frames=420)
+    O2 = OracleBatch(hrg.build_model_desc(dict(task_env_kwargs(ENV), shield_type="OFF", horizon=200, seed=9), n_clips=clips.n_clips, env_id=ENV), clips, n)
+    st = _rollout(O, G, n, 16, 8, True, "boxbox_fuzz", scenario=scenario, act_scale=0.0, twin=O2)
     assert st["box_box"] > 20 * 4

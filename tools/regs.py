@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
-"""Per-function register / scratch usage of the gfx950 code object (tuning aid): python tools/regs.py [-DHRG_NOINLINE=1 ...]"""
+"""Per-function register / scratch usage of the gfx950 code object (tuning aid): python tools/regs.py [-DHRG_PHASE='__device__ __noinline__' ...]"""
 import glob, os, re, subprocess, sys, tempfile
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "human-robot-gym_amd", "csrc", "hrgym_hip.hip")
 d = tempfile.mkdtemp()
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-save-temps", "-Wno-unused-value", *sys.argv[1:], "-o", "t.o", src], cwd=d, stderr=subprocess.DEVNULL)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-save-temps", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", *sys.argv[1:], "-o", "t.o", src], cwd=d, stderr=subprocess.DEVNULL)
 s = open(glob.glob(d + "/*gfx950*.s")[0]).read()
 for m in re.finditer(r"\.type\s+(\S+),@function", s):
     name = m.group(1)
