@@ -217,7 +217,7 @@ struct Lds {
     };
     struct {  // human_control + collide + classify (the dynamics step's rows take this space afterwards)
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
-      int cur[HRG_NPREV_MAX];
+      int hnear[HRG_NHB];                // human capsules whose bounding sphere comes near the robot (the pair rounds of collide run over these)
       double rcen[HRG_NRCAP][3];         // capsule centres: collide -> classify (the speed of a robot geom at a human contact)
 #if HRG_STACK
       double cR[NCUBE][9];               // cube rotation matrices of the substep's narrowphase
@@ -811,28 +811,10 @@ DI double lane_value(double v) {
   const int hi = __builtin_amdgcn_readlane((int)(b >> 32), K);
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// two independent factorisations in one pass (M and M + h D of a substep): the two dependency chains (rsqrt, shuffles) interleave
-DI void chol_lanes2(double a, double b, int lane, bool* ok, double* la, double* lb) {
-  const int i = lane >> 3, j = lane & 7;
-  bool good = true;
-#pragma unroll
-  for (int k = 0; k < NV; k++) {
-    const double akk = __shfl(a, k * 9, 64), bkk = __shfl(b, k * 9, 64);
-    if (!(akk > 0) || !(bkk > 0)) good = false;
-    const double inva = rsqrt(akk), da = akk * inva, invb = rsqrt(bkk), db = bkk * invb;
-    const double aik = __shfl(a, i * 8 + k, 64) * inva, bik = __shfl(b, i * 8 + k, 64) * invb;
-    const double ajk = __shfl(a, j * 8 + k, 64) * inva, bjk = __shfl(b, j * 8 + k, 64) * invb;
-    if (j == k) { if (i == k) { a = da; b = db; } else if (i > k) { a = aik; b = bik; } }
-    else if (i > k && j > k) { a -= aik * ajk; b -= bik * bjk; }
-  }
-  *ok = good;
-  *la = a; *lb = b;
-}
-// Inverses of two symmetric positive definite 8x8 matrices (M and M + h D of a substep) in one pass: in-place Gauss-Jordan sweeps, lane (i,j) owns entry
-// (i,j) of each matrix, three shuffles and one reciprocal per pivot and matrix -- the cost of the factorisation above, but what comes out turns every later
-// solve with these matrices (unconstrained acceleration, the Newton direction while no row has curvature, the implicit-damping step) into one product per
-// lane and a three-step row reduction, instead of a 16-step dependent substitution chain on 8 lanes.  Pivots are the same Schur complements as the
-// Cholesky pivots: positive definiteness is checked on them.
+// Inverse of a symmetric positive definite 8x8 matrix across the wave: in-place Gauss-Jordan sweeps, lane (i,j) owns entry (i,j), three shuffles and one reciprocal
+// per pivot -- the cost of a factorisation, but what comes out turns every later solve with the matrix (unconstrained acceleration, the Newton direction while no
+// row has curvature, the implicit-damping step) into one product per lane and a three-step row reduction, instead of a 16-step dependent substitution chain on
+// 8 lanes.  Pivots are the same Schur complements as the Cholesky pivots: positive definiteness is checked on them.
 #define HRG_PIVOT(v, K) lane_value<(K) * 9>(v)   // the pivot is one lane's value: scalar broadcast, and the reciprocal starts without waiting for a shuffle (-0.7 %)
 template <int K>
 DI void inv_pivot(double& a, int i, int j, bool& good) {
@@ -845,21 +827,7 @@ DI void inv_pivot(double& a, int i, int j, bool& good) {
   else if (j == K) a = -aik * pa;
   else a -= aik * akj * pa;
 }
-DI void spd_inverse2(double a, double b, int lane, bool* ok, double* ia, double* ib) {
-  const int i = lane >> 3, j = lane & 7;
-  bool good = true;
-  inv_pivot<0>(a, i, j, good); inv_pivot<0>(b, i, j, good);
-  inv_pivot<1>(a, i, j, good); inv_pivot<1>(b, i, j, good);
-  inv_pivot<2>(a, i, j, good); inv_pivot<2>(b, i, j, good);
-  inv_pivot<3>(a, i, j, good); inv_pivot<3>(b, i, j, good);
-  inv_pivot<4>(a, i, j, good); inv_pivot<4>(b, i, j, good);
-  inv_pivot<5>(a, i, j, good); inv_pivot<5>(b, i, j, good);
-  inv_pivot<6>(a, i, j, good); inv_pivot<6>(b, i, j, good);
-  inv_pivot<7>(a, i, j, good); inv_pivot<7>(b, i, j, good);
-  *ok = good;
-  *ia = a; *ib = b;
-}
-// the same sweep for one matrix (the Newton Hessian once a row has curvature)
+// (M of a substep; the Newton Hessian once a row has curvature)
 DI double spd_inverse1(double a, int lane, bool* ok) {
   const int i = lane >> 3, j = lane & 7;
   bool good = true;

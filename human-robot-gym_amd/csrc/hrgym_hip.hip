@@ -48,6 +48,45 @@ DI int row_zone(int type, double lim, double x) {  // which quadratic / linear p
   return x <= -lim ? -1 : (x >= lim ? 1 : 0);
 }
 
+// mj_Euler's implicit joint damping for the robot tree: qvel += h (M + h D)^-1 M qacc -- without a second 8 x 8 inverse.  D is diagonal: the two finger slides carry
+// real damping (h d ~ 0.4 against an inertia of ~ 1), the six arm hinges 1e-4 (h d / M ~ 1e-5).  With A = M + h D_fingers,
+//   A^-1 v = M^-1 v - M^-1[:, f] S^-1 (M^-1 v)[f],   S = (h D_f)^-1 + M^-1[f, f]                     (Woodbury, rank 2, exact)
+//   (A + h D_arm)^-1 t = A^-1 t - A^-1 (h D_arm A^-1 t) + O((h d_arm / M)^2 ~ 1e-10)                  (one Neumann term; hrg_batch_create checks the ratio)
+// lane (i, j) holds entry (i, j) of M and of M^-1; vectors go through L.d.  Returns nothing: qvel / qpos of the robot tree are integrated in place.
+DI void euler_robot_tree(ModelPtr dm, int lane, double Mij, double Minv) {
+  Lds& L = g_L;
+  const auto& m = dm->m;
+  hrg_env_state& s = L.st;
+  const int mi = lane >> 3, mj = lane & 7;
+  const double h = m.timestep;
+  const double hd6 = h * m.jnt_damping[NARM], hd7 = h * m.jnt_damping[NARM + 1];
+  const bool fingers = hd6 > 0 && hd7 > 0;
+  const double S00 = (fingers ? 1.0 / hd6 : 0.0) + lane_value<6 * 9>(Minv), S01 = lane_value<6 * 8 + 7>(Minv), S11 = (fingers ? 1.0 / hd7 : 0.0) + lane_value<7 * 9>(Minv);
+  const double idet = 1.0 / (S00 * S11 - S01 * S01);
+  auto Ainv = [&](const double* v) -> double {   // (A^-1 v)_mi in every lane of row mi
+    const double y = row8_sum(Minv * v[mj]);
+    if (!fingers) return y;
+    const double y6 = lane_value<6 * 8>(y), y7 = lane_value<7 * 8>(y);
+    const double z0 = (S11 * y6 - S01 * y7) * idet, z1 = (S00 * y7 - S01 * y6) * idet;
+    return y - row8_sum(mj == 6 ? Minv * z0 : (mj == 7 ? Minv * z1 : 0.0));
+  };
+  const double t = matvec_lanes(Mij, L.qacc, lane);
+  if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
+  wave_sync();
+  if (mj == 0) L.d[mi] = t;
+  wave_sync();
+  const double x0 = Ainv(L.d);
+  wave_sync();
+  if (mj == 0) L.d[mi] = mi < NARM ? h * m.jnt_damping[mi] * x0 : 0.0;
+  wave_sync();
+  const double x = x0 - Ainv(L.d);
+  if (mj == 0) {
+    const double v = s.qvel[mi] + h * x;
+    s.qvel[mi] = v;
+    s.qpos[mi] = s.qpos[mi] + h * v;
+  }
+}
+
 // returns 1 when the simulation diverged (MujocoException path, human_env.py:527-546)
 #if HRG_BOX
 // row a (0..5) of the box's inertia block times the 6 box entries v: m v_a for the translation, the world-frame rotational inertia
@@ -82,8 +121,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const int nc = ncon < NCON_DYN ? ncon : NCON_DYN;
   bool ok;
   const double Mij = L.M[lane];
-  double Minv, MDinv;   // entries (mi, mj) of M^-1 and (M + h D)^-1 of the robot tree
-  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  const double Minv = spd_inverse1(Mij, lane, &ok), M0inv = Minv;   // entry (mi, mj) of M^-1 of the robot tree
   if (!ok) return 1;
   if (lane < NV) {
     double act = L.ctrl[lane];
@@ -490,19 +528,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping for the robot tree
-  {
-    const double t = matvec_lanes(Mij, L.qacc, lane);
-    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
-    wave_sync();
-    if (mj == 0) L.d[mi] = t;
-    wave_sync();
-    const double x = matvec_lanes(MDinv, L.d, lane);
-    if (mj == 0) {
-      const double v = s.qvel[mi] + h * x;
-      s.qvel[mi] = v;
-      s.qpos[mi] = s.qpos[mi] + h * v;
-    }
-  }
+  euler_robot_tree(dm, lane, Mij, M0inv);
   { // the cubes' free joints: lanes 8..31 = (cube, component); quaternions by lanes 0..3 of each cube's group
     double vnew = 0;
     const int a = lane - NV, cu = lane >= NV && lane < NVS ? a / 6 : 0, k = lane >= NV && lane < NVS ? a - 6 * cu : 0;
@@ -550,8 +576,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const int nc = ncon < NCON_DYN ? ncon : NCON_DYN;
   bool ok;
   const double Mij = L.M[lane];
-  double Minv, MDinv;   // entries (mi, mj) of M^-1 and (M + h D)^-1 of the robot tree
-  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  const double Minv = spd_inverse1(Mij, lane, &ok), M0inv = Minv;   // entry (mi, mj) of M^-1 of the robot tree
   if (!ok) return 1;
   // ---- board + nail subtree: the board as a free body with world-frame angular velocity, the nail head a point mass at r that slides along the axis a ----
   double Mb;
@@ -1079,19 +1104,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping for the robot tree
-  {
-    const double t = matvec_lanes(Mij, L.qacc, lane);
-    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
-    wave_sync();
-    if (mj == 0) L.d[mi] = t;
-    wave_sync();
-    const double x = matvec_lanes(MDinv, L.d, lane);
-    if (mj == 0) {
-      const double v = s.qvel[mi] + h * x;
-      s.qvel[mi] = v;
-      s.qpos[mi] = s.qpos[mi] + h * v;
-    }
-  }
+  euler_robot_tree(dm, lane, Mij, M0inv);
   hammer_obs_pos(dm_, lane);   // body_xpos of the forward pass inside mj_step (pre-integration)
   wave_sync();
   { // the free joints: lanes 8..13 board, 14 the nail's slide joint, 16..21 hammer; quaternions by lanes 0, 1
@@ -1137,8 +1150,8 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   // ---- factor M across the wave; unconstrained acceleration a0 = M^-1 (actuation + passive - bias) ----
   bool ok;
   const double Mij = L.M[lane];
-  double Minv, MDinv;  // entries (mi, mj) of M^-1 and (M + h D)^-1 (mj_Euler's implicit damping, used at the end of the substep)
-  spd_inverse2(Mij, Mij + (mi == mj ? h * m.jnt_damping[mi] : 0.0), lane, &ok, &Minv, &MDinv);
+  double Minv = spd_inverse1(Mij, lane, &ok);   // entry (mi, mj) of M^-1; later the inverse of the Newton Hessian's robot block
+  const double M0inv = Minv;                    // M^-1 itself: mj_Euler's implicit damping at the end of the substep
   if (!ok) return 1;
   if (lane < NV) {
     double act = L.ctrl[lane];
@@ -1559,19 +1572,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
   const bool badacc = lane < NVS && !(fabs(L.qacc[lane]) < 1e10);
   if (__any(badacc)) return 1;
   // mj_Euler with implicit joint damping: (M + h D) qacc' = M qacc
-  {
-    const double t = matvec_lanes(Mij, L.qacc, lane);
-    if (lane < NV) s.qacc_warmstart[lane] = L.qacc[lane];
-    wave_sync();
-    if (mj == 0) L.d[mi] = t;
-    wave_sync();
-    const double x = matvec_lanes(MDinv, L.d, lane);
-    if (mj == 0) {
-      const double v = s.qvel[mi] + h * x;
-      s.qvel[mi] = v;
-      s.qpos[mi] = s.qpos[mi] + h * v;
-    }
-  }
+  euler_robot_tree(dm, lane, Mij, M0inv);
 #if HRG_BOX
   { // free joint: no damping; the quaternion is integrated with the world-frame angular velocity
     double vnew = 0;
@@ -3196,6 +3197,10 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
     if (!(desc->pfl_v_safe > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_v_safe must be positive");
     for (int j = 0; j < NARM; j++) if (!(desc->pfl_reach[j] > 0)) return fail(HRG_ERR_INVALID, "PFL: pfl_reach must be positive");
   }
+  for (int i = 0; i < NARM; i++)   // mj_Euler's implicit damping treats the arm's joint damping as a perturbation (euler_robot_tree): one Neumann term, error (h d / M)^2
+    if (!(desc->jnt_damping[i] >= 0 && desc->timestep * desc->jnt_damping[i] * desc->dof_invweight0[i] < 1e-3))
+      return fail(HRG_ERR_UNSUPPORTED, "arm joint damping too large for the implicit-damping expansion (h d / M must stay below 1e-3; robot.xml: 1e-4)");
+  if ((desc->jnt_damping[NARM] > 0) != (desc->jnt_damping[NARM + 1] > 0)) return fail(HRG_ERR_UNSUPPORTED, "the two finger slides must both carry damping, or neither");
   if (desc->solimp[4] != 2.0) return fail(HRG_ERR_UNSUPPORTED, "solimp power must be 2 (MuJoCo's default): the HIP stepper evaluates the impedance sigmoid as a square");
   if (clips->n_clips < 1 || clips->n_clips > HRG_MAX_CLIPS || clips->n_clips != desc->n_clips) return fail(HRG_ERR_INVALID, "clip table / desc.n_clips mismatch");
   for (int i = 0; i < NV; i++) {

@@ -627,12 +627,12 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     }
     // lanes = human reach capsules
     const int nh = dm->hc_n;
-    bool hit = false;
-    int mdl = 0;
+    int mdl = -1;
+    double c1[3] = {0, 0, 0}, c2[3] = {0, 0, 0}, r = 0, hc[3] = {0, 0, 0}, hl = 0;
+    bool near_robot = false;
     if (lane < nh) {
       const int kind = dm->hc_kind[lane], j1 = dm->hc_j1[lane], j2 = dm->hc_j2[lane];
       const double Td = dt + Tb + m.delay;
-      double c1[3], c2[3], r;
       if (kind == 0) {
         double va[3], vb[3];
         const double idt = have_vel ? 1.0 / (t - s.meas_prev_t) : 0.0;
@@ -657,34 +657,50 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
         r = dm->hc_th[lane] + m.meas_err_pos + dm->hc_v[lane] * Td;
         mdl = kind == 1 ? 1 : 2;
       }
-      double hc[3], hh[3];
+      double hh[3];
       for (int a = 0; a < 3; a++) { hc[a] = 0.5 * (c1[a] + c2[a]); hh[a] = 0.5 * (c2[a] - c1[a]); }
-      const double hl = fsqrt(v3dot(hh, hh));
+      hl = fsqrt(v3dot(hh, hh));
       // whole-robot cull: the box around the seven robot reach capsules against this capsule's bounding sphere (conservative: a culled lane cannot intersect
-      // any of them); the seven pair tests below run only for the lanes that come near
+      // any of them); the pair tests below run only for the lanes that come near
       double d2b = 0;
       for (int a = 0; a < 3; a++) { const double ee = hc[a] < rbl[a] ? rbl[a] - hc[a] : (hc[a] > rbh[a] ? hc[a] - rbh[a] : 0.0); d2b += ee * ee; }
-      const bool near_robot = d2b <= (hl + r + 1e-9) * (hl + r + 1e-9);
-#pragma unroll 1
-      for (int c = 0; c < (near_robot ? HRG_NSHIELD_RCAP : 0); c++) {
-        double x1[3], x2[3], rcn[3], dc[3];
-        const double rr = L.rc[c][6] + r;
-        for (int a = 0; a < 3; a++) rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]);
-        v3sub(dc, rcn, hc);
-        const double reach = L.scap[0][c][0] + hl + rr + 1e-9;   // (from LDS: the loop runs under divergence, lanes 0..6 may be culled)
-        if (v3dot(dc, dc) > reach * reach) continue;  // bounding spheres apart: cannot intersect
-        if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true;
-      }
+      near_robot = d2b <= (hl + r + 1e-9) * (hl + r + 1e-9);
       if (dbg_h) {
         double* o = dbg_h + ((size_t)e * HRG_NHCAP_MAX + lane) * 7;
         o[0] = c1[0]; o[1] = c1[1]; o[2] = c1[2]; o[3] = c2[0]; o[4] = c2[1]; o[5] = c2[2]; o[6] = r;
       }
     }
     if (dbg_nh && lane == 0) dbg_nh[e] = nh;
-    const bool hitA = __any(hit && mdl == 0) || !have_vel;
-    const bool hitV = __any(hit && mdl == 1);
-    const bool hitP = __any(hit && mdl == 2);
-    safe = !(hitA && hitV && hitP);
+    // The step is safe as soon as ONE of the three human models (ACC, VEL, POS) has no capsule that meets a robot reach capsule: the models are tested one after
+    // the other and the rest is skipped once one is clear -- usually the first (ACC: the tightest sets while the human moves slowly), so the large POS / VEL
+    // capsules, which come near the arm far more often, rarely reach their segment-segment tests at all; inside a model the search ends with its first hit.
+    // The verdict is the one of testing every capsule (oracle: shield_step).
+    bool all_hit = true;
+#pragma unroll 1
+    for (int mm = 0; mm < 3 && all_hit; mm++) {
+      if (mm == 0 && !have_vel) continue;   // without a velocity estimate the ACC model counts as violated
+      const bool mine = mdl == mm && near_robot;
+      bool hit = false;
+      if (__any(mine)) {
+#pragma unroll 1
+        for (int c = 0; c < HRG_NSHIELD_RCAP; c++) {
+          bool close = false;
+          const double rr = L.rc[c][6] + r;
+          if (mine) {
+            double rcn[3], dc[3];
+            for (int a = 0; a < 3; a++) rcn[a] = 0.5 * (L.rc[c][a] + L.rc[c][3 + a]);
+            v3sub(dc, rcn, hc);
+            const double reach = L.scap[0][c][0] + hl + rr + 1e-9;   // (half length of robot capsule c, stored above)
+            close = !(v3dot(dc, dc) > reach * reach);               // bounding spheres apart: cannot intersect
+          }
+          if (!__any(close)) continue;
+          if (close) { double x1[3], x2[3]; if (seg_seg(&L.rc[c][0], &L.rc[c][3], c1, c2, x1, x2) < rr * rr) hit = true; }
+          if (__any(hit)) break;
+        }
+      }
+      all_hit = __any(hit);
+    }
+    safe = !all_hit;
   }
   wave_sync();
   STAMP(14);
@@ -1223,10 +1239,12 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
     v3add(L.rcen[c], p, t);
   }
   wave_sync();
-  // Whole-robot cull of the 240 robot-human pairs: the box around all robot capsules, each inflated by its radius and the human
-  // contact margin, against the bounding sphere of every human capsule.  No sphere touching the box = no pair can be a contact
-  // (conservative), and the four robot-human rounds are skipped; the human usually stands clear of the arm.
-  bool human_near;
+  // Cull of the 240 robot-human pairs: the box around all robot capsules, each inflated by its radius and the human contact margin, against the bounding sphere
+  // of every human capsule.  A human capsule whose sphere misses the box cannot be in contact with any robot capsule (conservative); the capsules that come near
+  // (none while the human stands clear of the arm, a forearm and a hand when it reaches in) are listed in LDS, and the pair rounds below run over
+  // robot capsule x listed human capsule only: one round of 64 lanes for up to six of them instead of four rounds over all 240 pairs.  The pairs keep their
+  // order (robot capsule major, human capsule minor), so the contact list is the one of the full enumeration.
+  int n_hnear;
   {
     double bl[3], bh[3];
     if (lane < HRG_NRCAP) {
@@ -1239,24 +1257,29 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
     double d2 = 0;
     const int hb = lane < HRG_NHB ? lane : 0;
     for (int a = 0; a < 3; a++) {
-      const double hi = __shfl(row16_max(bh[a]), 0, 64), lo = -__shfl(row16_max(-bl[a]), 0, 64);
+      const double hi = lane_value<0>(row16_max(bh[a])), lo = -lane_value<0>(row16_max(-bl[a]));
       const double c = 0.5 * (L.hcap[hb][a] + L.hcap[hb][3 + a]);
       const double e = c < lo ? lo - c : (c > hi ? c - hi : 0.0);
       d2 += e * e;
     }
     const double rad = dm->hcap_hl[hb] + m.hcap_r[hb] + 1e-9;
-    human_near = __any(lane < HRG_NHB && d2 <= rad * rad);
+    const bool hn = lane < HRG_NHB && d2 <= rad * rad;
+    const uint64_t hmask = __ballot(hn);
+    n_hnear = __popcll(hmask);
+    if (hn) L.hnear[__popcll(hmask & ((1ull << lane) - 1))] = lane;
+    if (n_hnear) wave_sync();
   }
   int base = 0;
   const uint64_t lt = lane == 0 ? 0ull : (~0ull >> (64 - lane));
-  // rounds: 0 = robot-robot, 1..4 = robot-human (240 pairs), 5 = planes
+  const int n_hpairs = HRG_NRCAP * n_hnear, n_hrounds = (n_hpairs + 63) >> 6;
+  const float inv_hnear = n_hnear ? 1.0f / (float)n_hnear : 0.0f;
+  // rounds: 0 = robot-robot, 1..n_hrounds = robot-human (the listed capsules), last = planes
 #pragma unroll 1
-  for (int round = 0; round < 6; round++) {
-    if (round >= 1 && round <= 4 && !human_near) continue;
+  for (int round = 0; round < 2 + n_hrounds; round++) {
     bool hit = false;
     Contact c;
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
-    if (round <= 4) {
+    if (round <= n_hrounds) {
       int i = 0, g2 = 0;
       double r2 = 0, margin = 0, hl2 = 0;
       const double *a1, *a2;
@@ -1268,10 +1291,10 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         g2 = j; a1 = &L.rcapw[j][0]; a2 = &L.rcapw[j][3]; r2 = m.rcap_r[j]; hl2 = dm->rcap_hl[j];
         c.b2 = m.rcap_body[j];
       } else {
-        const int pidx = (round - 1) * 64 + lane;
-        valid = pidx < HRG_NRCAP * HRG_NHB;
-        i = valid ? pidx / HRG_NHB : 0;
-        const int hb = valid ? pidx % HRG_NHB : 0;
+        const int q = (round - 1) * 64 + lane;
+        valid = q < n_hpairs;
+        i = valid ? (int)(((float)q + 0.5f) * inv_hnear) : 0;   // q / n_hnear (exact: q <= 240, the quotient's distance to an integer is at least 0.5 / 24)
+        const int hb = valid ? L.hnear[q - i * n_hnear] : 0;
         g2 = GEOM_HUMAN0 + hb; a1 = &L.hcap[hb][0]; a2 = &L.hcap[hb][3]; r2 = m.hcap_r[hb]; hl2 = dm->hcap_hl[hb];
         margin = m.contact_margin_human;
         c.b2 = -2;

@@ -119,7 +119,7 @@ def test_hip_reproduces_the_scenario(shield):
         np.testing.assert_array_equal(sg, so)
         np.testing.assert_array_equal(ig, io)
     else:                                                 # PFL touches the human (contact dynamics are chaotic): same verdicts
-        assert q1g.min() < -0.5 and pvg[20:].min() >= pvo[20:].min() - 1e-9 and ig[11] == 0
+        assert q1g.min() < -0.5 and pvg[20:].min() >= pvo[20:].min() * (1 - 1e-5) - 1e-9 and ig[11] == 0   # (the slowest path speed: within the parity tolerance of the oracle's)
         k = int(np.argmax(np.abs(q1g - q1o) > 1e-4)) if (np.abs(q1g - q1o) > 1e-4).any() else STEPS
         assert k > 20                                      # identical until well into the first contact phase
     G.close()
