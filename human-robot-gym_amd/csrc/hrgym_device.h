@@ -579,8 +579,10 @@ DI void scurve(double va, double vb, double amax, double jmax, double* dur, doub
   jerk[0] = sg * jmax; jerk[1] = 0; jerk[2] = -sg * jmax;
 }
 
+// what the last three parts of a joint's profile ([S-curve v -> sg w][cruise][S-curve sg w -> 0], segments n0 ..) were planned from: the time synchronisation re-plans them
+struct LttTail { int n0; double v, sg, Dm, vm, w; };
 // one joint of a long-term trajectory (executed by lane j < 6)
-DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax) {
+DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax, LttTail* tail) {
   double* dur = L->dur[j];
   double* jerk = L->jerk[j];
   for (int i = 0; i < HRG_LTT_NSEG; i++) { dur[i] = 0; jerk[i] = 0; }
@@ -633,10 +635,51 @@ DI void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, doubl
       if (step <= 4e-16 * (1.0 + fabs(w)) || hi - lo <= 4e-16 * (1.0 + hi)) break;
     }
   }
+  tail->n0 = n; tail->v = v; tail->sg = sg; tail->Dm = Dm; tail->vm = vm; tail->w = w;
   scurve(v, sg * w, amax, jmax, dur + n, jerk + n);
   n += 3;
   dur[n] = tc; jerk[n] = 0; n++;
   scurve(sg * w, 0, amax, jmax, dur + n, jerk + n);
+}
+// Time synchronisation (sara-shield's LongTermPlanner [UPSTREAM]; oracle: ltt_sync_joint): a joint whose own time-optimal profile ends before T keeps its
+// first parts and drives the rest at a lower cruise speed w with g(w) = T1(w - vm) + T2(w) + (Dm - dist_nocruise(vm, w)) / w = T - (time of the first parts):
+// g falls monotonically from infinity to the time-optimal duration, Newton with the analytic derivative inside the bracket.  Lane j < 6.
+DI void ltt_sync_joint(hrg_ltt* L, int j, double T, double amax, double jmax, const LttTail& tl) {
+  double* dur = L->dur[j];
+  double* jerk = L->jerk[j];
+  double tpre = 0, tall = 0;
+  for (int i = 0; i < HRG_LTT_NSEG; i++) { if (i < tl.n0) tpre += dur[i]; tall += dur[i]; }
+  if (!(tall < T - 1e-12) || !(tl.w > 0)) return;
+  const double Tt = T - tpre, vm = tl.vm, Dm = tl.Dm, vtri = amax * amax / jmax;
+  double lo = 0, hi = tl.w;
+  double w = hi * (tall - tpre) / Tt;
+  bool found = false;
+  for (int it = 0; it < 80; it++) {
+    const double d1 = w - vm, T1 = scurve_time(d1, amax, jmax), T2 = scurve_time(w, amax, jmax);
+    const double dnc = 0.5 * (vm + w) * T1 + 0.5 * w * T2, rest = Dm - dnc;
+    const double g = T1 + T2 + rest / w - Tt;
+    if (g == 0) { found = true; break; }
+    if (g > 0) lo = w; else hi = w;
+    const double sd = d1 >= 0 ? 1.0 : -1.0;
+    const double T1p = sd * (fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / fsqrt(jmax * fabs(d1)) : 0.0));
+    const double T2p = w >= vtri ? 1.0 / amax : (w > 0 ? 1.0 / fsqrt(jmax * w) : 0.0);
+    const double dncp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
+    const double gp = T1p + T2p - dncp / w - rest / (w * w);
+    double nw = gp < 0 ? w - g / gp : 0.5 * (lo + hi);
+    if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);
+    const double step = fabs(nw - w);
+    w = nw;
+    found = true;
+    if (step <= 4e-16 * (1.0 + w) || hi - lo <= 4e-16 * (1.0 + hi)) break;
+  }
+  if (!found || !(w > 0)) return;
+  const double tc = (Dm - dist_nocruise(vm, w, amax, jmax)) / w;
+  if (!(tc >= 0)) return;
+  int n = tl.n0;
+  scurve(tl.v, tl.sg * w, amax, jmax, dur + n, jerk + n);
+  n += 3;
+  dur[n] = tc; jerk[n] = 0; n++;
+  scurve(tl.sg * w, 0, amax, jmax, dur + n, jerk + n);
 }
 
 DI void ltt_eval(const hrg_ltt* L, int j, double s, double* q, double* v, double* a) {

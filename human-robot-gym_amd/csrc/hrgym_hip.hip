@@ -1637,7 +1637,7 @@ DI bool config_collides(const DevModel* __restrict__ dm_, int lane) {
     const int c = 1 + (lane >> 1);
     const double* p = cc + 6 * c + 3 * (lane & 1);
     const double r = c == NCAP_CHECK - 1 ? m.scap_r[HRG_NSHIELD_RCAP - 1] : m.rcap_r[c], mg = m.obstacle_margin;
-    if (p[2] - r < m.table_top_z + mg && fabs(p[0]) <= m.table_half[0] + 0.5 * mg + r && fabs(p[1]) <= m.table_half[1] + 0.5 * mg + r) hit = true;
+    if (p[2] - r < m.table_top_z + mg && fabs(p[0] - m.table_center[0]) <= m.table_half[0] + 0.5 * mg + r && fabs(p[1] - m.table_center[1]) <= m.table_half[1] + 0.5 * mg + r) hit = true;
     const double dx = p[0] - m.base_pos[0], dy = p[1] - m.base_pos[1];
     if (p[2] - r < m.base_cyl_z && fsqrt(dx * dx + dy * dy) < m.base_cyl_r + mg + r) hit = true;
   } else if (lane >= 16 && lane - 16 < dm->n_chk) {

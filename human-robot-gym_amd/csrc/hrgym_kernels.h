@@ -540,11 +540,15 @@ PH_SHIELD void shield_step(const DevModel* __restrict__ dm_, int lane, int e, do
     if (!__any(bad)) {
       use_cand = 1;
       double tj = 0;
+      LttTail tail;
+      tail.n0 = 0; tail.v = tail.sg = tail.Dm = tail.vm = tail.w = 0;
       if (lane < NARM) {
-        ltt_plan_joint(&L.cand, lane, nq, nv, na, s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane]);
+        ltt_plan_joint(&L.cand, lane, nq, nv, na, s.new_goal_q[lane], m.v_max_ltt[lane], m.a_max_ltt[lane], m.j_max_ltt[lane], &tail);
         for (int i = 0; i < HRG_LTT_NSEG; i++) tj += L.cand.dur[lane][i];
       }
-      L.cand.T = wave_max(tj);
+      const double Tall = wave_max(tj);
+      L.cand.T = Tall;
+      if (m.ltt_time_sync && lane < NARM) ltt_sync_joint(&L.cand, lane, Tall, m.a_max_ltt[lane], m.j_max_ltt[lane], tail);   // the joints arrive together
     }
     wave_sync();
   }
@@ -764,7 +768,7 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 }
 
 // ================================================================================================ contacts
-#if HRG_STACK || HRG_HAMMER
+#if HRG_STACK || HRG_HAMMER || HRG_LIFT
 // Contacts of two boxes with half extents ha / hb (centres pa / pb, rotations Ra / Rb row-major in LDS; the stacking task's cubes share one h): separating-axis test over the 15 axes, then
 // the reference face's rectangle clipped against the incident face (candidates: incident vertices, rectangle corners under the incident face, edge
 // crossings; at most four penetrating candidates that span the patch are kept) or one edge-edge contact.  Restated as in
@@ -1008,7 +1012,7 @@ DI void collide_cubes(const DevModel* __restrict__ dm_, int lane, int* base_io) 
       v3add(p, p, sk.pos[cb]);
       const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
       bool ok = true;
-      if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+      if (pl == 0) ok = fabs(p[0] - m.table_center[0]) <= m.table_half[0] && fabs(p[1] - m.table_center[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
       if (ok && dist < 0) {
         hit = true;
         v3set(c.n, 0, 0, 1);
@@ -1173,7 +1177,7 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
         v3add(p, p, L.gc[g]);
         const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
         bool ok = true;
-        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+        if (pl == 0) ok = fabs(p[0] - m.table_center[0]) <= m.table_half[0] && fabs(p[1] - m.table_center[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
         if (ok && dist < 0) {
           hit = true;
           v3set(c.n, 0, 0, 1);
@@ -1327,7 +1331,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         const double* p = &L.rcapw[i][3 * en];
         const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - m.rcap_r[i] - z0;
         bool ok = true;
-        if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.025;  // end point above the mid-plane of the 0.05 m slab
+        if (pl == 0) ok = fabs(p[0] - m.table_center[0]) <= m.table_half[0] && fabs(p[1] - m.table_center[1]) <= m.table_half[1] && p[2] > z0 - 0.025;  // end point above the mid-plane of the 0.05 m slab
         if (ok && dist < 0) {
           hit = true;
           v3set(c.n, 0, 0, -1);
@@ -1380,15 +1384,47 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
           c.g1 = i; c.g2 = GEOM_BOX; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX; c.dist = dist;
         }
       }
-    } else if (lane >= 16 && lane < 32) {
+    }
+#if HRG_LIFT
+    // CollaborativeLiftingCart: the board against the table slab (0.4 m wide, 5 cm thick, one metre in front of the robot: collaborative_lifting_cartesian_env.py:
+    // 280-284, 742-746) by box-box contacts -- the two overlap in a cross, no corner of either lies over the other.  Lane 16 runs the pair (SAT + clipping, D13)
+    // when the board's circumsphere comes near the slab, lanes 16..19 take one contact each; the corner-against-plane test below is left to the floor.
+    else if (lane >= 16 && lane < 24) {
+      double* T = &L.Jc[20][0];      // scratch behind the collide arrays (the solver rows are dead here): 72 doubles of candidates, then the contacts
+      double* res = &L.Jc[26][0];
+      int nb = 0;
+      if (lane == 16) {
+        const double pt[3] = {m.table_center[0], m.table_center[1], m.table_top_z - 0.025}, ht[3] = {m.table_half[0], m.table_half[1], 0.025};
+        double d2 = 0;
+        for (int a = 0; a < 3; a++) { const double la = fabs(bx.pos[a] - pt[a]) - ht[a]; if (la > 0) d2 += la * la; }
+        if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9)) {
+          const double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          BBContact bc[4];
+          nb = box_box2(pt, Rt, ht, bx.pos, L.bR, hb, bc, T);
+          for (int q = 0; q < nb; q++) { for (int a = 0; a < 3; a++) { res[7 * q + a] = bc[q].pos[a]; res[7 * q + 3 + a] = bc[q].n[a]; } res[7 * q + 6] = bc[q].dist; }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();   // lane 16's LDS stores stay ahead of the other lanes' loads (a wave's LDS operations execute in issue order)
+      nb = __shfl(nb, 16, 64);   // (a shuffle inside a divergent branch reads lane 16, which is active here)
+      const int q = lane - 16;
+      if (q < nb) {
+        hit = true;
+        for (int a = 0; a < 3; a++) { c.pos[a] = res[7 * q + a]; c.n[a] = res[7 * q + 3 + a]; }
+        c.g1 = GEOM_TABLE; c.g2 = GEOM_BOX; c.b1 = -1; c.b2 = BODY_BOX; c.dist = res[7 * q + 6];
+      }
+    } else if (lane >= 24 && lane < 32) {
+      const int pl = 1, cn = lane & 7;
+#else
+    else if (lane >= 16 && lane < 32) {
       const int pl = (lane - 16) >> 3, cn = lane & 7;
+#endif
       const double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]};
       double p[3];
       m3mulv(p, L.bR, loc);
       v3add(p, p, bx.pos);
       const double z0 = pl ? m.floor_z : m.table_top_z, dist = p[2] - z0;
       bool ok = true;
-      if (pl == 0) ok = fabs(p[0]) <= m.table_half[0] && fabs(p[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
+      if (pl == 0) ok = fabs(p[0] - m.table_center[0]) <= m.table_half[0] && fabs(p[1] - m.table_center[1]) <= m.table_half[1] && p[2] > z0 - 0.05;
       if (ok && dist < 0) {
         hit = true;
         v3set(c.n, 0, 0, 1);

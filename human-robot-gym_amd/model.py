@@ -206,6 +206,7 @@ SHIELD_DEFAULTS = dict(
     v_max_allowed=1.0, a_max_allowed=10.0, j_max_allowed=400.0,
     v_max_ltt=1.0, a_max_ltt=2.0, j_max_ltt=15.0,
     secure_radius=0.02,
+    ltt_time_sync=True,   # sara-shield's planner synchronises the joints of a long-term trajectory to the slowest one; False: each joint time-optimal (rounds 1-2)
     pfl_v_safe=0.25,   # PFL: Cartesian speed [m/s] the arm may keep when the reachable sets intersect (ISO/TS 15066-style transient contact)
     meas_err_pos=0.0, meas_err_vel=0.0, delay=0.0,
 )
@@ -532,6 +533,7 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     for j in range(NARM):
         d.v_max_allowed[j], d.a_max_allowed[j], d.j_max_allowed[j] = sp["v_max_allowed"], sp["a_max_allowed"], sp["j_max_allowed"]
         d.v_max_ltt[j], d.a_max_ltt[j], d.j_max_ltt[j] = sp["v_max_ltt"], sp["a_max_ltt"], sp["j_max_ltt"]
+    d.ltt_time_sync = int(bool(sp["ltt_time_sync"]))
     d.path_amax = (sp["a_max_allowed"] - sp["a_max_ltt"]) / sp["v_max_ltt"]
     d.path_jmax = (sp["j_max_allowed"] - sp["j_max_ltt"] - 3.0 * sp["a_max_ltt"] * d.path_amax) / sp["v_max_ltt"]
     assert d.path_amax > 0 and d.path_jmax > 0
@@ -675,7 +677,10 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
             d.min_balance = float(kw["min_balance"])
             d.imbalance_failure_reward = float(kw["imbalance_failure_reward"])
             d.board_released_reward = float(kw["board_released_reward"])
-            d.table_half[:] = [0.0, 0.0]     # the 0.4 m table under the board's middle (737-747) is not modelled: nothing to rest on, the floor catches a dropped board
+            # the table under the board's middle: TableArena(table_full_size (0.4, 1.5, 0.05), table_offset (1.0, 0, 0.8)), 280-284, 742-746 -- a slab one metre in front
+            # of the robot, its top 0.8 m above the floor; a dropped board comes to rest on it (box-box contacts of the board with the slab)
+            d.table_center[:] = [1.0, 0.0]
+            d.table_top_z = 0.8
         d.obj_z = 0.8 + half[2]
         d.tgt_z = 0.8 + 0.5 * size[2] + half[2]
         d.n_obj_placements = max(int(kw["horizon"] * kw["n_object_placements_sampled_per_100_steps"] / 100), 1)

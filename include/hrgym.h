@@ -199,6 +199,7 @@ typedef struct hrg_model_desc {
   double rcap_r[HRG_NRCAP];
   uint32_t rcap_selfmask[HRG_NRCAP]; /* bit j set: pair (i,j), j>i, is a candidate self-collision pair */
   double table_top_z, table_half[2], floor_z;
+  double table_center[2];        /* x, y of the table's centre (TableArena table_offset: (0, 0) for most tasks, (1.0, 0) for CollaborativeLiftingCart, 284) */
   /* ---- human -------------------------------------------------------------------------------------------- */
   int32_t hb_parent[HRG_NHB];
   int32_t hb_depth[HRG_NHB];
@@ -220,6 +221,8 @@ typedef struct hrg_model_desc {
   double init_noise;            /* robosuite "default" initialization noise magnitude */
   /* ---- shield (synthetic stand-ins for sara-shield's three YAML files) ----------------------------- */
   int32_t shield_type;
+  int32_t ltt_time_sync;        /* 1: the joints of a long-term trajectory arrive together, each stretched to the slowest joint's duration (sara-shield's LongTermPlanner,
+                                 * SURVEY.md B.3); 0: every joint runs its own time-optimal profile (rounds 1-2: A/B of what the synchronisation costs the shield) */
   double v_max_allowed[HRG_NARM], a_max_allowed[HRG_NARM], j_max_allowed[HRG_NARM];
   double v_max_ltt[HRG_NARM], a_max_ltt[HRG_NARM], j_max_ltt[HRG_NARM];
   double path_amax, path_jmax;  /* limits on s'' and s''' of fail-safe / recovery manoeuvres */

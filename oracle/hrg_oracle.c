@@ -506,7 +506,7 @@ static void human_fk(const hrg_model_desc* m, const double* mocap_pos, const dou
  * Long-term trajectory: per joint jerk-limited point-to-point profile from (q0,v0,a0) to (goal,0,0)
  * (role of sara-shield LongTermPlanner behind SafetyShield.newLongTermTrajectory,
  * failsafe_controller.py:300).  Own construction (the planner source is absent): ramp a->0, then
- * S-curve / cruise / S-curve with the cruise velocity found by bisection; joints are not time-synchronised. */
+ * S-curve / cruise / S-curve with the cruise velocity found by a root search; the joints are then time-synchronised to the slowest one (ltt_sync_joint). */
 static int scurve(double va, double vb, double amax, double jmax, double* dur, double* jerk) {
   double d = vb - va, ad = fabs(d), sg = d >= 0 ? 1.0 : -1.0;
   if (ad >= amax * amax / jmax) {
@@ -528,7 +528,9 @@ static double dist_nocruise(double va, double vc, double amax, double jmax) {
   return 0.5 * (va + vc) * scurve_time(vc - va, amax, jmax) + 0.5 * vc * scurve_time(vc, amax, jmax);
 }
 
-static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax) {
+/* what the last three parts of a joint's profile ([S-curve v -> sg w][cruise][S-curve sg w -> 0], segments n0 ..) were planned from: the time synchronisation re-plans them */
+typedef struct { int n0; double v, sg, Dm, vm, w; } ltt_tail;
+static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, double goal, double vmax, double amax, double jmax, ltt_tail* tail) {
   double* dur = L->dur[j];
   double* jerk = L->jerk[j];
   for (int i = 0; i < HRG_LTT_NSEG; i++) { dur[i] = 0; jerk[i] = 0; }
@@ -583,20 +585,67 @@ static void ltt_plan_joint(hrg_ltt* L, int j, double q0, double v0, double a0, d
       if (step <= 4e-16 * (1.0 + fabs(w)) || hi - lo <= 4e-16 * (1.0 + hi)) break;
     }
   }
+  if (tail) { tail->n0 = n; tail->v = v; tail->sg = sg; tail->Dm = Dm; tail->vm = vm; tail->w = w; }
   n += scurve(v, sg * w, amax, jmax, dur + n, jerk + n);
   dur[n] = tc; jerk[n] = 0; n++;
   n += scurve(sg * w, 0, amax, jmax, dur + n, jerk + n);
 }
 
+/* Time synchronisation of a long-term trajectory (sara-shield's LongTermPlanner [UPSTREAM]: the joints are "time-synchronised to the slowest joint", SURVEY.md B.3;
+ * arXiv 2205.06311 section IV): a joint whose own time-optimal profile ends before T keeps its first parts (the ramp of its acceleration to zero, a stop if it moves
+ * away from its goal) and drives the rest at a LOWER cruise speed w, chosen so that it arrives exactly at T.  The duration of the rest,
+ *   g(w) = T1(w - vm) + T2(w) + (Dm - dist_nocruise(vm, w)) / w,
+ * falls monotonically from infinity (w -> 0) to the time-optimal duration (w = the speed planned): Newton on g(w) = Tt with the analytic derivative, safeguarded by the
+ * bracket.  A joint that has to use its whole remaining distance to stop (Dm = its stopping distance) cannot be slowed down and keeps its profile. */
+static void ltt_sync_joint(hrg_ltt* L, int j, double T, double amax, double jmax, const ltt_tail* tl) {
+  double* dur = L->dur[j];
+  double* jerk = L->jerk[j];
+  double tpre = 0, tall = 0;
+  for (int i = 0; i < HRG_LTT_NSEG; i++) { if (i < tl->n0) tpre += dur[i]; tall += dur[i]; }
+  if (!(tall < T - 1e-12) || !(tl->w > 0)) return;
+  const double Tt = T - tpre, vm = tl->vm, Dm = tl->Dm, vtri = amax * amax / jmax;
+  double lo = 0, hi = tl->w;                 /* g(lo) > Tt >= g(hi) */
+  double w = hi * (tall - tpre) / Tt;        /* the duration goes roughly like 1 / w */
+  int found = 0;
+  for (int it = 0; it < 80; it++) {
+    const double d1 = w - vm, T1 = scurve_time(d1, amax, jmax), T2 = scurve_time(w, amax, jmax);
+    const double dnc = 0.5 * (vm + w) * T1 + 0.5 * w * T2, rest = Dm - dnc;
+    const double g = T1 + T2 + rest / w - Tt;
+    if (g == 0) { found = 1; break; }
+    if (g > 0) lo = w; else hi = w;
+    const double sd = d1 >= 0 ? 1.0 : -1.0;
+    const double T1p = sd * (fabs(d1) >= vtri ? 1.0 / amax : (fabs(d1) > 0 ? 1.0 / sqrt(jmax * fabs(d1)) : 0.0));
+    const double T2p = w >= vtri ? 1.0 / amax : (w > 0 ? 1.0 / sqrt(jmax * w) : 0.0);
+    const double dncp = 0.5 * T1 + 0.5 * (vm + w) * T1p + 0.5 * T2 + 0.5 * w * T2p;
+    const double gp = T1p + T2p - dncp / w - rest / (w * w);
+    double nw = gp < 0 ? w - g / gp : 0.5 * (lo + hi);
+    if (!(nw > lo && nw < hi)) nw = 0.5 * (lo + hi);
+    const double step = fabs(nw - w);
+    w = nw;
+    found = 1;
+    if (step <= 4e-16 * (1.0 + w) || hi - lo <= 4e-16 * (1.0 + hi)) break;
+  }
+  if (!found || !(w > 0)) return;
+  const double tc = (Dm - dist_nocruise(vm, w, amax, jmax)) / w;
+  if (!(tc >= 0)) return;                    /* (the whole remaining distance is needed to stop: nothing to stretch) */
+  int n = tl->n0;
+  n += scurve(tl->v, tl->sg * w, amax, jmax, dur + n, jerk + n);
+  dur[n] = tc; jerk[n] = 0; n++;
+  n += scurve(tl->sg * w, 0, amax, jmax, dur + n, jerk + n);
+}
+
 static void ltt_plan(const hrg_model_desc* m, hrg_ltt* L, const double* q0, const double* v0, const double* a0, const double* goal) {
   double T = 0;
+  ltt_tail tail[NARM];
   for (int j = 0; j < NARM; j++) {
-    ltt_plan_joint(L, j, q0[j], v0[j], a0[j], goal[j], m->v_max_ltt[j], m->a_max_ltt[j], m->j_max_ltt[j]);
+    ltt_plan_joint(L, j, q0[j], v0[j], a0[j], goal[j], m->v_max_ltt[j], m->a_max_ltt[j], m->j_max_ltt[j], &tail[j]);
     double t = 0;
     for (int i = 0; i < HRG_LTT_NSEG; i++) t += L->dur[j][i];
     if (t > T) T = t;
   }
   L->T = T;
+  if (m->ltt_time_sync)
+    for (int j = 0; j < NARM; j++) ltt_sync_joint(L, j, T, m->a_max_ltt[j], m->j_max_ltt[j], &tail[j]);
 }
 static void ltt_const(hrg_ltt* L, const double* q) {
   memset(L, 0, sizeof *L);
@@ -954,6 +1003,8 @@ static int cap_box_two(const double* p1, const double* p2, const double* c, cons
   return 1;
 }
 
+typedef struct { double pos[3], n[3], dist; } bb_contact;
+static int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, bb_contact out[4]);
 static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, const hrg_box_state* bx, contact_t* con) {
   double rp1[HRG_NRCAP][3], rp2[HRG_NRCAP][3];
   double Rb[9];
@@ -998,7 +1049,7 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       for (int e = 0; e < 2; e++) {
         const double* p = e ? rp2[i] : rp1[i];
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - m->rcap_r[i] - z0;
-        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.025)) /* end point above the mid-plane of the 0.05 m slab */ continue;
+        if (pl == 0 && !(fabs(p[0] - m->table_center[0]) <= m->table_half[0] && fabs(p[1] - m->table_center[1]) <= m->table_half[1] && p[2] > z0 - 0.025)) /* end point above the mid-plane of the 0.05 m slab */ continue;
         if (dist < 0) {
           double nn[3] = {0, 0, -1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
           EMIT(i, pl ? GEOM_FLOOR : GEOM_TABLE, m->rcap_body[i], -1, dist, nn, pos);
@@ -1034,13 +1085,27 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       v3madd(pos, cs, nn, m->rcap_r[i] + 0.5 * dist);
       EMIT(i, GEOM_BOX, m->rcap_body[i], BODY_BOX, dist, nn, pos);
     }
-    for (int pl = 0; pl < 2; pl++)
+    if (m->task == HRG_TASK_LIFTING) {
+      /* CollaborativeLiftingCart: the 1.0 x 0.4 m board over a table 0.4 m wide (collaborative_lifting_cartesian_env.py:280-284, 742-746) -- board and table top
+       * overlap in a cross, no corner of either lies over the other: box-box contacts (MuJoCo: mjc_BoxBox; here the SAT + clipping of D13) of the board with the
+       * table slab (5 cm thick, TableArena) instead of the corner-against-plane test of the cube tasks */
+      const double pt[3] = {m->table_center[0], m->table_center[1], m->table_top_z - 0.025}, ht[3] = {m->table_half[0], m->table_half[1], 0.025};
+      const double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+      double d2 = 0;
+      for (int a = 0; a < 3; a++) { const double la = fabs(bx->pos[a] - pt[a]) - ht[a]; if (la > 0) d2 += la * la; }
+      if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9)) { /* broadphase: the board's circumsphere against the slab itself */
+        bb_contact bc[4];
+        const int nb = box_box2(pt, Rt, ht, bx->pos, Rx, hb, bc);
+        for (int q = 0; q < nb; q++) EMIT(GEOM_TABLE, GEOM_BOX, -1, BODY_BOX, bc[q].dist, bc[q].n, bc[q].pos);
+      }
+    }
+    for (int pl = m->task == HRG_TASK_LIFTING ? 1 : 0; pl < 2; pl++)
       for (int cn = 0; cn < 8; cn++) {
         double loc[3] = {(cn & 1) ? hb[0] : -hb[0], (cn & 2) ? hb[1] : -hb[1], (cn & 4) ? hb[2] : -hb[2]}, p[3];
         m3mulv(p, Rx, loc);
         v3add(p, p, bx->pos);
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
-        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (pl == 0 && !(fabs(p[0] - m->table_center[0]) <= m->table_half[0] && fabs(p[1] - m->table_center[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
         if (dist < 0) {
           double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
           EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_BOX, -1, BODY_BOX, dist, nn, pos);
@@ -1439,7 +1504,7 @@ static int config_collides(const hrg_model_desc* m, const double* q6) {
     for (int e = 0; e < 2; e++) {
       const double* p = e ? c2[c] : c1[c];
       const double r = rad[c];
-      if (p[2] - r < m->table_top_z + mg && fabs(p[0]) <= m->table_half[0] + 0.5 * mg + r && fabs(p[1]) <= m->table_half[1] + 0.5 * mg + r) return 1 + 16 * c;
+      if (p[2] - r < m->table_top_z + mg && fabs(p[0] - m->table_center[0]) <= m->table_half[0] + 0.5 * mg + r && fabs(p[1] - m->table_center[1]) <= m->table_half[1] + 0.5 * mg + r) return 1 + 16 * c;
       const double dx = p[0] - m->base_pos[0], dy = p[1] - m->base_pos[1];
       if (p[2] - r < m->base_cyl_z && sqrt(dx * dx + dy * dy) < m->base_cyl_r + mg + r) return 2 + 16 * c;
     }
@@ -2208,7 +2273,6 @@ static void stack_animation_time(const hrgo_batch* b, int64_t gid, const hrg_env
 /* near-ties between separating axes / candidate depths are broken towards the earlier one unless the later wins by this margin (1 nm): two nearly
  * parallel cubes keep their reference face while rounding-level differences come and go */
 #define BB_TIE 1e-9
-typedef struct { double pos[3], n[3], dist; } bb_contact;
 static int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, bb_contact out[4]) {
   double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
   v3sub(t, pb, pa);
@@ -2421,7 +2485,7 @@ static int collide_stack(const hrg_model_desc* m, const robot_kin* k, const huma
         m3mulv(p, Rx[c], loc);
         v3add(p, p, sk->pos[c]);
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
-        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (pl == 0 && !(fabs(p[0] - m->table_center[0]) <= m->table_half[0] && fabs(p[1] - m->table_center[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
         if (dist < 0) {
           double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
           EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_CUBE(c), -1, BODY_CUBE(c), dist, nn, pos);
@@ -2980,7 +3044,7 @@ static int collide_hammer(const hrg_model_desc* m, const robot_kin* k, const hum
         m3mulv(p, Rx, loc);
         v3add(p, p, G->c[g]);
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - z0;
-        if (pl == 0 && !(fabs(p[0]) <= m->table_half[0] && fabs(p[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
+        if (pl == 0 && !(fabs(p[0] - m->table_center[0]) <= m->table_half[0] && fabs(p[1] - m->table_center[1]) <= m->table_half[1] && p[2] > z0 - 0.05)) continue;
         if (dist < 0) {
           double nn[3] = {0, 0, 1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
           EMIT(pl ? GEOM_FLOOR : GEOM_TABLE, GEOM_HM(g), -1, BODY_HM(HM_GEOM_BODY[g]), dist, nn, pos);

@@ -87,6 +87,33 @@ def test_holding_the_board_pays_the_balance_reward_and_losing_it_ends_the_episod
     B.close()
 
 
+def test_a_released_board_comes_to_rest_on_the_table():
+    """The table of the lifting task (TableArena: 0.4 x 1.5 m, its top 0.8 m high, one metre in front of the robot: collaborative_lifting_cartesian_env.py:280-284,
+    742-746) lies under the board's middle.  Let go by the human (connects off) and by the robot (gripper opened), the board -- 9 cm above it at the reset --
+    drops onto the slab and stays there: box-box contacts between board and table (they overlap in a cross: no corner of one lies over the other), not the floor."""
+    B, d = _oracle(1, dict(seed=3, horizon=400, done_at_collision=False), _clips())
+    B.reset()
+    assert list(d.table_center) == [1.0, 0.0] and list(d.table_half) == [0.2, 0.75] and d.table_top_z == 0.8
+    assert B.get_box(0).pos[2] - d.box_half[2] > d.table_top_z + 0.05
+    bx = B.get_box(0)
+    bx.weld_active = 0
+    B.set_box(0, bx)
+    G_TABLE, G_BOX = 10 + 24, 10 + 24 + 2
+    zs, on_table = [], 0
+    for k in range(40):
+        a = np.zeros((1, 7)); a[0, 6] = -1.0                           # open the gripper
+        o, r, dn, i = B.step(a)
+        if dn[0]:
+            break                                                      # (the episode ends a few steps after the grip is lost: _check_done, 509-561)
+        pairs, n = B.contacts()
+        on_table += int(any(tuple(p) == (G_TABLE, G_BOX) for p in pairs[0][:n[0]].tolist()))
+        zs.append(B.get_box(0).pos[2])
+    assert k >= 5 and on_table >= 3
+    assert d.table_top_z + d.box_half[2] - 0.005 < zs[-1] < d.table_top_z + d.box_half[2] + 0.03      # on the slab (its robot-side end still leans on a finger), not on the floor
+    assert abs(zs[-1] - zs[-2]) < 2e-3
+    B.close()
+
+
 def test_animation_complete_is_the_success_and_starts_the_next_task():
     nominal = lifting_hands_nominal(hrg.build_model_desc(None, env_id=ENV))
     clips = hrg.synthetic_clips(2, fps=20.0, lifting=nominal, lift_height=0.1, min_frames=20, max_frames=24)   # 1.0-1.2 s, a 10 cm lift: over after 10-12 policy steps

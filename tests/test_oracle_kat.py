@@ -163,6 +163,42 @@ def test_long_term_trajectory_end_conditions_and_limits(oracle_lib, seed):
             prev = out.copy()
 
 
+@pytest.mark.parametrize("seed", range(4))
+def test_long_term_trajectory_is_time_synchronised(oracle_lib, seed):
+    """sara-shield's LongTermPlanner synchronises the joints of a long-term trajectory to the slowest one: every joint that moves arrives at its goal
+    at the same instant L.T (here: within 1e-9 s, far inside one 4 ms sample) -- from rest, with initial velocities, with initial accelerations; a joint already at
+    its goal stays there.  Without the synchronisation (shield_params ltt_time_sync=False, the planner of rounds 1-2) the joints arrive one by one."""
+    rng = np.random.RandomState(100 + seed)
+    for trial in range(50):
+        q0 = rng.uniform(-2, 2, NARM)
+        v0 = rng.uniform(-1, 1, NARM) * (seed > 0)
+        a0 = rng.uniform(-2, 2, NARM) * (seed > 1)
+        goal = rng.uniform(-2.5, 2.5, NARM)
+        if seed == 3:
+            goal[2] = q0[2]; v0[2] = a0[2] = 0.0     # a joint that is where it has to be
+        ends = {}
+        for sync in (True, False):
+            d = hrg.build_model_desc(shield_params=dict(ltt_time_sync=sync))
+            L = LTT()
+            oracle_lib.hrgo_test_ltt(ctypes.byref(d), _p(q0), _p(v0), _p(a0), _p(goal), ctypes.byref(L))
+            ends[sync] = (np.array([sum(L.dur[j][:]) for j in range(NARM)]), L.T)
+            out = np.zeros(3)
+            for j in range(NARM):
+                assert all(x >= 0 for x in L.dur[j][:])
+                oracle_lib.hrgo_test_ltt_eval(ctypes.byref(L), j, float(L.T), _p(out))
+                np.testing.assert_allclose(out, [goal[j], 0, 0], atol=1e-9)
+                for sx in np.linspace(0, L.T, 60):   # the stretched profiles stay inside the planner's limits
+                    oracle_lib.hrgo_test_ltt_eval(ctypes.byref(L), j, float(sx), _p(out))
+                    assert abs(out[2]) <= max(d.a_max_ltt[j], abs(a0[j])) + 1e-9
+                    assert abs(out[1]) <= max(d.v_max_ltt[j], abs(v0[j]) + a0[j] ** 2 / (2 * d.j_max_ltt[j])) + 1e-9
+        (t_sync, T_sync), (t_own, T_own) = ends[True], ends[False]
+        assert T_sync == pytest.approx(T_own, abs=1e-12)                       # the slowest joint sets the duration either way
+        moving = t_own > 0
+        assert np.all(np.abs(t_sync[moving] - T_sync) < 1e-9), (t_sync, T_sync)
+        assert np.all(t_sync[~moving] == 0)
+        assert t_own[moving].max() - t_own[moving].min() > 1e-3                # (unsynchronised: they do not)
+
+
 @pytest.mark.parametrize("v0,a0,ve", [(1.0, 0.0, 0.0), (0.0, 0.0, 1.0), (0.6, 3.0, 0.0), (0.4, -5.0, 1.0), (0.9, 7.9, 1.0), (0.0, 0.0, 0.0)])
 def test_path_profile_reaches_target_velocity(oracle_lib, v0, a0, ve):
     d = hrg.build_model_desc()
