@@ -267,7 +267,7 @@ def spawn_ranks(n, argv, script=None, deadline_s=3000.0, poll_s=0.2):
         raise
 
 
-def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None):
+def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None, robot_geometry="capsule"):
     """The benchmark's workloads by name (BASELINE.json configs): env kwargs as the reference's training configs set them, envs per GPU, wrappers.
     tests/test_bench_state_gpu.py builds its batches through this function and `make_bench_batch`, so what it compares with the oracle is what is timed."""
     pick_place = env != "ReachHuman"   # every other task carries the manipulation object's state block
@@ -289,7 +289,9 @@ def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None):
                           reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
     n = envs_per_gpu or (8192 if env == "PickPlaceHumanCart" else ENVS_PER_GPU)
     wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if ik else {}
-    return dict(env=env, shield=shield, ik=bool(ik), n=n, env_kwargs=env_kwargs, wrappers=wrappers, pick_place=pick_place)
+    if robot_geometry != "capsule":   # arm links as the convex hulls of their meshes: passed on to build_model_desc like the wrappers
+        wrappers["robot_geometry"] = robot_geometry
+    return dict(env=env, shield=shield, ik=bool(ik), n=n, env_kwargs=env_kwargs, wrappers=wrappers, pick_place=pick_place, robot_geometry=robot_geometry)
 
 
 def make_bench_batch(W, rank=0, local_rank=0, stagger=True):
@@ -347,6 +349,8 @@ def main():
     ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
                     "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--robot-geometry", default="capsule", choices=["capsule", "hull"], help="collision geometry of the arm links: bounding capsules (default) or the convex "
+                    "hulls of the link meshes (ReachHuman only; DESIGN.md D3); named in config.robot_geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=10.0, help="seconds of CPU work for the all-cores leg of cpu_baseline (the 16-thread leg gets 0.6 x)")
     ap.add_argument("--pmc-json", default=DEFAULT_PMC, help="committed PMC capture of this command (tools/profile_capture.sh): source of roofline.traffic / valu_* / fp64_*")
@@ -390,7 +394,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    W = bench_workload(args.env, args.shield, args.ik, args.envs_per_gpu)
+    W = bench_workload(args.env, args.shield, args.ik, args.envs_per_gpu, args.robot_geometry)
     args.shield, n, env_kwargs, wrappers, pick_place = W["shield"], W["n"], W["env_kwargs"], W["wrappers"], W["pick_place"]
     G, desc, mixed_tasks, staggered = make_bench_batch(W, rank=rank, local_rank=local_rank, stagger=not args.no_stagger)
     dev = G.device
@@ -453,11 +457,11 @@ def main():
             kernel_ms = 1e3 * elapsed / args.steps
         achieved = per_env * n / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
         kernel_name = "all step kernels, concurrent (wall time per step)" if mixed_tasks else (
-            OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else "hrg_step_kernel"))
+            OTHER_TASKS[args.env][1] if args.env in OTHER_TASKS else ("hrg_step_kernel_box" if pick_place else ("hrg_step_kernel_hull" if args.robot_geometry == "hull" else "hrg_step_kernel")))
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "traffic_source": None, "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_env * n}
         # PMC figures: from the committed capture of the default workload's kernel (never from this run: a counter pass perturbs the timing)
-        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib
+        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib and args.robot_geometry == "capsule"
         if default_workload:
             try:
                 with open(args.pmc_json) as f:
@@ -488,10 +492,10 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": f"{args.env}, {n} envs/GPU, shield {args.shield}, 25 x 4 ms cycles/step, "
+            "config": {"workload": f"{args.env}, {n} envs/GPU, shield {args.shield}, " + ("arm links as convex hulls, " if args.robot_geometry == "hull" else "") + "25 x 4 ms cycles/step, "
                                    + ("Cartesian random actions via IK + collision prevention" if args.ik else "random actions U(-1,1)^7")
                                    + f", 13 synthetic clips, auto-reset, steady state ({preroll}-step pre-roll)",
-                       "envs_per_gpu": n, "shield_type": args.shield, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
+                       "envs_per_gpu": n, "shield_type": args.shield, "robot_geometry": args.robot_geometry, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
                        "preroll_steps": preroll, "episode_phases_staggered": staggered,
                        "parallelism": f"env-sharded x{world}" + (", 1 RCCL all-gather/step" + ("" if args.gather_mode == "serial" else " on a side stream") if publish is not None else "")},
             "substeps_per_s": world * n * args.steps * int(desc.n_cycles) / elapsed,

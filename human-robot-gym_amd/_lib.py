@@ -18,6 +18,7 @@ SRC_HO = os.path.join(_HERE, "csrc", "hrgym_handover.hip")   # ... and once more
 SRC_LIFT = os.path.join(_HERE, "csrc", "hrgym_lift.hip")     # ... and with the connect equalities / task logic of CollaborativeLiftingCart
 SRC_STACK = os.path.join(_HERE, "csrc", "hrgym_stack.hip")   # ... and the four-cube system of CollaborativeStackingCart
 SRC_HAMMER = os.path.join(_HERE, "csrc", "hrgym_hammer.hip")  # ... and board + nail + hammer of CollaborativeHammeringCart
+SRC_HULLS = os.path.join(_HERE, "csrc", "hrgym_hulls.hip")    # ... and the ReachHuman kernels with the arm links' convex hulls as collision geometry
 
 EXPORTS = [
     "hrg_last_error", "hrg_version", "hrg_state_bytes", "hrg_batch_create", "hrg_batch_destroy", "hrg_batch_reset",
@@ -30,7 +31,7 @@ EXPORTS = [
 
 def build_library(force=False, verbose=False):
     """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    deps = [SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h")] + [
+    deps = [SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER, SRC_HULLS] + [os.path.join(_HERE, "csrc", f) for f in ("hrgym_device.h", "hrgym_kernels.h", "hrgym_hull.h")] + [
         os.path.join(os.path.dirname(_HERE), "include", f) for f in ("hrgym.h", "hrgym_state.h")]
     if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps):
         return LIB_PATH
@@ -38,7 +39,7 @@ def build_library(force=False, verbose=False):
     # IEEE-exact sequence with scaling and fix-up (12+): 140 division sites in the ReachHuman kernel alone, 5 % of its vector instructions.  The host side and the
     # oracle keep IEEE arithmetic; the parity tolerance (1e-5 relative) is eleven orders of magnitude above the difference.
     cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", "-o", LIB_PATH,
-           SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER]
+           SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER, SRC_HULLS]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

@@ -37,9 +37,13 @@
 #ifndef HRG_STACK
 #define HRG_STACK 0   // HRG_STACK=1 (hrgym_stack.hip, HRG_BOX=0): CollaborativeStackingCart -- four free cubes, box-box contacts, two welds; its own collision tail and solver
 #endif
+#ifndef HRG_HULLS
+#define HRG_HULLS 0   // HRG_HULLS=1 (hrgym_hulls.hip, ReachHuman): the arm links collide as the convex hulls of their meshes (hrg_model_desc.robot_hulls; hrgym_hull.h)
+#endif
 #ifndef HRG_HAMMER
 #define HRG_HAMMER 0  // HRG_HAMMER=1 (hrgym_hammer.hip, HRG_BOX=0): CollaborativeHammeringCart -- board + nail + hammer, a 24-DoF system in three 8-wide blocks; its own collision tail and solver
 #endif
+#define HRG_BASE_TU (!HRG_BOX && !HRG_STACK && !HRG_HAMMER && !HRG_HULLS)   // hrgym_hip.hip itself: the ReachHuman kernels, the pre-check kernel and the host side (C ABI)
 #define NVT HRG_NVT
 #if HRG_HAMMER
 #define NVS HRG_NV_HAMMER       // robot tree | board + nail (+ pad) | hammer (+ 2 pads)
@@ -136,6 +140,7 @@ struct DevModel {
   int32_t chk_i[32], chk_j[32];
   // animation clips (frames in device memory)
   hrg_clip_table clips;
+  const double* hull_dev;    // hull vertices of the arm links in device memory (m.robot_hulls; m.hull_verts is the creator's host pointer)
 };
 
 struct Contact {
@@ -169,6 +174,7 @@ struct Contact {
 
 // per-workgroup (= per-env) LDS image.  Sized to <= 10 KB so that 16 envs (4 waves/SIMD) are resident per CU:
 // 4096 envs on 256 CUs then run in one round.  Phase-local scratch shares one union.
+struct GjkLds { double y[4][3], a[4][3], b[4][3], l[4], lam[4]; int ia[4], ib[4]; };   // GJK simplex: points of the Minkowski difference, their witnesses on the hull / the segment, weights
 struct Lds {
   hrg_env_state st;
   // robot tree at the simulation state (live across the whole cycle)
@@ -219,6 +225,9 @@ struct Lds {
       double hcap[HRG_NHB][6], rcapw[HRG_NRCAP][6];
       int hnear[HRG_NHB];                // human capsules whose bounding sphere comes near the robot (the pair rounds of collide run over these)
       double rcen[HRG_NRCAP][3];         // capsule centres: collide -> classify (the speed of a robot geom at a human contact)
+#if HRG_HULLS
+      GjkLds gjk;                        // the simplex of a hull query (hrgym_hull.h)
+#endif
 #if HRG_STACK
       double cR[NCUBE][9];               // cube rotation matrices of the substep's narrowphase
 #endif

@@ -2863,6 +2863,10 @@ typedef hrg_stack_state ObjState;   // the per-env object block this variant str
 #define hrg_step_kernel hrg_step_kernel_hammer
 #define hrg_reset_kernel hrg_reset_kernel_hammer
 typedef hrg_hammer_state ObjState;
+#elif HRG_HULLS
+#define hrg_step_kernel hrg_step_kernel_hull
+#define hrg_reset_kernel hrg_reset_kernel_hull
+typedef hrg_box_state ObjState;     // (ReachHuman streams no object block: the pointer is null)
 #else
 typedef hrg_box_state ObjState;
 #endif
@@ -2992,7 +2996,7 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_reset
 #endif
 }
 
-#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#if HRG_BASE_TU
 // HumanEnv.check_collision_action for every env: goal configuration of the action at the env's current joint angles -> pre-check capsule model.
 // The check reads the robot part of the state only, so one kernel serves every task.
 __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_check_kernel(const DevModel* __restrict__ dm_, const hrg_env_state* __restrict__ states, const double* __restrict__ actions,
@@ -3019,7 +3023,7 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_step(int n_
                                                                            float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                             int64_t env_id0, hrg_box_state* boxes);
-#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#if HRG_BASE_TU
 // ... of the stacking variant (hrgym_stack.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                              float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -3027,7 +3031,7 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_step(int 
 extern "C" __attribute__((visibility("hidden"))) void hrg_stack_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                               int64_t env_id0, hrg_stack_state* stacks);
 #endif
-#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#if HRG_BASE_TU
 // ... of the hammering variant (hrgym_hammer.hip)
 extern "C" __attribute__((visibility("hidden"))) void hrg_hammer_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
                                                                               float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
@@ -3046,6 +3050,23 @@ extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_step(int n
                                                                             float* scratch_obs, hrg_box_state* boxes, StepOrder ord);
 extern "C" __attribute__((visibility("hidden"))) void hrg_lift_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
                                                                              int64_t env_id0, hrg_box_state* boxes);
+#endif
+#if HRG_BASE_TU
+// ... of the hull variant of the ReachHuman kernels (hrgym_hulls.hip)
+extern "C" __attribute__((visibility("hidden"))) void hrg_hull_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs,
+                                                                            float* reward, uint8_t* done, int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0,
+                                                                            float* scratch_obs, StepOrder ord);
+extern "C" __attribute__((visibility("hidden"))) void hrg_hull_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs,
+                                                                             int64_t env_id0);
+#endif
+#if HRG_HULLS
+extern "C" void hrg_hull_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
+                                     int32_t* info, double* dbg_r, double* dbg_h, int32_t* dbg_nh, int64_t env_id0, float* scratch_obs, StepOrder ord) {
+  hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, actions, obs, term_obs, reward, done, info, dbg_r, dbg_h, dbg_nh, env_id0, scratch_obs, (ObjState*)nullptr, n_envs, ord);
+}
+extern "C" void hrg_hull_launch_reset(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, const uint8_t* mask, float* obs, int64_t env_id0) {
+  hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(n_envs), 0, st, dm, states, mask, obs, env_id0, (ObjState*)nullptr, n_envs);
+}
 #endif
 #if HRG_HAMMER
 extern "C" void hrg_hammer_launch_step(int n_envs, hipStream_t st, const DevModel* dm, hrg_env_state* states, double* actions, float* obs, float* term_obs, float* reward, uint8_t* done,
@@ -3086,8 +3107,10 @@ extern "C" void hrg_box_launch_reset(int n_envs, hipStream_t st, const DevModel*
 #define hrg_debug_stamps hrg_debug_stamps_lift
 #elif HRG_BOX
 #define hrg_debug_stamps hrg_debug_stamps_box
+#elif HRG_HULLS
+#define hrg_debug_stamps hrg_debug_stamps_hull
 #endif
-#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#if HRG_BASE_TU
 // waves that live longer than `thresh` shader cycles are also summed into a second set of accumulators: out[0..31] phase sums, out[32] their number, out[33] lifetime sum
 extern "C" int hrg_debug_stamps_slow(double* out, unsigned long long thresh, int reset) {
   unsigned long long h[34];
@@ -3120,6 +3143,9 @@ extern "C" int hrg_debug_stamps(double* out, int reset) {
 #elif HRG_BOX
 #define hrg_debug_envacc hrg_debug_envacc_box
 #define hrg_debug_envcyc hrg_debug_envcyc_box
+#elif HRG_HULLS
+#define hrg_debug_envacc hrg_debug_envacc_hull
+#define hrg_debug_envcyc hrg_debug_envcyc_hull
 #endif
 #if 1
 extern "C" int hrg_debug_envacc(unsigned long long* out, int n) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_envacc), sizeof(unsigned long long) * 32 * n) == hipSuccess ? 0 : -1; }
@@ -3127,7 +3153,7 @@ extern "C" int hrg_debug_envcyc(unsigned long long* out, int n) { return hipMemc
 #endif
 #endif
 
-#if !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#if HRG_BASE_TU
 
 // ================================================================================================ host side
 static thread_local std::string g_err;
@@ -3144,6 +3170,8 @@ struct hrg_batch {
   int64_t env_id0 = 0;
   DevModel* d_model = nullptr;
   double* d_frames = nullptr;
+  double* d_hull = nullptr;            // hull vertices of the arm links (robot_hulls)
+  bool hulls = false;                  // the hull variant of the ReachHuman kernels steps this batch (hrgym_hulls.hip)
   hrg_env_state* d_states = nullptr;
   double* d_rcaps = nullptr;
   double* d_hcaps = nullptr;
@@ -3338,6 +3366,18 @@ int hrg_batch_create(const hrg_model_desc* desc, const hrg_clip_table* clips, in
   HIPCHK_C(hipMemcpy(b->d_frames, clips->frames, fbytes, hipMemcpyHostToDevice));
   hm->clips = *clips;
   hm->clips.frames = b->d_frames;
+  hm->hull_dev = nullptr;
+  if (desc->robot_hulls) {   // convex hulls of the arm links: the vertex table goes to device memory like the clip frames
+    if (desc->task != HRG_TASK_REACH) return bail(HRG_ERR_UNSUPPORTED, "robot_hulls: the hull variant of the step kernel exists for ReachHuman (the lean model) so far");
+    b->hulls = true;
+    if (!desc->hull_verts || desc->hull_off[0] != 0) return bail(HRG_ERR_INVALID, "robot_hulls: hull_verts / hull_off missing");
+    for (int h = 0; h < HRG_NHULL; h++)
+      if (!(desc->hull_off[h + 1] > desc->hull_off[h] + 3 && desc->hull_off[h + 1] <= 1000000)) return bail(HRG_ERR_INVALID, "robot_hulls: every hull needs at least four vertices");
+    const size_t hbytes = sizeof(double) * 3 * (size_t)desc->hull_off[HRG_NHULL];
+    HIPCHK_C(hipMalloc(&b->d_hull, hbytes));
+    HIPCHK_C(hipMemcpy(b->d_hull, desc->hull_verts, hbytes, hipMemcpyHostToDevice));
+    hm->hull_dev = b->d_hull;
+  }
   HIPCHK_C(hipMalloc(&b->d_model, sizeof(DevModel)));
   HIPCHK_C(hipMemcpy(b->d_model, hm, sizeof(DevModel), hipMemcpyHostToDevice));
   // ---- state ----
@@ -3380,7 +3420,7 @@ void hrg_batch_destroy(hrg_batch* b) {
   hipDeviceSynchronize();
   for (auto& p : b->events) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
   for (auto& p : b->pool) { hipEventDestroy(p.first); hipEventDestroy(p.second); }
-  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks); hipFree(b->d_hammers); hipFree(b->d_order);
+  hipFree(b->d_model); hipFree(b->d_frames); hipFree(b->d_hull); hipFree(b->d_states); hipFree(b->d_rcaps); hipFree(b->d_hcaps); hipFree(b->d_nh); hipFree(b->d_scratch_obs); hipFree(b->d_boxes); hipFree(b->d_stacks); hipFree(b->d_hammers); hipFree(b->d_order);
   delete b;
 }
 
@@ -3392,6 +3432,7 @@ int hrg_batch_reset(hrg_batch* b, const uint8_t* mask_dev, float* obs_dev, void*
   else if (b->task == HRG_TASK_LIFTING) hrg_lift_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (HRG_IS_HANDOVER(b->task)) hrg_ho_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
   else if (b->task != HRG_TASK_REACH) hrg_box_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes);
+  else if (b->hulls) hrg_hull_launch_reset(b->n_envs, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0);
   else hipLaunchKernelGGL(hrg_reset_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, (hipStream_t)stream, b->d_model, b->d_states, mask_dev, obs_dev, b->env_id0, b->d_boxes, b->n_envs);
   HIPCHK(hipGetLastError());
   return HRG_OK;
@@ -3433,6 +3474,9 @@ int hrg_batch_step(hrg_batch* b, double* actions_dev, float* obs_dev, float* ter
   else if (b->task != HRG_TASK_REACH)
     hrg_box_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, ord);
+  else if (b->hulls)
+    hrg_hull_launch_step(b->n_envs, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
+                         b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, ord);
   else
     hipLaunchKernelGGL(hrg_step_kernel, HRG_LAUNCH_DIMS(b->n_envs), 0, st, b->d_model, b->d_states, actions_dev, obs_dev, term_obs_dev, reward_dev, done_dev, info_dev,
                        b->taps ? b->d_rcaps : nullptr, b->taps ? b->d_hcaps : nullptr, b->taps ? b->d_nh : nullptr, b->env_id0, b->d_scratch_obs, b->d_boxes, b->n_envs, ord);
@@ -3598,4 +3642,4 @@ int hrg_batch_kernel_time(hrg_batch* b, double* avg_ms, int64_t* n_launches) {
 }
 
 } // extern "C"
-#endif // !HRG_BOX && !HRG_STACK && !HRG_HAMMER
+#endif // HRG_BASE_TU

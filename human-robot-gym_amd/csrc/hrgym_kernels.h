@@ -2,6 +2,9 @@
 // Reference call sites are cited per phase (paths relative to the reference root, human_robot_gym/...).
 #pragma once
 #include "hrgym_device.h"
+#if HRG_HULLS
+#include "hrgym_hull.h"
+#endif
 
 // ================================================================================================ robot tree
 // Chain kinematics for THREE configurations at once (lanes 0,1,2): 0 = shield's current commanded motion,
@@ -1340,6 +1343,51 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         }
       }
     }
+#if HRG_HULLS
+    // hrg_model_desc.robot_hulls: the capsule tests above are the BROADPHASE of the arm links (geoms 0 .. 6).  A pair that passed -- link against a human capsule
+    // or against the table / floor plane -- now runs the narrowphase of the link's CONVEX HULL before it is reported (oracle: collide, robot_hulls): distance of
+    // the hull to the capsule's axis minus its radius, normal along the witness points, position half way between the two surfaces (an axis that pierces the hull
+    // keeps the capsule contact); the hull's lowest point under a plane, one contact per link and plane (the capsule has one per end point).  A hull that does
+    // not reach the other geom drops the pair.  One pair at a time in lane (= pair) order, the whole wave on the hull's support mappings; the lane that owns the
+    // pair takes the result into its registers.
+    if (m.robot_hulls) {
+      uint64_t todo = __ballot(hit && c.g1 < HRG_NHULL && c.g2 >= GEOM_HUMAN0);
+      int last_plane = -1;
+      while (todo) {
+        const int src = __ffsll((unsigned long long)todo) - 1;
+        todo &= todo - 1;
+        const int g1 = __builtin_amdgcn_readlane(c.g1, src), g2 = __builtin_amdgcn_readlane(c.g2, src);
+        const int lb = m.rcap_body[g1];
+        const HullRef H = {dm_->hull_dev + 3 * m.hull_off[g1], m.hull_off[g1 + 1] - m.hull_off[g1], lb < 0 ? dm_->Rbase : L.kR[lb], lb < 0 ? dm_->m.base_pos : L.kp[lb]};
+        if (g2 < GEOM_TABLE) {
+          const int hb = g2 - GEOM_HUMAN0;
+          double wa[3], wb[3];
+          const double dh = gjk_hull_segment_wave(H, &L.hcap[hb][0], &L.hcap[hb][3], wa, wb);
+          if (dh > 1e-9 && lane == src) {
+            const double dist = dh - m.hcap_r[hb];
+            if (!(dist < m.contact_margin_human)) hit = false;
+            else {
+              for (int a = 0; a < 3; a++) { c.n[a] = (wb[a] - wa[a]) / dh; c.pos[a] = wa[a] + c.n[a] * (0.5 * dist); }
+              c.dist = dist;
+            }
+          }
+        } else {
+          const int key = 2 * g1 + (g2 == GEOM_FLOOR ? 1 : 0);
+          if (key == last_plane) { if (lane == src) hit = false; continue; }   // the capsule's second end point: the hull has one contact with the plane
+          last_plane = key;
+          double low[3];
+          hull_lowest_wave(H, low);
+          const double z0 = g2 == GEOM_FLOOR ? m.floor_z : m.table_top_z, dist = low[2] - z0;
+          bool ok = dist < 0;
+          if (g2 == GEOM_TABLE) ok = ok && fabs(low[0] - m.table_center[0]) <= m.table_half[0] && fabs(low[1] - m.table_center[1]) <= m.table_half[1] && low[2] > z0 - 0.025;
+          if (lane == src) {
+            if (!ok) hit = false;
+            else { c.pos[0] = low[0]; c.pos[1] = low[1]; c.pos[2] = z0 + 0.5 * dist; c.dist = dist; }
+          }
+        }
+      }
+    }
+#endif
     const uint64_t mask = __ballot(hit);
     if (hit) {
       const int idx = base + __popcll(mask & lt);

@@ -9,6 +9,7 @@ here: the RethinkGripper/RethinkMount geometry [robosuite 1.
 defaults, and the three sara-shield YAML files (robot/trajectory/mocap parameters).
 """
 import json
+import ctypes
 import math
 import os
 
@@ -331,8 +332,14 @@ def _check_env_kwargs(env_id, known, given):
         raise NotImplementedError(f"{env_id}: unknown env kwarg {k!r} (known: {sorted(known)})")
 
 
+def load_robot_hulls():
+    """(verts [N, 3] float64 C-contiguous, offsets [8] int32): convex hulls of the seven arm collision meshes, compiled by tools/compile_model.py."""
+    with np.load(os.path.join(_ASSETS, "schunk_hulls.npz")) as z:
+        return np.ascontiguousarray(z["verts"], np.float64), np.ascontiguousarray(z["offsets"], np.int32)
+
+
 def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None, collision_prevention=None, goal_check=True,
-                     env_id="ReachHuman", ik_position_delta=None, reach_box=False):
+                     env_id="ReachHuman", ik_position_delta=None, reach_box=False, robot_geometry="capsule"):
     """Return a filled `ModelDesc` for `env_id` ("ReachHuman" or "PickPlaceHumanCart") on the Schunk arm.
 
     `env_kwargs` takes the same keys as the reference's environment config
@@ -342,7 +349,9 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     `reach_box=True` (ReachHuman only) adds the task's free `smallBox` object (reach_human_env.py:573-579) and steps the task with the cube kernel; the default
     is the lean model without it (the box is not observed and only matters when the arm happens to hit it).
     `ik_position_delta` takes the keys of config/wrappers/ik_position_delta/*.yaml (action_limit, x_output_max,
-    x_position_limits, residual_threshold, max_iter): actions become [dx, dy, dz, gripper]; None = joint-space actions."""
+    x_position_limits, residual_threshold, max_iter): actions become [dx, dy, dz, gripper]; None = joint-space actions.
+    `robot_geometry`: "capsule" = every arm link collides as the bounding capsule of its mesh; "hull" = as the convex hull of its mesh
+    (what MuJoCo makes of a mesh geom) against the human's capsules and the table / floor planes, the capsule being the broadphase."""
     if env_id not in ENV_DEFAULTS:
         raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)}")
     kw = dict(ENV_DEFAULTS[env_id])
@@ -718,6 +727,15 @@ def build_model_desc(env_kwargs=None, n_clips=1, shield_params=None, assets=None
     R_init, _ = robot_fk_numpy(d, np.concatenate([np.asarray(d.init_qpos[:]), np.zeros(NV - NARM)]))
     d.ik_target_rot[:] = R_init[NARM - 1].reshape(-1).tolist()      # orientation at init_qpos, ik_position_delta_wrapper.py:74-82
     d.seed = int(kw["seed"]) & 0xFFFFFFFFFFFFFFFF
+    if robot_geometry not in ("capsule", "hull"):
+        raise ValueError(f"robot_geometry {robot_geometry!r}: 'capsule' or 'hull'")
+    if robot_geometry == "hull":
+        hv, ho = load_robot_hulls()
+        assert len(ho) == CONST["HRG_NHULL"] + 1
+        d.robot_hulls = 1
+        d.hull_off[:] = ho.tolist()
+        d.hull_verts = hv.ctypes.data_as(ctypes.POINTER(ctypes.c_double))
+        d._hull_keep = hv   # the desc points into this array: it lives as long as the desc
     return d
 
 

@@ -255,7 +255,7 @@ class HipVecEnv(_VecEnvBase):
 
     def __init__(self, n_envs=1, env_id="ReachHuman", env_kwargs=None, obs_keys=None, seed=None, clips=None,
                  device=0, env_id0=0, backend=None, info_dicts=True, collision_prevention=None, goal_check=True, ik_position_delta=None,
-                 expert_obs_keys=None, goal_env=False, obs_norm=None, monitor_dir=None, monitor_kwargs=None, reach_box=False):
+                 expert_obs_keys=None, goal_env=False, obs_norm=None, monitor_dir=None, monitor_kwargs=None, reach_box=False, robot_geometry="capsule"):
         if env_id not in ENV_DEFAULTS:
             raise NotImplementedError(f"env_id {env_id!r}: the HIP stepper covers {sorted(ENV_DEFAULTS)} (DESIGN.md §6)")
         self.env_id = env_id
@@ -298,8 +298,9 @@ class HipVecEnv(_VecEnvBase):
         # [dx, dy, dz, gripper] (IKPositionDeltaWrapper, wrappers/ik_position_delta_wrapper.py), converted in the kernel
         self._cp, self._goal_check, self._ik = collision_prevention, goal_check, ik_position_delta
         self._reach_box = bool(reach_box)   # ReachHuman with its free smallBox object (stepped by the cube kernel); default: the lean model
+        self._robot_geometry = robot_geometry   # "capsule" (default) | "hull": the arm links collide as the convex hulls of their meshes (ReachHuman only)
         self._desc = build_model_desc(kw, n_clips=self._clips.n_clips, collision_prevention=collision_prevention, goal_check=goal_check, env_id=env_id,
-                                      ik_position_delta=ik_position_delta, reach_box=self._reach_box)
+                                      ik_position_delta=ik_position_delta, reach_box=self._reach_box, robot_geometry=robot_geometry)
         self._device, self._env_id0 = device, env_id0
         if backend is not None and (isinstance(backend, type) or not hasattr(backend, "step_async")):   # a factory (desc, clips, n_envs, env_id0) -> backend: the caller cannot build the
             backend = backend(self._desc, self._clips, n_envs, env_id0)    # backend itself when the model description is composed here (create_training_vec_env)
@@ -446,7 +447,7 @@ class HipVecEnv(_VecEnvBase):
             return [None] * self.num_envs
         self.env_kwargs["seed"] = int(seed)
         self._desc = build_model_desc(self.env_kwargs, n_clips=self._clips.n_clips, collision_prevention=self._cp, goal_check=self._goal_check,
-                                      env_id=self.env_id, ik_position_delta=self._ik, reach_box=self._reach_box)
+                                      env_id=self.env_id, ik_position_delta=self._ik, reach_box=self._reach_box, robot_geometry=self._robot_geometry)
         if isinstance(self._backend, _TorchBackend):
             self._backend.close()
             self._backend = _TorchBackend(self._desc, self._clips, self.num_envs, self._env_id0, self._device)

@@ -52,6 +52,7 @@ extern "C" {
 #define HRG_NHJ 23        /* measured human joints (models/objects/human/human.py:57-81) */
 #define HRG_NHQ 69        /* human hinge DoF = 23 x 3 */
 #define HRG_NRCAP 10      /* robot collision capsules: link0..link6, gripper base, 2 fingers */
+#define HRG_NHULL 7         /* arm links with a mesh collision geom: link0 .. link6 = robot capsules 0 .. 6 (robot.xml:29-55) */
 #define HRG_NSHIELD_RCAP 7 /* robot capsules the shield tracks: 6 links + gripper */
 #define HRG_NBODYPART_MAX 20 /* human body parts (capsule between two measured joints) */
 #define HRG_NEXTREMITY_MAX 4 /* POS-model extremities (ball at proximal joint) */
@@ -328,6 +329,14 @@ typedef struct hrg_model_desc {
   double noslip_scale;            /* 1 / (stat.meaninertia * nv): the scale of that improvement (mean diagonal of M at qpos0 over the stepper's real DoF) */
   int32_t gripper_controllable;   /* False: the gripper action is replaced by 'close' (486-487) */
   int32_t noslip_iterations;      /* opt.noslip_iterations: sweeps of the pass at most; 0 = off (every task but CollaborativeHammeringCart) */
+  /* ---- collision geometry of the seven arm links (robot.xml:29-55: mesh geoms, which MuJoCo convexifies at compile time) ----
+   * robot_hulls = 1: contacts of an arm link with the human's capsules and with the table / floor planes are those of the link's CONVEX HULL (support mapping
+   * over its vertices: GJK distance to a capsule's axis, deepest vertex under a plane); the link's bounding capsule is then only the broadphase.  0: the bounding
+   * capsule itself is the collision geom (rounds 1-2).  Hull vertices: body frame, hull h = vertices hull_off[h] .. hull_off[h + 1] - 1 of
+   * hull_verts[.][3] (host memory, copied at create like the clip frames; compiled from the STL files by tools/compile_model.py). */
+  int32_t robot_hulls;
+  int32_t hull_off[HRG_NHULL + 1];
+  const double* hull_verts;
   uint64_t seed;
 } hrg_model_desc;
 

@@ -118,6 +118,7 @@ typedef struct hrgo_batch {
   hrg_model_desc m;
   hrg_clip_table clips;
   double* frames; /* owned copy */
+  double* hull_verts; /* owned copy of the arm links' hull vertices (robot_hulls) */
   int32_t n_envs;
   int64_t env_id0;
   hrg_env_state* st;
@@ -1003,6 +1004,138 @@ static int cap_box_two(const double* p1, const double* p2, const double* c, cons
   return 1;
 }
 
+/* ---- convex hulls of the arm links (robot_hulls = 1): MuJoCo convexifies a mesh geom at compile time and collides its hull (robot.xml:29-55).
+ * Restated with the textbook tools: the support mapping of the hull (the vertex farthest along a direction) and the GJK distance iteration (Gilbert, Johnson,
+ * Keerthi 1988; closest-point sub-problems as in Ericson, Real-Time Collision Detection 5.1.2 / 5.1.5 / 5.1.6) between the hull and the AXIS of a capsule -- the
+ * capsule's radius is taken off the distance afterwards, which is exact while the axis stays outside the hull. ---- */
+typedef struct { const double* v; int n; const double* R; const double* p; } hull_t; /* body-frame vertices, world pose of the body */
+/* vertex of the hull farthest along the world direction d (the first one on a tie): index, world point in out */
+static int hull_support(const hull_t* H, const double* d, double* out) {
+  const double dl[3] = {H->R[0] * d[0] + H->R[3] * d[1] + H->R[6] * d[2], H->R[1] * d[0] + H->R[4] * d[1] + H->R[7] * d[2], H->R[2] * d[0] + H->R[5] * d[1] + H->R[8] * d[2]};
+  int best = 0;
+  double bv = -1e300;
+  for (int i = 0; i < H->n; i++) {
+    const double t = H->v[3 * i] * dl[0] + H->v[3 * i + 1] * dl[1] + H->v[3 * i + 2] * dl[2];
+    if (t > bv) { bv = t; best = i; }
+  }
+  m3mulv(out, H->R, H->v + 3 * best);
+  v3add(out, out, H->p);
+  return best;
+}
+/* barycentric coordinates of the point of triangle (a, b, c) closest to the origin (Ericson 5.1.5) */
+static void closest_triangle(const double* a, const double* b, const double* c, double* l) {
+  double ab[3], ac[3];
+  v3sub(ab, b, a); v3sub(ac, c, a);
+  const double d1 = -v3dot(ab, a), d2 = -v3dot(ac, a);
+  if (d1 <= 0 && d2 <= 0) { l[0] = 1; l[1] = 0; l[2] = 0; return; }
+  const double d3 = -v3dot(ab, b), d4 = -v3dot(ac, b);
+  if (d3 >= 0 && d4 <= d3) { l[0] = 0; l[1] = 1; l[2] = 0; return; }
+  const double vc = d1 * d4 - d3 * d2;
+  if (vc <= 0 && d1 >= 0 && d3 <= 0) { const double v = d1 / (d1 - d3); l[0] = 1 - v; l[1] = v; l[2] = 0; return; }
+  const double d5 = -v3dot(ab, c), d6 = -v3dot(ac, c);
+  if (d6 >= 0 && d5 <= d6) { l[0] = 0; l[1] = 0; l[2] = 1; return; }
+  const double vb = d5 * d2 - d1 * d6;
+  if (vb <= 0 && d2 >= 0 && d6 <= 0) { const double w = d2 / (d2 - d6); l[0] = 1 - w; l[1] = 0; l[2] = w; return; }
+  const double va = d3 * d6 - d5 * d4;
+  if (va <= 0 && (d4 - d3) >= 0 && (d5 - d6) >= 0) { const double w = (d4 - d3) / ((d4 - d3) + (d5 - d6)); l[0] = 0; l[1] = 1 - w; l[2] = w; return; }
+  const double den = 1.0 / (va + vb + vc), v = vb * den, w = vc * den;
+  l[0] = 1 - v - w; l[1] = v; l[2] = w;
+}
+typedef struct { int n; double y[4][3], a[4][3], b[4][3]; int ia[4], ib[4]; } gjk_simplex;
+/* point of the simplex closest to the origin: v, the simplex reduced to the vertices that carry it, their weights in lam; returns 1 when the origin is inside */
+static int simplex_closest(gjk_simplex* S, double* v, double* lam) {
+  double l[4] = {0, 0, 0, 0};
+  int keep[4] = {0, 1, 2, 3}, nk = S->n;
+  if (S->n == 1) l[0] = 1;
+  else if (S->n == 2) {
+    double ab[3];
+    v3sub(ab, S->y[1], S->y[0]);
+    const double den = v3dot(ab, ab);
+    double t = den > 0 ? -v3dot(S->y[0], ab) / den : 0.0;
+    t = t < 0 ? 0 : (t > 1 ? 1 : t);
+    l[0] = 1 - t; l[1] = t;
+  } else if (S->n == 3) closest_triangle(S->y[0], S->y[1], S->y[2], l);
+  else { /* tetrahedron (Ericson 5.1.6): the closest of the faces the origin lies outside of; inside all four -> the origin is in the simplex */
+    static const int F[4][4] = {{0, 1, 2, 3}, {0, 2, 3, 1}, {0, 3, 1, 2}, {1, 3, 2, 0}}; /* face vertices, then the opposite vertex */
+    double best = 1e300;
+    int any = 0;
+    for (int f = 0; f < 4; f++) {
+      const double *a = S->y[F[f][0]], *b = S->y[F[f][1]], *c = S->y[F[f][2]], *d = S->y[F[f][3]];
+      double ab[3], ac[3], nrm[3], ad[3];
+      v3sub(ab, b, a); v3sub(ac, c, a); v3cross(nrm, ab, ac); v3sub(ad, d, a);
+      const double sp = -v3dot(a, nrm), sd = v3dot(ad, nrm);
+      if (!(sp * sd < 0) && sd != 0) continue; /* the origin is on the inner side of this face (a flat tetrahedron counts as outside) */
+      double lf[3], q[3];
+      closest_triangle(a, b, c, lf);
+      for (int k = 0; k < 3; k++) q[k] = lf[0] * a[k] + lf[1] * b[k] + lf[2] * c[k];
+      const double dq = v3dot(q, q);
+      if (dq < best) { best = dq; any = 1; l[0] = l[1] = l[2] = l[3] = 0; l[F[f][0]] = lf[0]; l[F[f][1]] = lf[1]; l[F[f][2]] = lf[2]; }
+    }
+    if (!any) { v3set(v, 0, 0, 0); return 1; }
+  }
+  nk = 0;
+  for (int i = 0; i < S->n; i++) if (l[i] > 0) keep[nk++] = i;
+  v3set(v, 0, 0, 0);
+  for (int q = 0; q < nk; q++) {
+    const int i = keep[q];
+    lam[q] = l[i];
+    for (int k = 0; k < 3; k++) v[k] += l[i] * S->y[i][k];
+    if (q != i) { v3cpy(S->y[q], S->y[i]); v3cpy(S->a[q], S->a[i]); v3cpy(S->b[q], S->b[i]); S->ia[q] = S->ia[i]; S->ib[q] = S->ib[i]; }
+  }
+  S->n = nk;
+  return 0;
+}
+/* distance between the hull and the segment [s1, s2]; witness points wa (on the hull) and wb (on the segment).  0 when they intersect. */
+static double gjk_hull_segment(const hull_t* H, const double* s1, const double* s2, double* wa, double* wb) {
+  gjk_simplex S;
+  S.n = 0;
+  double v[3], lam[4] = {1, 0, 0, 0};
+  { /* start: the hull's first vertex against the segment's first end */
+    double a0[3];
+    m3mulv(a0, H->R, H->v); v3add(a0, a0, H->p);
+    v3sub(v, a0, s1);
+    v3cpy(S.y[0], v); v3cpy(S.a[0], a0); v3cpy(S.b[0], s1); S.ia[0] = 0; S.ib[0] = 0; S.n = 1;
+  }
+  for (int it = 0; it < 64; it++) {
+    const double vv = v3dot(v, v);
+    if (vv <= 1e-24) { v3cpy(wa, S.a[0]); v3cpy(wb, S.a[0]); return 0.0; }
+    double dir[3] = {-v[0], -v[1], -v[2]}, a[3], w[3];
+    const int ia = hull_support(H, dir, a);
+    const int ib = v3dot(v, s2) > v3dot(v, s1) ? 1 : 0; /* support of the segment along +v */
+    const double* b = ib ? s2 : s1;
+    v3sub(w, a, b);
+    if (vv - v3dot(v, w) <= 1e-12 * vv) break;      /* no vertex pair gets closer along -v: v is the closest point of A - B */
+    int seen = 0;
+    for (int q = 0; q < S.n; q++) if (S.ia[q] == ia && S.ib[q] == ib) seen = 1;
+    if (seen) break;
+    v3cpy(S.y[S.n], w); v3cpy(S.a[S.n], a); v3cpy(S.b[S.n], b); S.ia[S.n] = ia; S.ib[S.n] = ib; S.n++;
+    if (simplex_closest(&S, v, lam)) { v3cpy(wa, a); v3cpy(wb, a); return 0.0; }
+  }
+  v3set(wa, 0, 0, 0); v3set(wb, 0, 0, 0);
+  for (int q = 0; q < S.n; q++) for (int k = 0; k < 3; k++) { wa[k] += lam[q] * S.a[q][k]; wb[k] += lam[q] * S.b[q][k]; }
+  return sqrt(v3dot(v, v));
+}
+/* the hull against a horizontal plane: out = (x, y, z) with z the height of the hull's lowest vertex and (x, y) the mean of the vertices within 1e-6 m of it -- a
+ * link that lies flat on a face or an edge touches in the middle of that face or edge, whichever vertex rounding makes the lowest */
+static void hull_lowest(const hull_t* H, double* out) {
+  double zmin = 1e300;
+  for (int i = 0; i < H->n; i++) {
+    const double z = H->p[2] + H->R[6] * H->v[3 * i] + H->R[7] * H->v[3 * i + 1] + H->R[8] * H->v[3 * i + 2];
+    if (z < zmin) zmin = z;
+  }
+  double sx = 0, sy = 0, cnt = 0;
+  for (int i = 0; i < H->n; i++) {
+    const double* v = H->v + 3 * i;
+    const double z = H->p[2] + H->R[6] * v[0] + H->R[7] * v[1] + H->R[8] * v[2];
+    if (z <= zmin + 1e-6) {
+      sx += H->p[0] + H->R[0] * v[0] + H->R[1] * v[1] + H->R[2] * v[2];
+      sy += H->p[1] + H->R[3] * v[0] + H->R[4] * v[1] + H->R[5] * v[2];
+      cnt += 1;
+    }
+  }
+  out[0] = sx / cnt; out[1] = sy / cnt; out[2] = zmin;
+}
+
 typedef struct { double pos[3], n[3], dist; } bb_contact;
 static int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, bb_contact out[4]);
 static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin* h, const hrg_box_state* bx, contact_t* con) {
@@ -1040,18 +1173,49 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
         v3sub(d, c2, c1);
         if (dd > 1e-12) v3scl(nn, d, 1.0 / dd);
         v3madd(pos, c1, nn, m->rcap_r[i] + 0.5 * dist);
+        if (m->robot_hulls && i < HRG_NHULL) {
+          /* robot_hulls: the capsule test was the BROADPHASE of an arm link (geoms 0 .. 6: robot.xml:29-55, mesh geoms that MuJoCo convexifies).  The pair now
+           * runs the narrowphase of the link's CONVEX HULL: distance of the hull to the human capsule's axis minus its radius, normal along the witness points,
+           * position half way between the two surfaces (an axis that pierces the hull -- a penetration deeper than the capsule's radius -- keeps the capsule
+           * contact).  A hull that does not come within the margin drops the pair. */
+          const int lb = m->rcap_body[i];
+          const hull_t H = {m->hull_verts + 3 * m->hull_off[i], m->hull_off[i + 1] - m->hull_off[i], lb < 0 ? Rb : k->R[lb], lb < 0 ? m->base_pos : k->p[lb]};
+          double wa[3], wb[3];
+          const double dh = gjk_hull_segment(&H, h->cap1[b], h->cap2[b], wa, wb);
+          if (dh > 1e-9) {
+            dist = dh - m->hcap_r[b];
+            if (!(dist < m->contact_margin_human)) continue;
+            for (int a = 0; a < 3; a++) { nn[a] = (wb[a] - wa[a]) / dh; pos[a] = wa[a] + nn[a] * (0.5 * dist); }
+          }
+        }
         EMIT(i, GEOM_HUMAN0 + b, m->rcap_body[i], -2, dist, nn, pos);
       }
     }
   for (int pl = 0; pl < 2; pl++)
     for (int i = 0; i < HRG_NRCAP; i++) {
       if (m->rcap_body[i] < 0) continue; /* welded to the world: static-static pairs are filtered */
+      int hull_done = 0;
       for (int e = 0; e < 2; e++) {
         const double* p = e ? rp2[i] : rp1[i];
         double z0 = pl ? m->floor_z : m->table_top_z, dist = p[2] - m->rcap_r[i] - z0;
         if (pl == 0 && !(fabs(p[0] - m->table_center[0]) <= m->table_half[0] && fabs(p[1] - m->table_center[1]) <= m->table_half[1] && p[2] > z0 - 0.025)) /* end point above the mid-plane of the 0.05 m slab */ continue;
         if (dist < 0) {
           double nn[3] = {0, 0, -1}, pos[3] = {p[0], p[1], z0 + 0.5 * dist};
+          if (m->robot_hulls && i < HRG_NHULL) {
+            /* robot_hulls: an end point of the bounding capsule under the plane = broadphase; the contact is the hull's lowest point, ONE per link and plane
+             * (the capsule has one per end point), with the plane's own footprint test on that point. */
+            if (hull_done) continue;
+            hull_done = 1;
+            const int lb = m->rcap_body[i];
+            const hull_t H = {m->hull_verts + 3 * m->hull_off[i], m->hull_off[i + 1] - m->hull_off[i], k->R[lb], k->p[lb]};
+            double low[3];
+            hull_lowest(&H, low);
+            dist = low[2] - z0;
+            int ok = dist < 0;
+            if (pl == 0) ok = ok && fabs(low[0] - m->table_center[0]) <= m->table_half[0] && fabs(low[1] - m->table_center[1]) <= m->table_half[1] && low[2] > z0 - 0.025;
+            if (!ok) continue;
+            pos[0] = low[0]; pos[1] = low[1]; pos[2] = z0 + 0.5 * dist;
+          }
           EMIT(i, pl ? GEOM_FLOOR : GEOM_TABLE, m->rcap_body[i], -1, dist, nn, pos);
         }
       }
@@ -3502,6 +3666,12 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
   B->frames = (double*)malloc(sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames);
   memcpy(B->frames, clips->frames, sizeof(double) * HRG_FRAME_DIM * (size_t)clips->total_frames);
   B->clips.frames = B->frames;
+  if (desc->robot_hulls) { /* own copy of the hull vertices (the caller's table need not outlive the call) */
+    const size_t nb = sizeof(double) * 3 * (size_t)desc->hull_off[HRG_NHULL];
+    B->hull_verts = (double*)malloc(nb);
+    memcpy(B->hull_verts, desc->hull_verts, nb);
+    B->m.hull_verts = B->hull_verts;
+  }
   B->n_envs = n_envs;
   B->env_id0 = env_id0;
   B->st = (hrg_env_state*)calloc((size_t)n_envs, sizeof(hrg_env_state));
@@ -3517,7 +3687,7 @@ int hrgo_create(const hrg_model_desc* desc, const hrg_clip_table* clips, int32_t
 }
 void hrgo_destroy(hrgo_batch* B) {
   if (!B) return;
-  free(B->frames); free(B->st); free(B->box); free(B->stk); free(B->hmr); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
+  free(B->frames); free(B->hull_verts); free(B->st); free(B->box); free(B->stk); free(B->hmr); free(B->rcaps); free(B->hcaps); free(B->n_hcaps); free(B);
 }
 int hrgo_reset(hrgo_batch* B, const uint8_t* mask, float* obs) {
   for (int e = 0; e < B->n_envs; e++) if (!mask || mask[e]) env_reset(B, e, obs + (size_t)e * HRG_OBS_DIM);
@@ -3712,6 +3882,21 @@ int hrgo_capsules(hrgo_batch* B, double* robot, double* human, int32_t* n_human)
 }
 
 /* ---- unit-level taps used by tests/ (known-answer tests of the pieces) ---- */
+/* hull h of the desc at body pose (R row-major, p): vertex farthest along d -> out[3]; returns its index */
+int hrgo_test_hull_support(const hrg_model_desc* m, int h, const double* R, const double* p, const double* d, double* out) {
+  const hull_t H = {m->hull_verts + 3 * m->hull_off[h], m->hull_off[h + 1] - m->hull_off[h], R, p};
+  return hull_support(&H, d, out);
+}
+/* ... its lowest point over a horizontal plane (hull_lowest) -> out[3] */
+void hrgo_test_hull_lowest(const hrg_model_desc* m, int h, const double* R, const double* p, double* out) {
+  const hull_t H = {m->hull_verts + 3 * m->hull_off[h], m->hull_off[h + 1] - m->hull_off[h], R, p};
+  hull_lowest(&H, out);
+}
+/* ... and its GJK distance to the segment [s1, s2]: out = [distance, witness on the hull 3, witness on the segment 3] */
+void hrgo_test_hull_segment(const hrg_model_desc* m, int h, const double* R, const double* p, const double* s1, const double* s2, double* out) {
+  const hull_t H = {m->hull_verts + 3 * m->hull_off[h], m->hull_off[h + 1] - m->hull_off[h], R, p};
+  out[0] = gjk_hull_segment(&H, s1, s2, out + 1, out + 4);
+}
 void hrgo_test_robot(const hrg_model_desc* m, const double* q, const double* qd, double* M, double* bias, double* eef) {
   robot_kin k;
   robot_fk(m, q, &k);

@@ -108,13 +108,13 @@ def _compare_part(name, k, G, O, a_np, kind, tally):
     return post
 
 
-def _run(env, shield="SSM"):
+def _run(env, shield="SSM", robot_geometry="capsule"):
     import torch
     import bench
     import human_robot_gym_amd as hrg
     from human_robot_gym_amd import mixed
     from oracle.oracle import OracleBatch
-    W = bench.bench_workload(env, shield)
+    W = bench.bench_workload(env, shield, robot_geometry=robot_geometry)
     G, desc, mixed_tasks, staggered = bench.make_bench_batch(W)
     n = W["n"]
     assert n == (8192 if env == "PickPlaceHumanCart" else 4096)
@@ -150,7 +150,7 @@ def _run(env, shield="SSM"):
             post = _compare_part(eid, k, b, O, a_np[sl].copy(), _kinds(eid), tally)
             _hip_set_states(b, _kinds(eid), *post)      # resynchronise: the next step starts from the oracle's state on both sides
     live = tally["compared"] / tally["total"]
-    line = dict(test=f"test_bench_state_gpu::{env}_{shield}", n=n, preroll=pre, steps=N_STEPS, live=live, seconds_preroll=round(t_roll, 1), seconds_compare=round(time.time() - t0, 1), **tally)
+    line = dict(test=f"test_bench_state_gpu::{env}_{shield}" + ("" if robot_geometry == "capsule" else f"_{robot_geometry}"), n=n, preroll=pre, steps=N_STEPS, live=live, seconds_preroll=round(t_roll, 1), seconds_compare=round(time.time() - t0, 1), **tally)
     print("[parity]", line)
     try:
         import json
@@ -174,6 +174,13 @@ def test_reach_human_4096_steady_state_matches_oracle(shield):
     t = _run("ReachHuman", shield)
     if shield == "SSM":
         assert t["unsafe"] > 0, "a steady-state SSM batch has envs under fail-safe manoeuvres"
+
+
+def test_reach_human_4096_with_hull_geometry_matches_oracle():
+    """The headline workload with the arm links colliding as the convex hulls of their meshes (bench.py --robot-geometry hull; shield OFF: the batch with the most
+    robot-human contacts)."""
+    t = _run("ReachHuman", "OFF", robot_geometry="hull")
+    assert t["contacts"] > 0
 
 
 def test_pick_place_8192_steady_state_matches_oracle():

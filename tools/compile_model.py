@@ -152,6 +152,31 @@ def compile_human(assets):
     return dict(bodies=bodies, armature=armature, margin=margin)
 
 
+def compile_hulls(assets, chain):
+    """Convex hulls of the seven arm collision meshes (robot.xml:29-55; MuJoCo convexifies every collision mesh at compile time [UPSTREAM: qhull]): the hull's
+    vertices in the frame of the body the geom hangs on, in the order of the chain's capsules (link0 .. link6).  scipy's Qhull wrapper runs here, at model-compile
+    time only; the stepper reads the table.  Returns (verts [N, 3] float64, offsets [8] int32)."""
+    from scipy.spatial import ConvexHull
+    root = ET.parse(f"{assets}/robots/schunk/robot.xml").getroot()
+    meshes = {m.get("name"): m.get("file") for m in root.find("asset").findall("mesh")}
+    geoms = {g.get("name"): g for g in root.iter("geom") if g.get("contype") != "0" and g.get("type") == "mesh"}
+    verts, offs = [], [0]
+    for rec in chain:
+        for cap in rec["capsules"]:
+            g = geoms[cap["name"]]
+            V = load_stl(f"{assets}/robots/schunk/{meshes[g.get('mesh')]}")
+            V = V @ quat_to_mat(fnum(g.get("quat", "1 0 0 0"))).T + np.array(fnum(g.get("pos", "0 0 0")))
+            H = V[np.sort(ConvexHull(V).vertices)]
+            # the bounding capsule of the mesh bounds its hull: the capsule narrowphase stays a valid broadphase for the hull
+            p1, p2, r = np.array(cap["p1"]), np.array(cap["p2"]), cap["r"]
+            ab = p2 - p1
+            u = np.clip((H - p1) @ ab / max(float(ab @ ab), 1e-300), 0, 1)
+            assert np.linalg.norm(H - (p1 + u[:, None] * ab), axis=1).max() <= r * (1 + 1e-6) + 1e-9
+            verts.append(H)
+            offs.append(offs[-1] + len(H))
+    return np.concatenate(verts), np.array(offs, np.int32)
+
+
 def main():
     assets, out = sys.argv[1], sys.argv[2]
     model = dict(
@@ -164,6 +189,10 @@ def main():
     )
     with open(out, "w") as f:
         json.dump(model, f, indent=1)
+    hv, ho = compile_hulls(assets, model["robot"]["chain"])
+    import os
+    np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(out)), "schunk_hulls.npz"), verts=hv, offsets=ho)
+    print(f"hull vertices per link {np.diff(ho).tolist()}")
     nb = len(model["human"]["bodies"])
     print(f"robot bodies {len(model['robot']['chain'])}, human bodies {nb}")
 

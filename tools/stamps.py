@@ -10,15 +10,16 @@ lib = load_library()
 env_id = sys.argv[2] if len(sys.argv) > 2 else "ReachHuman"
 N = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
 SLOW = int(float(sys.argv[4])) if len(sys.argv) > 4 else 0     # > 0: also profile the waves that live longer than this many cycles (ReachHuman kernel only)
+GEOM = os.environ.get("HRG_GEOMETRY", "capsule")                # "hull": the hull variant of the ReachHuman kernel
 from human_robot_gym_amd.mixed import task_clips
 clips = task_clips(env_id, 13)
 from human_robot_gym_amd.mixed import task_env_kwargs
 kw = dict(shield_type=sys.argv[1] if len(sys.argv) > 1 else "SSM", control_freq=10, seed=1234, **task_env_kwargs(env_id))
 if env_id == "ReachHuman":
     kw.update(horizon=100, done_at_success=True, reward_shaping=True)
-G = HipBatch(hrg.build_model_desc(kw, n_clips=13, env_id=env_id), clips, N); G.reset()
-if os.environ.get("HRG_STAGGER", "1") != "0": G.stagger_episode_phases(100 if "ReachHuman" in str(getattr(G, "n", "")) or True else 100)
-stamps = lib.hrg_debug_stamps if env_id == "ReachHuman" else (lib.hrg_debug_stamps_hammer if "Hammering" in env_id else lib.hrg_debug_stamps_stack if "Stacking" in env_id else (lib.hrg_debug_stamps_ho if "Handover" in env_id else lib.hrg_debug_stamps_box))
+G = HipBatch(hrg.build_model_desc(kw, n_clips=13, env_id=env_id, robot_geometry=GEOM), clips, N); G.reset()
+if os.environ.get("HRG_STAGGER", "1") != "0": G.stagger_episode_phases(100)
+stamps = (lib.hrg_debug_stamps_hull if GEOM == "hull" else lib.hrg_debug_stamps) if env_id == "ReachHuman" else (lib.hrg_debug_stamps_hammer if "Hammering" in env_id else lib.hrg_debug_stamps_stack if "Stacking" in env_id else (lib.hrg_debug_stamps_ho if "Handover" in env_id else lib.hrg_debug_stamps_box))
 gen = torch.Generator(device="cuda"); gen.manual_seed(0)
 acts = [torch.rand((N, 7), generator=gen, device="cuda", dtype=torch.float64) * 2 - 1 for _ in range(16)]
 out = np.zeros(32)
