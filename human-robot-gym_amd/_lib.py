@@ -38,7 +38,11 @@ def build_library(force=False, verbose=False):
     # -fapprox-func, device code only: FP64 divisions become v_rcp_f64 + two Newton steps + one residual correction (8 instructions, within an ulp) instead of the
     # IEEE-exact sequence with scaling and fix-up (12+): 140 division sites in the ReachHuman kernel alone, 5 % of its vector instructions.  The host side and the
     # oracle keep IEEE arithmetic; the parity tolerance (1e-5 relative) is eleven orders of magnitude above the difference.
-    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", "-o", LIB_PATH,
+    # -mllvm -disable-machine-licm: the machine-level loop-invariant code motion pulled the materialisation of ~25 FP64 literals (polynomial coefficients of the
+    # in-loop sincos / atan / exp code) out of the 25-cycle loop into VGPR pairs that then stayed live across EVERY phase -- a fifth of the 128-register budget, one
+    # pair spilled.  Without it the ReachHuman kernel allocates 120 VGPRs with no VGPR spill (was 128 + 5 spilled; SGPR spills 93 -> 64) and every variant is
+    # 3 - 6 % faster (profiles/r03_*).
+    cmd = ["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", "-mllvm", "-disable-machine-licm", "-o", LIB_PATH,
            SRC, SRC_BOX, SRC_HO, SRC_LIFT, SRC_STACK, SRC_HAMMER, SRC_HULLS]
     if verbose:
         print(" ".join(cmd))

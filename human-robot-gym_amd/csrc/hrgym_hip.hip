@@ -2968,7 +2968,9 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_step_
     ord.buf[(size_t)(1 - ord.parity) * ord.n + at] = e;
     if (slot == 0) { int32_t* mine = ord.buf + 2 * (size_t)ord.n + 2 * ord.parity; mine[0] = 0; mine[1] = 0; }
   }
-  double* out = (double*)(states + e);
+  hrg_env_state* st_out = states;
+  asm volatile("" : "+s"(st_out));   // the write-back address is computed here, from the kernel argument, instead of sitting in two VGPRs across the whole step
+  double* out = (double*)(st_out + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
 #if HRG_BOX || HRG_STACK || HRG_HAMMER
   box_store(boxes, e, lane);
@@ -2989,7 +2991,9 @@ __global__ __launch_bounds__(64 * HRG_WG_WAVES, HRG_KERNEL_WAVES) void hrg_reset
   wave_sync();
   env_reset(dm, lane, env_id0 + e, obs ? obs + (size_t)e * HRG_OBS_DIM : nullptr);
   wave_sync();
-  double* out = (double*)(states + e);
+  hrg_env_state* st_out = states;
+  asm volatile("" : "+s"(st_out));   // the write-back address is computed here, from the kernel argument, instead of sitting in two VGPRs across the whole step
+  double* out = (double*)(st_out + e);
   for (int k = lane; k < NW; k += 64) out[k] = dst[k];
 #if HRG_BOX || HRG_STACK || HRG_HAMMER
   box_store(boxes, e, lane);

@@ -3,7 +3,7 @@
 import glob, os, re, subprocess, sys, tempfile
 src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "human-robot-gym_amd", "csrc", "hrgym_hip.hip")
 d = tempfile.mkdtemp()
-subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-save-temps", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", *sys.argv[1:], "-o", "t.o", src], cwd=d, stderr=subprocess.DEVNULL)
+subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", "-save-temps", "-Wno-unused-value", "-Xarch_device", "-fapprox-func", "-mllvm", "-disable-machine-licm", *sys.argv[1:], "-o", "t.o", src], cwd=d, stderr=subprocess.DEVNULL)
 s = open(glob.glob(d + "/*gfx950*.s")[0]).read()
 for m in re.finditer(r"\.type\s+(\S+),@function", s):
     name = m.group(1)
