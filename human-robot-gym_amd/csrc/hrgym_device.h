@@ -201,7 +201,6 @@ struct Lds {
   double Mb[64], fb[8];                  // mass matrix (8 x 8, pad DoF with a unit diagonal) and applied force of the board + nail subtree
   double Ihw[9], tauh[3];                // the hammer's world-frame rotational inertia and gyroscopic torque
   double nsG[(9 + 2 * NCON_DYN) * (10 + 2 * NCON_DYN) / 2];   // noslip pass: Gram matrix of its items (9 friction-loss rows + 2 pairs per contact), packed lower triangle
-  double nsC[9 + 2 * NCON_DYN][3];                            // ... per item: 1 / curvature, bound, curvature
   Contact con[NCON_DYN];
 #elif HRG_STACK
   hrg_stack_state sk;                    // the four cubes + task bookkeeping (streamed from its own HBM array)

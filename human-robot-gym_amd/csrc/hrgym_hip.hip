@@ -1050,33 +1050,60 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       }
     }
     wave_sync();
-    // per item: curvature, its reciprocal and the bound, read back by every lane at a uniform LDS address while the previous item is still being worked on.  A
-    // pair without curvature (both edges then go to the mean) is a zero bound with a zero step.
-    double Gjj = lane < nitem ? L.nsG[tri(lane, lane)] : 0.0;
-    {
-      const bool flat = lane >= NI0 && !(Gjj >= 1e-15);
-      const double inv = flat ? 0.0 : 1.0 / (Gjj > 1e-15 ? Gjj : 1e-15);
-      if (lane < nitem) { L.nsC[lane][0] = inv; L.nsC[lane][1] = flat ? 0.0 : bnd; L.nsC[lane][2] = Gjj; }
-    }
-    wave_sync();
+    // per item: curvature, its reciprocal and the bound stay in the item's own lane.  A pair without curvature (both edges then go to the mean) is a zero bound
+    // with a zero step.  An update of item i:  every lane works out the step ITS item would take now, z' = clamp(z - res / G_jj), from its own registers; the step
+    // of lane i is broadcast (two v_readlane) and every lane takes res += G_ij dl; lane i keeps z' and its share of the cost decrease.  The sweeps repeat over the
+    // same items, so every lane first takes its entries of the Gram columns of the first NS_REG active items into registers (one wave per SIMD: up to 512 VGPRs).
+    // An update is then 12 instructions without a memory access; broadcasting the item's five values and reading the column from LDS it was 34 and ~ 450 cycles of
+    // a strictly sequential chain, ~ 260 times per substep (40 % of the kernel).  Items beyond NS_REG (more than seven contacts: 0.5 % of the substeps) read LDS.
+    const double Gjj = lane < nitem ? L.nsG[tri(lane, lane)] : 0.0;
+    const bool flat = lane >= NI0 && !(Gjj >= 1e-15);
+    const double inv_own = flat ? 0.0 : 1.0 / (Gjj > 1e-15 ? Gjj : 1e-15), bnd_own = flat ? 0.0 : bnd, nbnd_own = -bnd_own, hG_own = 0.5 * Gjj;
     const int tri_lane = lane * (lane + 1) / 2;
+    constexpr int NS_REG = 24;
+    double gcol[NS_REG];
+    uint64_t rest = imask;   // active items beyond the register columns
+    {
+      uint64_t mm = imask;
+#pragma unroll
+      for (int k = 0; k < NS_REG; k++) {
+        gcol[k] = 0.0;
+        if (mm) {
+          const int i = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          if (item) gcol[k] = L.nsG[lane <= i ? i * (i + 1) / 2 + lane : tri_lane + i];
+        }
+      }
+      rest = mm;
+    }
+    STAMP(31);
+    double imp_own = 0.0;   // this lane's item: its cost decrease in the running sweep
+    auto update = [&](int i, double gij) {
+      const double zn = fmin(fmax(z - res * inv_own, nbnd_own), bnd_own);
+      const double dl_own = zn - z;
+      const double dl = lane_value_dyn(dl_own, i);
+      if (lane == i) { imp_own -= dl_own * (res + hG_own * dl_own); z = zn; }
+      res += gij * dl;
+    };
 #pragma unroll 1
     for (int it = 0; it < m.noslip_iterations; it++) {
       COUNT(30, 1);   // noslip sweeps
-      double imp = it == 0 ? imp0 : 0.0;
+      imp_own = 0.0;
+      uint64_t mm = imask;
+#pragma unroll
+      for (int k = 0; k < NS_REG; k++)
+        if (mm) {
+          const int i = __ffsll((long long)mm) - 1;
+          mm &= mm - 1;
+          update(i, gcol[k]);
+        }
 #pragma unroll 1
-      for (int i = 0; i < nitem; i++) {
-        if (!((imask >> i) & 1ull)) continue;
-        const int tri_i = i * (i + 1) / 2;
-        const double gij = item ? L.nsG[lane <= i ? tri_i + lane : tri_lane + i] : 0.0;
-        const double invi = L.nsC[i][0], bi = L.nsC[i][1], Gii = L.nsC[i][2];
-        const double ri = lane_value_dyn(res, i), zi = lane_value_dyn(z, i);
-        const double zn = fmin(fmax(zi - ri * invi, -bi), bi);
-        const double dl = zn - zi;
-        z = lane == i ? zn : z;
-        res += gij * dl;
-        imp -= dl * (ri + 0.5 * Gii * dl);
+      for (uint64_t mr = rest; mr;) {
+        const int i = __ffsll((long long)mr) - 1;
+        mr &= mr - 1;
+        update(i, item ? L.nsG[lane <= i ? i * (i + 1) / 2 + lane : tri_lane + i] : 0.0);
       }
+      const double imp = (it == 0 ? imp0 : 0.0) + wave_sum(imp_own);
       if (imp * m.noslip_scale < m.noslip_tolerance) break;
     }
     // ---- the changed forces back into the acceleration: a += M^-1 U' dz ----
@@ -2921,10 +2948,9 @@ DI void box_store(hrg_stack_state* __restrict__ stacks, int e, int lane) {
 }
 #elif HRG_HAMMER
 #ifndef HRG_HAMMER_WAVES
-#define HRG_HAMMER_WAVES 1   // 2 (256 registers, five 30 KB workgroups per CU) is 9 % faster (8.88 -> 8.09 ms per 4096-env step) but spills 752 B per lane inside the cycle
-                             // loop: 990 MB through HBM per launch against 74 MB at one wave per SIMD (100 MB algorithmic; profiles/r02t_tasks_summary.md)
+#define HRG_HAMMER_WAVES 1   // the allocator's budget (512 registers); it uses 209 without a spill, so the hardware runs a second wave on a SIMD whenever LDS allows
 #endif
-#define HRG_KERNEL_WAVES HRG_HAMMER_WAVES   // 30 KB of LDS per env (89 dense rows of J over 24 DoF): 4 workgroups per CU, one wave per SIMD, up to 512 VGPRs
+#define HRG_KERNEL_WAVES HRG_HAMMER_WAVES   // 29.5 KB of LDS per env (65 dense rows of J over 24 DoF, the noslip pass's Gram matrix): 5 workgroups per CU
 DI void box_load(const hrg_hammer_state* __restrict__ hammers, int e, int lane) {
   constexpr int NB = (int)(sizeof(hrg_hammer_state) / sizeof(double));
   const double* src = (const double*)(hammers + e);

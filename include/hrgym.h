@@ -84,7 +84,8 @@ extern "C" {
 #define HRG_NCON_DYN_STACK 23 /* contacts that enter its solve: 8 + 16 + 12 + 4 x 23 = 128 constraint rows = two per lane of a wavefront */
 #define HRG_NROW_STACK 128
 #define HRG_NV_HAMMER 24   /* CollaborativeHammeringCart: three 8-wide blocks -- robot tree 0..7 | board 8..13, nail slide joint 14, pad | hammer 16..21, pad, pad */
-#define HRG_NCON_DYN_HAMMER 20 /* contacts that enter its solve: 9 + 18 + 9 + 4 x 20 = 116 constraint rows (two per lane of a wavefront) */
+#define HRG_NCON_DYN_HAMMER 14 /* contacts that enter its solve: 9 + 18 + 9 + 4 x 14 = 92 constraint rows (two per lane of a wavefront).  14: a soak of 2.4 M env steps had
+                                 * more contacts at the end of 6 of them (tools/soak_hammering.py prints the histogram); the rows of 20 cost the kernel two of its five workgroups per CU */
 #define HRG_NPREV_MAX 24  /* remembered robot contact pairs (edge trigger, human_env.py:1109-1121) */
 #define HRG_MAX_CLIPS 16
 #define HRG_MAX_LOOP 4     /* layered sines of an animation loop (utils/animation_utils.py:91-119) */

@@ -29,6 +29,7 @@ in_events = in_unstruck = 0
 goals_prev = np.zeros(n, np.int64)
 completed = completed_unstruck = 0
 max_progress = 0.0
+ncon_hist = np.zeros(C["HRG_NCON_MAX"] + 1, np.int64)   # contacts at the substep that ends a policy step (the solve takes the first HRG_NCON_DYN_HAMMER)
 for k in range(steps):
     a = (torch.rand((n, 7), generator=g, dtype=torch.float64) * 2 - 1).cuda()
     if mode == "still":
@@ -36,6 +37,7 @@ for k in range(steps):
     obs, r, dn, info = G.step(a)
     crashes += int(info[:, 11].sum().item()); dones += int(dn.sum().item()); wins += int((r > 0).sum().item())
     pairs, ncon = G.contacts()
+    ncon_hist += np.bincount(np.minimum(ncon, C["HRG_NCON_MAX"]), minlength=C["HRG_NCON_MAX"] + 1)
     hit = np.zeros(n, bool)
     for gh in g_hammer:
         hit |= np.any(((pairs[:, :, 0] == gh) & (pairs[:, :, 1] == g_nail)) | ((pairs[:, :, 1] == gh) & (pairs[:, :, 0] == g_nail)), axis=1)
@@ -64,3 +66,4 @@ order, nb = G.launch_order()
 print("launch order a permutation", bool(np.array_equal(np.sort(order), np.arange(n))))
 print(f"RESULT mode {mode} steps {steps} envs {n} nail_frictionloss {d.hm_nail_frictionloss}: nails hammered in {in_events}, of them without a hammer contact {in_unstruck}; tasks completed {completed}, "
       f"of them without a hammer contact {completed_unstruck}; largest nail progress {max_progress:.4f}; crashes {crashes}")
+print('contacts per env at the end of a policy step (histogram 0 ..):', ncon_hist.tolist(), ' share above', C['HRG_NCON_DYN_HAMMER'], ':', float(ncon_hist[C['HRG_NCON_DYN_HAMMER'] + 1:].sum()) / ncon_hist.sum())

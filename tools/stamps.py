@@ -31,9 +31,9 @@ for k in range(50): G.step(acts[k % 16])
 torch.cuda.synchronize(); stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
 names = {0: "cycle prologue (set_goal)", 1: "shield: tail (after des)", 2: "robot_dynamics_terms", 3: "controller", 4: "human_control", 5: "collide", 6: "classify", 7: "dynamics_step", 8: "epilogue", 9: "reset/obs",
          10: " shield: cur+plan", 11: " shield: paths", 12: " shield: qe eval", 13: " shield: chain fk", 14: " shield: reach+verify", 15: " shield: update+des"}
-names.update({20: " dyn: M chol + a0", 21: " dyn: row setup", 22: " dyn: warm start", 23: " dyn: grad + Hessian", 24: " dyn: chol H", 25: " dyn: solve + p", 26: " dyn: line search", 27: " handover: first-pass tail / stacking: gradient", 28: " dyn: end of the Newton loop", 29: " dyn: noslip pass (hammering)"})
-tot = out[:16].sum() + out[20:30].sum()
-for k in list(range(16)) + list(range(20, 30)):
+names.update({20: " dyn: M chol + a0", 21: " dyn: row setup", 22: " dyn: warm start", 23: " dyn: grad + Hessian", 24: " dyn: chol H", 25: " dyn: solve + p", 26: " dyn: line search", 27: " handover: first-pass tail / stacking: gradient", 28: " dyn: end of the Newton loop", 29: " dyn: noslip sweeps + write-back (hammering)", 31: " dyn: noslip forces + Gram matrix (hammering)"})
+tot = out[:16].sum() + out[20:30].sum() + out[31]
+for k in list(range(16)) + list(range(20, 30)) + [31]:
     print("%-26s %6.2f %%  (%.0f cycles/env-step)" % (names.get(k, k), 100 * out[k] / tot, out[k] / (50 * N)))
 sub = 50 * N * 25
 print("per substep: Newton iterations %.2f, line-search evaluations %.2f, Hessian factorizations %.2f, active rows %.2f, noslip sweeps %.2f" % (out[16] / sub, out[17] / sub, out[18] / sub, out[19] / sub, out[30] / sub))
