@@ -2096,7 +2096,7 @@ DI void hammer_take_board(const DevModel* __restrict__ dm_, int lane, int64_t gi
   if (lane < 4) hm.quat[0][lane] = qt[lane];
   if (lane < 3) hm.pos[0][lane] = hm.mocap_pos[1][lane] - t[lane];
   if (lane < 6) { hm.vel[0][lane] = 0.0; hm.acc_warmstart[0][lane] = 0.0; }
-  hm.nail_q = 0.0; hm.nail_v = 0.0; hm.nail_acc_warmstart = 0.0;
+  hm.nail_q = 0.0; hm.nail_v = 0.0; hm.nail_acc_warmstart = 0.0; hm.nail_touch = 0; hm.pad_ = 0;
   if (lane == 0) hm.nail_xy[0] = m.hm_nail_bin[0] + (m.hm_nail_bin[1] - m.hm_nail_bin[0]) * u0;
   if (lane == 1) hm.nail_xy[1] = m.hm_nail_bin[2] + (m.hm_nail_bin[3] - m.hm_nail_bin[2]) * u1;
   wave_sync();

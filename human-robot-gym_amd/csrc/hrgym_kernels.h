@@ -1516,6 +1516,17 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
   L.st.ncon = ncon;
   *ncon_out = ncon;
   wave_sync();
+#if HRG_HAMMER
+  { // diagnostic: who touches the nail head (hrg_hammer_state.nail_touch)
+    int t = 0;
+    if (lane < ncon) {
+      const int gn = GEOM_BOX + HRG_HG_NAIL, g1 = L.st.con_pairs[lane][0], g2 = L.st.con_pairs[lane][1], o = g1 == gn ? g2 : (g2 == gn ? g1 : -1);
+      if (o >= 0 && o != GEOM_BOX + HRG_HG_BOARD) t = (o == GEOM_BOX + HRG_HG_HANDLE || o == GEOM_BOX + HRG_HG_HEAD) ? 1 : 2;
+    }
+    const int any = (__any(t & 1) ? 1 : 0) | (__any(t & 2) ? 2 : 0);
+    if (any) L.hm.nail_touch = L.hm.nail_touch | any;
+  }
+#endif
 }
 
 // the manipulation object is whitelisted -> COLLISION_TYPE.ALLOWED (pick_place_human_cartesian_env.py:710-717)

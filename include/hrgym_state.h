@@ -135,6 +135,9 @@ typedef struct hrg_hammer_state {
   int32_t gripped;                   /* hammer_gripped sensor (1283-1289) at the last substep */
   int32_t task_phase;                /* HRG_HM_* */
   int32_t n_delayed;                 /* _n_delayed_timesteps */
+  int32_t nail_touch;                /* diagnostic: who has touched the nail head at the end of ANY substep since the nail was last pulled out -- bit 0 a hammer geom
+                                      * (handle / head), bit 1 anything else (an arm link, the gripper); tools/soak_hammering.py: is a driven-in nail the hammer's doing */
+  int32_t pad_;
 } hrg_hammer_state;
 
 #ifdef __cplusplus

@@ -3269,7 +3269,7 @@ static void hammer_take_board(const hrgo_batch* B, int64_t gid, const hrg_env_st
   m3mulv(t, Rt, m->hm_anchor[1]);
   v3sub(hm->pos[0], hm->mocap_pos[1], t);
   for (int a = 0; a < 6; a++) { hm->vel[0][a] = 0; hm->acc_warmstart[0][a] = 0; }
-  hm->nail_q = 0; hm->nail_v = 0; hm->nail_acc_warmstart = 0;
+  hm->nail_q = 0; hm->nail_v = 0; hm->nail_acc_warmstart = 0; hm->nail_touch = 0; hm->pad_ = 0;
   /* nail_placements[index]: UniformRandomSampler over the board (889-960), drawn counter-based on demand (D6) */
   hm->nail_xy[0] = m->hm_nail_bin[0] + (m->hm_nail_bin[1] - m->hm_nail_bin[0]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_OBJECT, (uint64_t)(2 * hm->nail_index));
   hm->nail_xy[1] = m->hm_nail_bin[2] + (m->hm_nail_bin[3] - m->hm_nail_bin[2]) * rng_u01(m->seed, (uint64_t)gid, (uint64_t)s->episode, STREAM_OBJECT, (uint64_t)(2 * hm->nail_index + 1));
@@ -3425,6 +3425,10 @@ static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, fl
     hammer_geometry(m, hm, &G);
     contact_t con[HRG_NCON_MAX];
     int ncon = collide_hammer(m, &k, &hk, hm, &G, con);
+    for (int c = 0; c < ncon; c++) { /* diagnostic: who touches the nail head */
+      const int gn = GEOM_BOX + HRG_HG_NAIL, o = con[c].g1 == gn ? con[c].g2 : (con[c].g2 == gn ? con[c].g1 : -1);
+      if (o >= 0 && o != GEOM_BOX + HRG_HG_BOARD) hm->nail_touch |= (o == GEOM_BOX + HRG_HG_HANDLE || o == GEOM_BOX + HRG_HG_HEAD) ? 1 : 2;
+    }
     double rc[HRG_NRCAP][3], Rb[9];
     quat2mat(Rb, m->base_quat);
     for (int c = 0; c < HRG_NRCAP; c++) {

@@ -26,6 +26,7 @@ g_nail, g_hammer = GEOM_BOX + C["HRG_HG_NAIL"], (GEOM_BOX + C["HRG_HG_HANDLE"], 
 struck = np.zeros(n, bool)          # a hammer geom has touched the nail head since the nail was last pulled out
 was_in = np.zeros(n, bool)
 in_events = in_unstruck = 0
+touch_hammer = touch_other_only = touch_none = touch_unknown = 0   # hrg_hammer_state.nail_touch of a newly driven-in nail: who touched the nail head at ANY substep end
 goals_prev = np.zeros(n, np.int64)
 completed = completed_unstruck = 0
 max_progress = 0.0
@@ -47,6 +48,12 @@ for k in range(steps):
     now_in = 1.0 - prog < d.hm_goal_tolerance
     new_in = now_in & ~was_in
     in_events += int(new_in.sum()); in_unstruck += int((new_in & ~struck).sum())
+    for e in np.nonzero(new_in)[0]:
+        if bool(dn[e].item()):
+            touch_unknown += 1          # the episode ended in this very step: the reset has pulled the nail out and cleared the record
+            continue
+        t = G.get_hammer(int(e)).nail_touch
+        touch_hammer += int(t & 1 != 0); touch_other_only += int(t == 2); touch_none += int(t == 0)
     was_in = now_in
     goals = info[:, 9].cpu().numpy().astype(np.int64)
     done_np = dn.cpu().numpy().astype(bool)
@@ -66,4 +73,5 @@ order, nb = G.launch_order()
 print("launch order a permutation", bool(np.array_equal(np.sort(order), np.arange(n))))
 print(f"RESULT mode {mode} steps {steps} envs {n} nail_frictionloss {d.hm_nail_frictionloss}: nails hammered in {in_events}, of them without a hammer contact {in_unstruck}; tasks completed {completed}, "
       f"of them without a hammer contact {completed_unstruck}; largest nail progress {max_progress:.4f}; crashes {crashes}")
+print(f'nail_touch of the {in_events} driven-in nails (every substep end since the nail was pulled out): a hammer geom touched it {touch_hammer}, only other geoms {touch_other_only}, nothing {touch_none}, episode ended in the same step {touch_unknown}')
 print('contacts per env at the end of a policy step (histogram 0 ..):', ncon_hist.tolist(), ' share above', C['HRG_NCON_DYN_HAMMER'], ':', float(ncon_hist[C['HRG_NCON_DYN_HAMMER'] + 1:].sum()) / ncon_hist.sum())
