@@ -203,7 +203,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         const double sg = (d & 1) ? -1.0 : 1.0;
         for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
         pos = cc.dist;
-        margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+        margin = ((cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) || (cc.g1 >= GEOM_HUMAN0 && cc.g1 < GEOM_TABLE)) ? m.contact_margin_human : 0.0;   // a human geom on either side
         const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
         diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
         const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
@@ -731,7 +731,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
         const double sg = (d & 1) ? -1.0 : 1.0;
         for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
         pos = cc.dist;
-        margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+        margin = ((cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) || (cc.g1 >= GEOM_HUMAN0 && cc.g1 < GEOM_TABLE)) ? m.contact_margin_human : 0.0;   // a human geom on either side
         const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
         diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
         const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;
@@ -1254,7 +1254,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       const double sg = (d & 1) ? -1.0 : 1.0;
       for (int a = 0; a < 3; a++) dir[a] = n[a] + sg * m.friction_static * (d < 2 ? t1[a] : t2[a]);
       pos = cc.dist;
-      margin = (cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) ? m.contact_margin_human : 0.0;
+      margin = ((cc.g2 >= GEOM_HUMAN0 && cc.g2 < GEOM_TABLE) || (cc.g1 >= GEOM_HUMAN0 && cc.g1 < GEOM_TABLE)) ? m.contact_margin_human : 0.0;   // a human geom on either side
       const bool rb1 = cc.b1 >= 0 && cc.b1 < NV, rb2 = cc.b2 >= 0 && cc.b2 < NV;
       diag = (rb1 ? m.body_invweight0[cc.b1] : 0.0) + (rb2 ? m.body_invweight0[cc.b2] : 0.0);
       const int am1 = rb1 ? dm->anc_mask[cc.b1] : 0, am2 = rb2 ? dm->anc_mask[cc.b2] : 0;

@@ -1397,26 +1397,46 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
     base += __popcll(mask);
   }
 #if HRG_BOX
-  { // the cube: lanes 0..9 robot capsule - cube, 16..23 table - cube corners, 24..31 floor - cube corners
+  { // the cube, pass 0: lanes 0..9 robot capsule - cube, 16..23 table - cube corners, 24..31 floor - cube corners;
+    // pass 1: lanes 0..23 human capsule - cube (human.xml:5: the human's geoms collide with the manipulation object like everything else -- contype / conaffinity
+    // 7, margin 0.001; the animated human does not yield).  One copy of the capsule - box narrowphase serves both; the human's contacts close the list, the robot's
+    // and the table's come first into the NCON_DYN the solve takes.  Pass 1 runs only when the human does not hold the object and a capsule's bounding sphere reaches the cube's.
     hrg_box_state& bx = L.bx;
     if (lane == 0) { double Rm[9]; quat2mat(Rm, bx.quat); for (int a = 0; a < 9; a++) L.bR[a] = Rm[a]; }
     wave_sync();
+    const double hb[3] = {m.box_half[0], m.box_half[1], m.box_half[2]};
+#pragma unroll 1
+    for (int pass = 0; pass < 2; pass++) {
     bool hit = false;
     Contact c;
     c.g1 = c.g2 = c.b1 = c.b2 = 0; c.dist = 0; v3set(c.n, 0, 0, 1); v3set(c.pos, 0, 0, 0);
-    const double hb[3] = {m.box_half[0], m.box_half[1], m.box_half[2]};
-    if (lane < HRG_NRCAP || (lane >= 40 && lane < 40 + HRG_NRCAP)) {   // lanes 40..: the second contact of a capsule lying along a face (behind the corner contacts)
-      const bool second = lane >= 40;
-      const int i = second ? lane - 40 : lane;
-      if (m.rcap_body[i] >= 0) {
+    // capsule lanes: the first contact of capsule i on lane i, the second one of a capsule lying along a face on lane SEC0 + i (behind the corner contacts)
+    const int ncap = pass ? HRG_NHB : HRG_NRCAP, sec0 = pass ? 32 : 40;
+    const bool cap_lane = lane < ncap || (lane >= sec0 && lane < sec0 + ncap);
+    const bool second = lane >= sec0;
+    const int i = cap_lane ? (second ? lane - sec0 : lane) : 0;
+    const double* a1 = pass ? &L.hcap[i][0] : &L.rcapw[i][0];
+    const double rad = pass ? m.hcap_r[i] : m.rcap_r[i], margin = pass ? m.contact_margin_human : 0.0;
+    bool live = cap_lane && (pass ? true : m.rcap_body[i] >= 0);
+    if (pass) {   // broadphase of the human pass: bounding spheres.  No human contacts for an object the human holds (weld / connects active): it lies partly inside
+                  // the human's BOUNDING capsules (oracle: collide)
+      if (bx.weld_active || HRG_LIFT) break;   // (lifting: the board's pose between the hands stays inside them when let go)
+      double d2 = 0;
+      for (int a = 0; a < 3; a++) { const double d = 0.5 * (a1[a] + a1[3 + a]) - bx.pos[a]; d2 += d * d; }
+      const double reach = dm->hcap_hl[i] + rad + margin + fsqrt(hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2]) + 1e-9;
+      live = live && d2 <= reach * reach;
+      if (!__any(live)) break;
+    }
+    if (cap_lane) {
+      if (live) {
         double cs[3], cb[3];
-        const double e2 = seg_box(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, cs, cb);
+        const double e2 = seg_box(a1, a1 + 3, bx.pos, L.bR, hb, cs, cb);
         double dd = fsqrt(e2);
-        double dist = dd - m.rcap_r[i];
-        if (dist < 0) {
+        double dist = dd - rad;
+        if (dist < margin) {
           double s2[3], b2[3];
-          const bool two = dd > 1e-9 && cap_box_two(&L.rcapw[i][0], &L.rcapw[i][3], bx.pos, L.bR, hb, m.rcap_r[i], cs, cb, second ? 1 : 0, s2, b2);
-          if (two) { v3cpy(cs, s2); v3cpy(cb, b2); double dv[3]; v3sub(dv, cb, cs); dd = v3norm(dv); dist = dd - m.rcap_r[i]; }
+          const bool two = dist < 0 && dd > 1e-9 && cap_box_two(a1, a1 + 3, bx.pos, L.bR, hb, rad, cs, cb, second ? 1 : 0, s2, b2);
+          if (two) { v3cpy(cs, s2); v3cpy(cb, b2); double dv[3]; v3sub(dv, cb, cs); dd = v3norm(dv); dist = dd - rad; }
           hit = two || !second;
           if (dd > 1e-9) { v3sub(c.n, cb, cs); v3scl(c.n, c.n, 1.0 / dd); }
           else { // capsule axis inside the cube: push out through the nearest face
@@ -1426,13 +1446,14 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
             for (int a = 0; a < 3; a++) { loc[a] = L.bR[a] * rel[0] + L.bR[3 + a] * rel[1] + L.bR[6 + a] * rel[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
             const double sg = loc[ax] >= 0 ? -1.0 : 1.0;
             for (int a = 0; a < 3; a++) c.n[a] = sg * L.bR[3 * a + ax];
-            dist = -best - m.rcap_r[i];
+            dist = -best - rad;
           }
-          v3madd(c.pos, cs, c.n, m.rcap_r[i] + 0.5 * dist);
-          c.g1 = i; c.g2 = GEOM_BOX; c.b1 = m.rcap_body[i]; c.b2 = BODY_BOX; c.dist = dist;
+          v3madd(c.pos, cs, c.n, rad + 0.5 * dist);
+          c.g1 = pass ? GEOM_HUMAN0 + i : i; c.g2 = GEOM_BOX; c.b1 = pass ? -2 : m.rcap_body[i]; c.b2 = BODY_BOX; c.dist = dist;
         }
       }
     }
+    else if (pass) {}
 #if HRG_LIFT
     // CollaborativeLiftingCart: the board against the table slab (0.4 m wide, 5 cm thick, one metre in front of the robot: collaborative_lifting_cartesian_env.py:
     // 280-284, 742-746) by box-box contacts -- the two overlap in a cross, no corner of either lies over the other.  Lane 16 runs the pair (SAT + clipping, D13)
@@ -1481,7 +1502,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
       }
     }
 #if HRG_HANDOVER
-    { // RobotHumanHandoverCart._get_object_palm_contact_pos (476-505): does the cube touch the palm (= the collision capsule of the holding hand's body)?
+    if (pass == 0) { // RobotHumanHandoverCart._get_object_palm_contact_pos (476-505): does the cube touch the palm (= the collision capsule of the holding hand's body)?
       bool palm = false;
       if (m.task == HRG_TASK_HANDOVER_R2H && lane == 32) {
         const int hl = dm->clips.clip_holding_hand[clip_of(dm, (int64_t)L.st.stream_id, L.st.episode, L.st.anim_index)];
@@ -1498,11 +1519,13 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
       if (idx < NCON_DYN) L.con[idx] = c;
       if (idx < HRG_NCON_MAX) { L.st.con_pairs[idx][0] = c.g1; L.st.con_pairs[idx][1] = c.g2; }
     }
-    // _check_grasp: both fingers touch the cube (contacts beyond HRG_NCON_MAX are not reported and do not count)
-    const int slot = base + __popcll(mask & lt);
-    const bool f0 = __any(hit && lane == HRG_NRCAP - 2 && slot < HRG_NCON_MAX), f1 = __any(hit && lane == HRG_NRCAP - 1 && slot < HRG_NCON_MAX);
-    bx.gripped = f0 && f1;
+    if (pass == 0) {   // _check_grasp: both fingers touch the cube (contacts beyond HRG_NCON_MAX are not reported and do not count)
+      const int slot = base + __popcll(mask & lt);
+      const bool f0 = __any(hit && lane == HRG_NRCAP - 2 && slot < HRG_NCON_MAX), f1 = __any(hit && lane == HRG_NRCAP - 1 && slot < HRG_NCON_MAX);
+      bx.gripped = f0 && f1;
+    }
     base += __popcll(mask);
+    }
   }
 #endif
 #if HRG_STACK

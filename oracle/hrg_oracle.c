@@ -1284,6 +1284,46 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       v3madd(pos, second_s[q], nn, m->rcap_r[i] + 0.5 * dist);
       EMIT(i, GEOM_BOX, m->rcap_body[i], BODY_BOX, dist, nn, pos);
     }
+    /* human capsule - object (human.xml:5: contype / conaffinity 7, margin 0.001 -- the human's geoms collide with the manipulation object like everything else;
+     * the human itself is animated and does not yield).  The same narrowphase as for the arm's capsules, with the human geoms' contact margin; these contacts
+     * close the list: the robot's and the table's come first into the HRG_NCON_DYN_BOX the solve takes.
+     * NOT while the human holds the object (weld / connects active): the human here is a set of BOUNDING capsules of its meshes (D1), and an object in its hands
+     * lies partly inside them -- the held board of the lifting task reaches into the capsules of pelvis and thighs, a welded cube into the hand's -- where the
+     * reference's mesh hulls leave it free; those contacts would be artefacts of the approximation fighting the weld. */
+    n_second = 0;
+    int second_h[HRG_NHB];
+    double second_hs[HRG_NHB][3], second_hb[HRG_NHB][3];
+    for (int b = 0; b < HRG_NHB && !bx->weld_active && m->task != HRG_TASK_LIFTING; b++) { /* (lifting: the board's pose between the hands stays inside them when let go) */
+      double t, cs[3], cb[3], nn[3], pos[3], s2[2][3], b2[2][3];
+      const double r = m->hcap_r[b];
+      double e2 = seg_box(h->cap1[b], h->cap2[b], bx->pos, Rx, hb, &t, cs, cb), dd = sqrt(e2), dist = dd - r;
+      if (!(dist < m->contact_margin_human)) continue;
+      if (dist < 0 && dd > 1e-9 && cap_box_two(h->cap1[b], h->cap2[b], bx->pos, Rx, hb, r, cs, cb, s2, b2)) {
+        v3cpy(cs, s2[0]); v3cpy(cb, b2[0]);
+        v3sub(nn, cb, cs); dd = v3norm(nn); dist = dd - r;
+        second_h[n_second] = b; v3cpy(second_hs[n_second], s2[1]); v3cpy(second_hb[n_second], b2[1]); n_second++;
+      }
+      if (dd > 1e-9) { v3sub(nn, cb, cs); v3scl(nn, nn, 1.0 / dd); }
+      else {
+        double loc[3], best = 1e300; int ax = 0;
+        v3sub(pos, cs, bx->pos);
+        for (int a = 0; a < 3; a++) { loc[a] = Rx[a] * pos[0] + Rx[3 + a] * pos[1] + Rx[6 + a] * pos[2]; if (hb[a] - fabs(loc[a]) < best) { best = hb[a] - fabs(loc[a]); ax = a; } }
+        double sg = loc[ax] >= 0 ? -1.0 : 1.0;
+        for (int a = 0; a < 3; a++) nn[a] = sg * Rx[3 * a + ax];
+        dist = -best - r;
+      }
+      v3madd(pos, cs, nn, r + 0.5 * dist);
+      EMIT(GEOM_HUMAN0 + b, GEOM_BOX, -2, BODY_BOX, dist, nn, pos);
+    }
+    for (int q = 0; q < n_second; q++) {
+      const int b = second_h[q];
+      double nn[3], pos[3];
+      v3sub(nn, second_hb[q], second_hs[q]);
+      const double dd = v3norm(nn), dist = dd - m->hcap_r[b];
+      v3scl(nn, nn, 1.0 / dd);
+      v3madd(pos, second_hs[q], nn, m->hcap_r[b] + 0.5 * dist);
+      EMIT(GEOM_HUMAN0 + b, GEOM_BOX, -2, BODY_BOX, dist, nn, pos);
+    }
   }
 #undef EMIT
   return n;
@@ -2123,7 +2163,7 @@ static void env_step(hrgo_batch* B, int e, double* action, float* obs, float* te
       v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
       v3scl(t1, t1, 1.0 / v3norm(t1));
       v3cross(t2, n, t1);
-      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      double margin = (con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE) || (con[c].g1 >= GEOM_HUMAN0 && con[c].g1 < GEOM_TABLE) ? m->contact_margin_human : 0.0; /* a human geom on either side */
       for (int d = 0; d < 4; d++) {
         double dir[3], J[NVT] = {0};
         const double* tt = d < 2 ? t1 : t2;
@@ -2938,7 +2978,7 @@ static void env_step_stack(hrgo_batch* B, int e, double* action, float* obs, flo
       v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
       v3scl(t1, t1, 1.0 / v3norm(t1));
       v3cross(t2, n, t1);
-      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      double margin = (con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE) || (con[c].g1 >= GEOM_HUMAN0 && con[c].g1 < GEOM_TABLE) ? m->contact_margin_human : 0.0; /* a human geom on either side */
       for (int d = 0; d < 4; d++) {
         double dir[3], J[NVMAX] = {0};
         const double* tt = d < 2 ? t1 : t2;
@@ -3508,7 +3548,7 @@ static void env_step_hammer(hrgo_batch* B, int e, double* action, float* obs, fl
       v3cross(t1, n, fabs(n[0]) < 0.5 ? e1 : e2);
       v3scl(t1, t1, 1.0 / v3norm(t1));
       v3cross(t2, n, t1);
-      double margin = con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE ? m->contact_margin_human : 0.0;
+      double margin = (con[c].g2 >= GEOM_HUMAN0 && con[c].g2 < GEOM_TABLE) || (con[c].g1 >= GEOM_HUMAN0 && con[c].g1 < GEOM_TABLE) ? m->contact_margin_human : 0.0; /* a human geom on either side */
       for (int d = 0; d < 4; d++) {
         double dir[3], J[NVMAX] = {0};
         const double* tt = d < 2 ? t1 : t2;

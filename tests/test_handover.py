@@ -232,7 +232,7 @@ def test_collaboration_tasks_long_run_stays_finite(env_id, shield):
         if k % 40 == 39:
             o = obs.cpu().numpy()
             assert np.isfinite(o).all() and np.isfinite(r.cpu().numpy()).all()
-            assert (o[:, 49] > 0.5).all() and (o[:, 49] < 2.5).all()           # object height: on the table, in a hand, or on the floor
+            assert (o[:, 49] > 0.015).all() and (o[:, 49] < 2.5).all()         # object height: on the table, in a hand, or -- pushed off the table by the human -- on the floor (z = 0; the cube's half size is 0.02)
             _, bx = G.get_states(np.arange(0, n, 16))
             phases += np.bincount([b.task_phase for b in bx], minlength=8)
             assert max(abs(np.linalg.norm(list(b.quat)) - 1) for b in bx) < 1e-12
