@@ -39,7 +39,7 @@ sys.path.insert(0, ROOT)
 ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector peak
-DEFAULT_PMC = os.path.join(ROOT, "profiles", "r02_pmc.json")
+DEFAULT_PMC = os.path.join(ROOT, "profiles", "r03_pmc.json")
 
 
 def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):

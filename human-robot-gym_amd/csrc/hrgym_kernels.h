@@ -1466,7 +1466,11 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         const double pt[3] = {m.table_center[0], m.table_center[1], m.table_top_z - 0.025}, ht[3] = {m.table_half[0], m.table_half[1], 0.025};
         double d2 = 0;
         for (int a = 0; a < 3; a++) { const double la = fabs(bx.pos[a] - pt[a]) - ht[a]; if (la > 0) d2 += la * la; }
-        if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9)) {
+        // ... and the board's extent along z against the slab's (a separating axis of the pair: box_box2 would find no contact): the board is carried 9 cm above the
+        // table, so the SAT + clipping below -- one lane, its index arrays in scratch: 5.6 KB of partial-line scratch writes per substep, 576 MB per launch -- runs
+        // only for a board that has come down
+        const double ez = fabs(L.bR[6]) * hb[0] + fabs(L.bR[7]) * hb[1] + fabs(L.bR[8]) * hb[2];
+        if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9) && bx.pos[2] - ez < m.table_top_z + 1e-9 && bx.pos[2] + ez > m.table_top_z - 0.05 - 1e-9) {
           const double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
           BBContact bc[4];
           nb = box_box2(pt, Rt, ht, bx.pos, L.bR, hb, bc, T);

@@ -1257,7 +1257,8 @@ static int collide(const hrg_model_desc* m, const robot_kin* k, const human_kin*
       const double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
       double d2 = 0;
       for (int a = 0; a < 3; a++) { const double la = fabs(bx->pos[a] - pt[a]) - ht[a]; if (la > 0) d2 += la * la; }
-      if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9)) { /* broadphase: the board's circumsphere against the slab itself */
+      const double ez = fabs(Rx[6]) * hb[0] + fabs(Rx[7]) * hb[1] + fabs(Rx[8]) * hb[2]; /* the board's half extent along z: a separating axis of the pair */
+      if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9) && bx->pos[2] - ez < m->table_top_z + 1e-9 && bx->pos[2] + ez > m->table_top_z - 0.05 - 1e-9) { /* broadphase: the board's circumsphere against the slab itself, then its z extent */
         bb_contact bc[4];
         const int nb = box_box2(pt, Rt, ht, bx->pos, Rx, hb, bc);
         for (int q = 0; q < nb; q++) EMIT(GEOM_TABLE, GEOM_BOX, -1, BODY_BOX, bc[q].dist, bc[q].n, bc[q].pos);
