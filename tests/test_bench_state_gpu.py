@@ -108,21 +108,22 @@ def _compare_part(name, k, G, O, a_np, kind, tally):
     return post
 
 
-def _run(env, shield="SSM", robot_geometry="capsule"):
+def _run(env, shield="SSM", robot_geometry="capsule", ik=False):
     import torch
     import bench
     import human_robot_gym_amd as hrg
     from human_robot_gym_amd import mixed
     from oracle.oracle import OracleBatch
-    W = bench.bench_workload(env, shield, robot_geometry=robot_geometry)
+    W = bench.bench_workload(env, shield, ik=ik, robot_geometry=robot_geometry)
     G, desc, mixed_tasks, staggered = bench.make_bench_batch(W)
     n = W["n"]
     assert n == (8192 if env == "PickPlaceHumanCart" else 4096)
-    pool = bench.bench_action_pool(n, G.device)
+    pool = bench.bench_action_pool(n, G.device, ik=ik)
+    step_hip = (lambda a: G.step(a.clone())) if ik else G.step     # (with the wrappers on the kernel writes the executed joint actions over the rows it was given)
     pre = bench.bench_preroll_steps(desc) + 20     # bench.py: pre-roll of one horizon (at most 1000 steps), then the default 20 warm-up steps
     t0 = time.time()
     for k in range(pre):
-        G.step(pool[k % len(pool)])
+        step_hip(pool[k % len(pool)])
     torch.cuda.synchronize()
     t_roll = time.time() - t0
     # the checker's batches: same model, same clips, same global env ids -- and from here on the HIP batch's own state
@@ -143,14 +144,14 @@ def _run(env, shield="SSM", robot_geometry="capsule"):
     t0 = time.time()
     for k in range(N_STEPS):
         a = pool[(pre + k) % len(pool)]
-        G.step(a)
+        step_hip(a)
         torch.cuda.synchronize()
         a_np = a.cpu().numpy()
         for (eid, b, sl), O in zip(parts, oracles):
             post = _compare_part(eid, k, b, O, a_np[sl].copy(), _kinds(eid), tally)
             _hip_set_states(b, _kinds(eid), *post)      # resynchronise: the next step starts from the oracle's state on both sides
     live = tally["compared"] / tally["total"]
-    line = dict(test=f"test_bench_state_gpu::{env}_{shield}" + ("" if robot_geometry == "capsule" else f"_{robot_geometry}"), n=n, preroll=pre, steps=N_STEPS, live=live, seconds_preroll=round(t_roll, 1), seconds_compare=round(time.time() - t0, 1), **tally)
+    line = dict(test=f"test_bench_state_gpu::{env}_{shield}" + ("" if robot_geometry == "capsule" else f"_{robot_geometry}") + ("_ik" if ik else ""), n=n, preroll=pre, steps=N_STEPS, live=live, seconds_preroll=round(t_roll, 1), seconds_compare=round(time.time() - t0, 1), **tally)
     print("[parity]", line)
     try:
         import json
@@ -176,10 +177,23 @@ def test_reach_human_4096_steady_state_matches_oracle(shield):
         assert t["unsafe"] > 0, "a steady-state SSM batch has envs under fail-safe manoeuvres"
 
 
-def test_reach_human_4096_with_hull_geometry_matches_oracle():
-    """The headline workload with the arm links colliding as the convex hulls of their meshes (bench.py --robot-geometry hull; shield OFF: the batch with the most
+@pytest.mark.parametrize("shield", ["OFF", "SSM"])
+def test_reach_human_4096_with_hull_geometry_matches_oracle(shield):
+    """The headline workload with the arm links colliding as the convex hulls of their meshes (bench.py --robot-geometry hull; shield OFF is the batch with the most
     robot-human contacts)."""
-    t = _run("ReachHuman", "OFF", robot_geometry="hull")
+    t = _run("ReachHuman", shield, robot_geometry="hull")
+    if shield == "OFF":
+        assert t["contacts"] > 0
+
+
+def test_pick_place_8192_cartesian_front_end_matches_oracle():
+    """bench.py --env PickPlaceHumanCart --ik: Cartesian actions through the in-kernel IK front-end and the collision-prevention screen, 8192 envs."""
+    _run("PickPlaceHumanCart", ik=True)
+
+
+def test_hammering_4096_steady_state_matches_oracle():
+    """The seventh task at benchmark size: the 24-DoF system with the noslip post-pass (bench.py --env CollaborativeHammeringCart)."""
+    t = _run("CollaborativeHammeringCart")
     assert t["contacts"] > 0
 
 
