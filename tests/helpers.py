@@ -11,7 +11,7 @@ RTOL = 1e-5
 ATOL = 1e-7
 
 
-def record_live(test, live, floor):
+def record_live(test, live, floor, **extra):
     """Free-running comparisons drop an env once its oracle trajectory turns violent (|qvel| > 5 rad/s or a crash: chaotic from then on).  The fraction
     that stayed in is printed, appended to gpurun_out/parity_live.jsonl (so that the floors below are the levels the runs actually achieve) and
     asserted against `floor`."""
@@ -23,7 +23,7 @@ def record_live(test, live, floor):
         out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
         os.makedirs(out, exist_ok=True)
         with open(os.path.join(out, "parity_live.jsonl"), "a") as f:
-            f.write(json.dumps(dict(test=test, live=frac, n=int(len(live)), floor=floor)) + "\n")
+            f.write(json.dumps(dict(test=test, live=frac, n=int(len(live)), floor=floor, **extra)) + "\n")
     except OSError:
         pass
     assert frac >= floor, f"{test}: too many envs dropped as chaotic: live fraction {frac:.3f} < {floor}"

@@ -79,5 +79,5 @@ def test_contacts_and_collisions_occur():
         a[:, 1] = np.where(np.arange(len(a)) % 2 == 0, 1.0, -1.0)  # tilt the arm towards / away from the hand
         a[:, [0, 2, 3, 4, 5]] *= 0.2
         return a
-    n_coll = _rollout(kw, n_envs=16, n_steps=22, seed=5, resync=True, clips=clips, action_fn=act, min_live=0.0, name="contacts")
+    n_coll = _rollout(kw, n_envs=16, n_steps=22, seed=5, resync=True, clips=clips, action_fn=act, min_live=0.75, name="contacts")   # (measured: 16 of 16)
     assert n_coll > 0, "scenario was meant to produce collisions"

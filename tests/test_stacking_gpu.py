@@ -72,6 +72,7 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
                 fo, fg = (np.array([x for c in range(4) for x in list(B.get_stack(e).pos[c]) + list(B.get_stack(e).quat[c])]) for B in (O, G))
                 assert np.abs(fo - fg).max() < 1e-7, f"{msg} env {e}: contact lists differ and so do the cubes ({np.abs(fo - fg).max():.2e})"
                 live[e] = chk[e] = False
+                stats["flicker"] = stats.get("flicker", 0) + 1      # counted apart from the violent drops
         np.testing.assert_array_equal(ng[chk], no[chk], err_msg=msg)        # contact-pair indices bit-exact
         np.testing.assert_array_equal(pg[chk], po[chk], err_msg=msg)
         np.testing.assert_array_equal(i_g.cpu().numpy()[chk], i_o[chk], err_msg=msg)
@@ -90,7 +91,7 @@ def _rollout(O, G, n, n_steps, seed, resync, name, scenario=None, min_live=0.9, 
             if resync:
                 G.set_state(e, post[e])
                 G.set_stack(e, psk[e])
-    record_live(f"test_stacking_gpu::{name}", live, min_live)
+    record_live(f"test_stacking_gpu::{name}", live, min_live, dropped_contact_list_flicker=stats.get("flicker", 0), dropped_violent=int(len(live) - int(np.sum(live)) - stats.get("flicker", 0)))
     O.close(); G.close()
     return stats
 
@@ -106,7 +107,7 @@ def test_random_actions_parity_resync(shield):
 
 def test_random_actions_parity_free_running():
     O, G, _ = _pair(16, dict(shield_type="SSM", horizon=30, seed=3))
-    st = _rollout(O, G, 16, 50, 2, False, "random_free", min_live=0.5)   # incl. auto-resets; most envs leave when the human drops its first cube
+    st = _rollout(O, G, 16, 50, 2, False, "random_free", min_live=0.85)   # incl. auto-resets (measured: 15 of 16 stay in; the floor leaves one more env of margin)
     assert st["cube_contacts"] > 0
 
 
@@ -133,7 +134,7 @@ def test_cube_stacks_parity():
     st = _rollout(O, G, 6, 14, 3, True, "stacks", scenario=_stacks(d), act_scale=0.3)
     assert st["cube_cube"] >= 4 * 6 and st["max_ncon"] >= 12
     O, G, d = _pair(6, dict(shield_type="OFF", horizon=100, seed=4))
-    _rollout(O, G, 6, 10, 3, False, "stacks_free", scenario=_stacks(d), act_scale=0.3, min_live=0.8)
+    _rollout(O, G, 6, 10, 3, False, "stacks_free", scenario=_stacks(d), act_scale=0.3, min_live=0.83)   # (measured: 6 of 6)
 
 
 def test_scripted_episode_through_success_parity():
