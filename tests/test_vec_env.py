@@ -236,3 +236,26 @@ def test_monitor_rows_do_not_depend_on_the_info_dicts(tmp_path):
         assert lines[1] == "r,l,t,n_goal_reached,timeout"
         rows[flag] = [l.split(",")[:2] + l.split(",")[3:] for l in lines[2:]]   # (without the wall-clock column)
     assert len(rows[True]) >= 12 and rows[True] == rows[False]
+
+
+def test_robot_geometry_reaches_the_model_through_the_vec_env():
+    """`HipVecEnv(robot_geometry="hull")` composes the model with the arm links' hull tables (the backend factory sees the description the env built); the default
+    stays the capsule model, the object tasks refuse hulls (no hull - box narrowphase)."""
+    clips = hrg.synthetic_clips(2, seed=0, min_frames=100, max_frames=120)
+    seen = {}
+
+    def factory(desc, clips_, n, env_id0):
+        seen["hulls"] = (int(desc.robot_hulls), list(desc.hull_off))
+        return OracleBackend(desc, clips_, n)
+
+    env = HipVecEnv(3, env_kwargs=dict(shield_type="OFF", horizon=20), clips=clips, backend=factory, robot_geometry="hull")
+    assert seen["hulls"][0] == 1 and seen["hulls"][1][-1] == 4321
+    env.reset()
+    obs, r, d, info = env.step(np.zeros((3, 7)))
+    assert np.isfinite(obs).all()
+    env.close()
+    env = HipVecEnv(3, env_kwargs=dict(shield_type="OFF", horizon=20), clips=clips, backend=factory)
+    assert seen["hulls"][0] == 0
+    env.close()
+    with pytest.raises(ValueError):
+        hrg.build_model_desc(None, robot_geometry="mesh")
