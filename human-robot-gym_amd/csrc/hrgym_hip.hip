@@ -1209,7 +1209,7 @@ PH_DYNSTEP int dynamics_step(const DevModel* __restrict__ dm_, int lane, int nco
       v3cross(tau, Lw, w);   // -(w x L)
       for (int k = 0; k < 3; k++) tl[k] = (L.bR[k] * tau[0] + L.bR[3 + k] * tau[1] + L.bR[6 + k] * tau[2]) / m.box_inertia[k];
       for (int k = 0; k < 3; k++) ar[k] = L.bR[3 * k] * tl[0] + L.bR[3 * k + 1] * tl[1] + L.bR[3 * k + 2] * tl[2];
-      a0v = ar[a - 3];
+      a0v = a == 3 ? ar[0] : (a == 4 ? ar[1] : ar[2]);   // (selects: an index would put ar[] into scratch memory)
       Ma0v = L.bMr[3 * (a - 3)] * ar[0] + L.bMr[3 * (a - 3) + 1] * ar[1] + L.bMr[3 * (a - 3) + 2] * ar[2];
     }
     L.a0[lane] = a0v;

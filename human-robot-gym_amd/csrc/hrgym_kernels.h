@@ -779,8 +779,12 @@ DI void shield_reset(const DevModel* __restrict__ /*dm_*/, int lane) {
 // near-ties between separating axes / candidate depths go to the earlier one unless the later wins by this margin (1 nm)
 #define BB_TIE 1e-9
 struct BBContact { double pos[3], n[3], dist; };
+// T: 144 doubles of the caller's LDS scratch -- the candidate table (72) and the function's index-addressed arrays (axes, their products, the clipping frame: as
+// private arrays they live in scratch memory, and a single lane's scratch stores cost a partial cache line each: 5.6 KB of HBM writes per call)
+#define BB_WORK 152   // (138 used by box_box2; the rest is the caller's: the lifting task keeps the slab's and the board's extents there)
 DI int box_box2(const double* pa, const double* Ra, const double* ha, const double* pb, const double* Rb, const double* hb, BBContact* out, double* T) {
-  double A[3][3], B[3][3], C[3][3], AC[3][3], t[3], ta[3], tb[3];
+  double (*A)[3] = (double (*)[3])(T + 72), (*B)[3] = (double (*)[3])(T + 81), (*C)[3] = (double (*)[3])(T + 90), (*AC)[3] = (double (*)[3])(T + 99);
+  double t[3], ta[3], tb[3];
   v3sub(t, pb, pa);
   for (int i = 0; i < 3; i++) for (int k = 0; k < 3; k++) { A[i][k] = Ra[3 * k + i]; B[i][k] = Rb[3 * k + i]; }
   for (int i = 0; i < 3; i++) { ta[i] = v3dot(t, A[i]); tb[i] = v3dot(t, B[i]); for (int j = 0; j < 3; j++) { C[i][j] = v3dot(A[i], B[j]); AC[i][j] = fabs(C[i][j]); } }
@@ -831,7 +835,8 @@ DI int box_box2(const double* pa, const double* Ra, const double* ha, const doub
   }
   const bool refA = bf < 3;
   const int r = refA ? bf : bf - 3, r1 = (r + 1) % 3, r2 = (r + 2) % 3;
-  double Rf[3][3], In[3][3], pr[3], pi_[3];
+  double (*Rf)[3] = (double (*)[3])(T + 108), (*In)[3] = (double (*)[3])(T + 117);
+  double pr[3], pi_[3];
   for (int a = 0; a < 3; a++) for (int k = 0; k < 3; k++) { Rf[a][k] = refA ? A[a][k] : B[a][k]; In[a][k] = refA ? B[a][k] : A[a][k]; }
   for (int k = 0; k < 3; k++) { pr[k] = refA ? pa[k] : pb[k]; pi_[k] = refA ? pb[k] : pa[k]; }
   const double* hr = refA ? ha : hb;   // half extents of the reference / the incident box
@@ -848,7 +853,7 @@ DI int box_box2(const double* pa, const double* Ra, const double* ha, const doub
   v3madd(ci, pi_, In[k], si * hi[k]);
   const double hu = hr[r1], hv = hr[r2];
   const double S1[4] = {1, -1, -1, 1}, S2[4] = {1, 1, -1, -1};
-  double vu[4], vv[4], vd[4];
+  double *vu = T + 126, *vv = T + 130, *vd = T + 134;
   for (int q = 0; q < 4; q++) {
     double x[3], d[3];
     v3madd(x, ci, In[k1], S1[q] * hi[k1]);
@@ -1039,7 +1044,8 @@ DI void collide_cubes(const DevModel* __restrict__ dm_, int lane, int* base_io) 
         double d[3];
         v3sub(d, sk.pos[pb_], sk.pos[pa_]);
         // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
-        if (!(v3dot(d, d) > 4.0 * circ2)) nc = box_box(sk.pos[pa_], L.cR[pa_], sk.pos[pb_], L.cR[pb_], hb, bc, &L.Jc[40][0] + 72 * lane);
+        static_assert(40 * 21 + 6 * BB_WORK <= 4 * NCON_DYN * 21, "box_box2 workspace of the six cube pairs");
+        if (!(v3dot(d, d) > 4.0 * circ2)) nc = box_box(sk.pos[pa_], L.cR[pa_], sk.pos[pb_], L.cR[pb_], hb, bc, &L.Jc[40][0] + BB_WORK * lane);
       }
       // exclusive prefix of the contact counts over lanes 0..5
       int pre = 0, tot = 0;
@@ -1211,7 +1217,8 @@ DI void collide_hammer(const DevModel* __restrict__ dm_, int lane, int* base_io)
         }
         const double ra = fsqrt(ha[0] * ha[0] + ha[1] * ha[1] + ha[2] * ha[2]) + 1e-9;
         // candidate scratch: the tail of the (dead) solver rows; the collide arrays (hcap, rcapw, cur) sit in the first 1.7 KB of the same union
-        if (!(d2 > ra * ra)) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + 72 * lane);
+        static_assert(40 * (NVS + 1) + 4 * BB_WORK <= (4 * NCON_DYN + HROW_NEQ) * (NVS + 1), "box_box2 workspace of the four box pairs");
+        if (!(d2 > ra * ra)) nc = box_box2(L.gc[ga], L.gR[1], ha, L.gc[gb], L.gR[0], hb, bc, &L.Jc[40][0] + BB_WORK * lane);
       }
       int pre = 0, tot = 0;
       for (int q = 0; q < 4; q++) { const int nq = __shfl(nc, q, 64); if (q < lane) pre += nq; tot += nq; }
@@ -1459,21 +1466,24 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
     // 280-284, 742-746) by box-box contacts -- the two overlap in a cross, no corner of either lies over the other.  Lane 16 runs the pair (SAT + clipping, D13)
     // when the board's circumsphere comes near the slab, lanes 16..19 take one contact each; the corner-against-plane test below is left to the floor.
     else if (lane >= 16 && lane < 24) {
-      double* T = &L.Jc[20][0];      // scratch behind the collide arrays (the solver rows are dead here): 72 doubles of candidates, then the contacts
-      double* res = &L.Jc[26][0];
+      double* T = &L.Jc[20][0];      // scratch behind the collide arrays (the solver rows are dead here): BB_WORK doubles for box_box2, then the contacts
+      double* res = &L.Jc[34][0];
+      static_assert(20 * (NVS + 1) + BB_WORK <= 32 * (NVS + 1) && 34 * (NVS + 1) + 28 <= (4 * NCON_DYN + 6) * (NVS + 1), "box_box2 workspace");
       int nb = 0;
       if (lane == 16) {
         const double pt[3] = {m.table_center[0], m.table_center[1], m.table_top_z - 0.025}, ht[3] = {m.table_half[0], m.table_half[1], 0.025};
         double d2 = 0;
         for (int a = 0; a < 3; a++) { const double la = fabs(bx.pos[a] - pt[a]) - ht[a]; if (la > 0) d2 += la * la; }
         // ... and the board's extent along z against the slab's (a separating axis of the pair: box_box2 would find no contact): the board is carried 9 cm above the
-        // table, so the SAT + clipping below -- one lane, its index arrays in scratch: 5.6 KB of partial-line scratch writes per substep, 576 MB per launch -- runs
-        // only for a board that has come down
+        // table, so the SAT + clipping below runs only for a board that has come down
         const double ez = fabs(L.bR[6]) * hb[0] + fabs(L.bR[7]) * hb[1] + fabs(L.bR[8]) * hb[2];
         if (!(d2 > hb[0] * hb[0] + hb[1] * hb[1] + hb[2] * hb[2] + 1e-9) && bx.pos[2] - ez < m.table_top_z + 1e-9 && bx.pos[2] + ez > m.table_top_z - 0.05 - 1e-9) {
-          const double Rt[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+          // box_box2 indexes centres and extents by axis numbers it finds: they go through LDS (private arrays would sit in scratch memory, as its own arrays did)
+          double *wpt = T + 138, *wht = T + 141, *whb = T + 144, *wRt = &L.Jc[32][0];
+          for (int a = 0; a < 3; a++) { wpt[a] = pt[a]; wht[a] = ht[a]; whb[a] = hb[a]; }
+          for (int a = 0; a < 9; a++) wRt[a] = (a & 3) == 0 ? 1.0 : 0.0;
           BBContact bc[4];
-          nb = box_box2(pt, Rt, ht, bx.pos, L.bR, hb, bc, T);
+          nb = box_box2(wpt, wRt, wht, bx.pos, L.bR, whb, bc, T);
           for (int q = 0; q < nb; q++) { for (int a = 0; a < 3; a++) { res[7 * q + a] = bc[q].pos[a]; res[7 * q + 3 + a] = bc[q].n[a]; } res[7 * q + 6] = bc[q].dist; }
         }
       }
