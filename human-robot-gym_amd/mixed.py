@@ -24,11 +24,11 @@ ICRA_TASKS = (
 
 # ... and with the one task of the reference that is not part of that suite (CollaborativeHammeringCart has no experiment config): every task the stepper covers
 ALL_TASKS = ICRA_TASKS + (("CollaborativeHammeringCart", dict(horizon=1000, shield_type="SSM")),)
-# ms per 4096-env step of each task's kernel alone (profiles/r02t_tasks_summary.md): the mixed batch launches its kernels longest first.  The batch is bound by LDS residency
+# ms per 4096-env step of each task's kernel alone (profiles/r03t_tasks_summary.md): the mixed batch launches its kernels longest first.  The batch is bound by LDS residency
 # (the tasks' LDS images exceed the chip's 41 MB), so the order matters by 5 - 10 %, but which order wins did not reproduce from one GPU box to the next (round 2: a search over
 # all 720 orders and an A/B/A/B run, "short kernels first" 5.33 vs 5.60 ms on one box and 5.95 vs 5.71 ms on another).  Longest first is the order that was never the worst.
-_STEP_MS = {"CollaborativeHammeringCart": 8.9, "CollaborativeStackingCart": 7.44, "RobotHumanHandoverCart": 5.15, "HumanRobotHandoverCart": 4.86, "CollaborativeLiftingCart": 3.02,
-            "HumanObjectInspectionCart": 2.92, "PickPlaceHumanCart": 2.1, "ReachHuman": 1.32}
+_STEP_MS = {"CollaborativeHammeringCart": 11.5, "CollaborativeStackingCart": 6.27, "RobotHumanHandoverCart": 4.28, "HumanRobotHandoverCart": 3.93, "CollaborativeLiftingCart": 2.66,
+            "HumanObjectInspectionCart": 2.43, "PickPlaceHumanCart": 1.67, "ReachHuman": 1.00}
 
 
 def task_clips(env_id, n_clips=13, seed=0, **kw):
