@@ -45,6 +45,6 @@ say soak;       python3 tools/soak_tasks.py > $S/${TAG}_soak_tasks.log 2>&1
 python3 tools/soak_hammering.py 1500 random > $S/${TAG}_soak_hammering_random.log 2>&1
 python3 tools/soak_hammering.py 600 still > $S/${TAG}_soak_hammering_still.log 2>&1
 fi
-cp profiles/${TAG}* $S/ 2>/dev/null || true
+cp -n profiles/${TAG}* $S/ 2>/dev/null || true   # (what the summarisers wrote into profiles/; never over a file this run produced)
 (nproc; lscpu | head -20; cat /sys/fs/cgroup/cpu.max 2>/dev/null; uptime) > $S/${TAG}_host.txt 2>&1
 say done; ls $S
