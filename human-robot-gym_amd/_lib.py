@@ -25,7 +25,7 @@ EXPORTS = [
     "hrg_batch_step", "hrg_batch_contacts", "hrg_batch_capsules", "hrg_batch_get_state", "hrg_batch_set_state",
     "hrg_batch_kernel_time", "hrg_batch_enable_taps", "hrg_box_bytes", "hrg_batch_get_box", "hrg_batch_set_box", "hrg_batch_get_states", "hrg_batch_set_states",
     "hrg_batch_check_actions", "hrg_stack_bytes", "hrg_batch_get_stack", "hrg_batch_set_stack", "hrg_batch_launch_order",
-    "hrg_hammer_bytes", "hrg_batch_get_hammer", "hrg_batch_set_hammer",
+    "hrg_hammer_bytes", "hrg_batch_get_hammer", "hrg_batch_set_hammer", "hrg_test_hull_queries",
 ]
 
 
@@ -101,6 +101,7 @@ def load_library():
     lib.hrg_hammer_bytes.restype = ctypes.c_size_t
     lib.hrg_batch_get_hammer.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_hammer.argtypes = [vp, i32, vp, ctypes.c_size_t]
+    lib.hrg_test_hull_queries.argtypes = [vp, vp, vp, i32, vp]
     lib.hrg_stack_bytes.restype = ctypes.c_size_t
     lib.hrg_batch_get_stack.argtypes = [vp, i32, vp, ctypes.c_size_t]
     lib.hrg_batch_set_stack.argtypes = [vp, i32, vp, ctypes.c_size_t]

@@ -438,6 +438,10 @@ int hrg_batch_set_stack(hrg_batch* b, int32_t env, const void* buf_host, size_t 
 size_t hrg_hammer_bytes(void);
 int hrg_batch_get_hammer(hrg_batch* b, int32_t env, void* buf_host, size_t bytes);
 int hrg_batch_set_hammer(hrg_batch* b, int32_t env, const void* buf_host, size_t bytes);
+/* test tap of the hull variant (robot_hulls; oracle counterparts: hrgo_test_hull_segment / hrgo_test_hull_lowest): n queries {R[9] row-major, p[3], s1[3], s2[3], hull,
+ * pad} = 152 bytes each, against the vertex table (verts_host, off_host[HRG_NHULL + 1]) -> out_host[n][10] = GJK distance hull - segment, witness on the hull 3, witness
+ * on the segment 3, lowest point over a horizontal plane 3.  One wavefront per query runs the step kernel's own wave routines (csrc/hrgym_hull.h).  0 / -1. */
+int hrg_test_hull_queries(const double* verts_host, const int32_t* off_host, const void* queries_host, int32_t n, double* out_host);
 
 /* HumanEnv.check_collision_action (human_env.py:588-627; called by CollisionPreventionWrapper, wrappers/collision_prevention_wrapper.py:38-51, and
  * utils/training_utils.py:362-366): would the joint-space action drive the robot into the static scene or itself?  The goal configuration the

@@ -255,3 +255,38 @@ def test_hip_hull_variant_against_the_table():
             G.set_state(e, post[e])
     assert table > 0, "the scenario was meant to bring an arm link onto the table"
     O.close(); G.close()
+
+
+@pytest.mark.gpu
+def test_hip_wave_routines_match_the_oracle_on_random_poses(oracle_lib):
+    """hrg_test_hull_queries: the step kernel's own wave routines (support mapping with lanes = vertices, GJK with its simplex in LDS, lowest point), one wavefront
+    per query, against the oracle's scalar restatement -- 3500 random poses over the seven hulls, separated / touching / piercing segments."""
+    from human_robot_gym_amd._lib import load_library
+    lib = load_library()
+    V, off = load_robot_hulls()
+    d = hrg.build_model_desc(None, robot_geometry="hull")
+    rng = np.random.RandomState(7)
+    n = 3500
+    q = np.zeros(n, dtype=[("R", "f8", 9), ("p", "f8", 3), ("s1", "f8", 3), ("s2", "f8", 3), ("hull", "i4"), ("pad", "i4")])
+    assert q.dtype.itemsize == 152
+    want = np.zeros((n, 10))
+    o7, o3 = np.zeros(7), np.zeros(3)
+    for k in range(n):
+        h = k % NH
+        R, p = np.ascontiguousarray(_rot(rng)), rng.uniform(-0.5, 0.5, 3)
+        c = p + rng.randn(3) * (0.02 if k % 5 == 0 else 0.25)              # every fifth segment starts inside the link's bounding capsule: piercing / touching cases
+        s1, s2 = c + rng.randn(3) * 0.15, c - rng.randn(3) * 0.15
+        q[k] = (R.ravel(), p, s1, s2, h, 0)
+        oracle_lib.hrgo_test_hull_segment(ctypes.byref(d), h, _p(R), _p(p), _p(s1), _p(s2), _p(o7))
+        oracle_lib.hrgo_test_hull_lowest(ctypes.byref(d), h, _p(R), _p(p), _p(o3))
+        want[k, :7], want[k, 7:] = o7, o3
+    got = np.zeros((n, 10))
+    Vc, offc = np.ascontiguousarray(V), np.ascontiguousarray(off, np.int32)
+    assert lib.hrg_test_hull_queries(_p(Vc), _p(offc), q.ctypes.data_as(ctypes.c_void_p), n, _p(got)) == 0
+    pierced = want[:, 0] == 0.0
+    assert 50 < pierced.sum() < n // 2
+    np.testing.assert_array_equal(got[:, 0] == 0.0, pierced)                 # the same verdict on "the axis pierces the hull"
+    np.testing.assert_allclose(got[:, 0], want[:, 0], rtol=1e-10, atol=1e-12)   # distance
+    sep = ~pierced
+    np.testing.assert_allclose(got[sep, 1:7], want[sep, 1:7], rtol=0, atol=1e-9)   # witness points (a witness can slide along parallel features: both attain the distance)
+    np.testing.assert_allclose(got[:, 7:], want[:, 7:], rtol=0, atol=1e-12)  # lowest point
