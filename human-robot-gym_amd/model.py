@@ -103,7 +103,7 @@ HANDOVER_H2R_ENV_KWARGS = dict(
 HANDOVER_R2H_ENV_KWARGS = dict(
     PICK_PLACE_ENV_KWARGS,
     shield_type="PFL",
-    table_full_size=[1.0, 2.0, 0.05],
+    table_full_size=[1.5, 2.0, 0.05],   # (round 3: was the human-to-robot task's 1.0 m table by mistake; robot_human_handover_cartesian_env.py:305, RHH-*.yaml:63-66)
     human_animation_freq=90,
     human_rand=[0.0, 0.2, 0.1],
     n_animations_sampled_per_100_steps=2,
@@ -181,7 +181,7 @@ HAMMERING_ENV_KWARGS = dict(
     task_reward=1.0,
     human_animation_freq=100,
     human_rand=[0.0, 0.0, 0.0],
-    n_animations_sampled_per_100_steps=1,
+    n_animations_sampled_per_100_steps=5,   # default/human_env.yaml:60 through the task's default file (the constructor's own default is 1; round 3: was 1)
     gripper_controllable=False,
     noslip_iterations=20,       # self.sim.model.opt.noslip_iterations = 20 (_setup_references, 1161); 0 switches the pass off (round 2's model: the nail creeps)
     noslip_tolerance=1e-6,      # MuJoCo's default opt.noslip_tolerance
