@@ -267,7 +267,7 @@ def spawn_ranks(n, argv, script=None, deadline_s=3000.0, poll_s=0.2):
         raise
 
 
-def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None, robot_geometry="capsule"):
+def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None, robot_geometry="capsule", collision_prevention=False):
     """The benchmark's workloads by name (BASELINE.json configs): env kwargs as the reference's training configs set them, envs per GPU, wrappers.
     tests/test_bench_state_gpu.py builds its batches through this function and `make_bench_batch`, so what it compares with the oracle is what is timed."""
     pick_place = env != "ReachHuman"   # every other task carries the manipulation object's state block
@@ -289,6 +289,8 @@ def bench_workload(env="ReachHuman", shield="SSM", ik=False, envs_per_gpu=None, 
                           reward_shaping=True, collision_reward=0, safe_vel=0.01, seed=1234)
     n = envs_per_gpu or (8192 if env == "PickPlaceHumanCart" else ENVS_PER_GPU)
     wrappers = dict(ik_position_delta=dict(action_limit=0.15), collision_prevention=dict(replace_type=0, n_resamples=20)) if ik else {}
+    if collision_prevention and not ik:   # training/config/wrappers/safe.yaml (the `wrappers: safe` of human_reach_ppo_parallel.yaml): CollisionPreventionWrapper, replace_type 0, 20 resamples
+        wrappers["collision_prevention"] = dict(replace_type=0, n_resamples=20)
     if robot_geometry != "capsule":   # arm links as the convex hulls of their meshes: passed on to build_model_desc like the wrappers
         wrappers["robot_geometry"] = robot_geometry
     return dict(env=env, shield=shield, ik=bool(ik), n=n, env_kwargs=env_kwargs, wrappers=wrappers, pick_place=pick_place, robot_geometry=robot_geometry)
@@ -349,6 +351,8 @@ def main():
     ap.add_argument("--ik", action="store_true", help="Cartesian actions [dx,dy,dz,gripper] through the in-kernel IK front-end "
                     "(config/wrappers/safe_ik.yaml: IKPositionDeltaWrapper + CollisionPreventionWrapper), as the reference trains pick-place")
     ap.add_argument("--envs-per-gpu", type=int, default=None)
+    ap.add_argument("--collision-prevention", action="store_true", help="joint-space actions screened by the CollisionPreventionWrapper in the kernel prologue (config/wrappers/safe.yaml: "
+                    "replace_type 0, 20 resamples), as human_reach_ppo_parallel.yaml trains; named in config.workload")
     ap.add_argument("--robot-geometry", default="capsule", choices=["capsule", "hull"], help="collision geometry of the arm links: bounding capsules (default) or the convex "
                     "hulls of the link meshes (ReachHuman only; DESIGN.md D3); named in config.robot_geometry")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -394,7 +398,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
-    W = bench_workload(args.env, args.shield, args.ik, args.envs_per_gpu, args.robot_geometry)
+    W = bench_workload(args.env, args.shield, args.ik, args.envs_per_gpu, args.robot_geometry, args.collision_prevention)
     args.shield, n, env_kwargs, wrappers, pick_place = W["shield"], W["n"], W["env_kwargs"], W["wrappers"], W["pick_place"]
     G, desc, mixed_tasks, staggered = make_bench_batch(W, rank=rank, local_rank=local_rank, stagger=not args.no_stagger)
     dev = G.device
@@ -405,8 +409,9 @@ def main():
     if world > 1 or force:
         publish, finish, _ = make_gather(G, world, args.gather_mode)
 
+    rewrites_actions = args.ik or args.collision_prevention
     def one_step(k, exchange=True):
-        if args.ik:
+        if rewrites_actions:
             a = fresh[k & 1]
             a.copy_(pool[k % len(pool)])
             G.step(a)
@@ -461,7 +466,7 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "traffic_source": None, "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_env * n}
         # PMC figures: from the committed capture of the default workload's kernel (never from this run: a counter pass perturbs the timing)
-        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib and args.robot_geometry == "capsule"
+        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib and args.robot_geometry == "capsule" and not args.collision_prevention
         if default_workload:
             try:
                 with open(args.pmc_json) as f:
@@ -493,7 +498,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": f"{args.env}, {n} envs/GPU, shield {args.shield}, " + ("arm links as convex hulls, " if args.robot_geometry == "hull" else "") + "25 x 4 ms cycles/step, "
-                                   + ("Cartesian random actions via IK + collision prevention" if args.ik else "random actions U(-1,1)^7")
+                                   + ("Cartesian random actions via IK + collision prevention" if args.ik else ("random actions U(-1,1)^7 screened by collision prevention (replace_type 0, 20 resamples)" if args.collision_prevention else "random actions U(-1,1)^7"))
                                    + f", 13 synthetic clips, auto-reset, steady state ({preroll}-step pre-roll)",
                        "envs_per_gpu": n, "shield_type": args.shield, "robot_geometry": args.robot_geometry, "horizon": int(desc.horizon), "substeps_per_step": int(desc.n_cycles),
                        "preroll_steps": preroll, "episode_phases_staggered": staggered,

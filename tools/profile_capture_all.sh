@@ -37,6 +37,7 @@ rm -rf gpurun_out/${TAG}_mixed_trace
 python3 bench.py --env mixed --steps 200 --warmup 20 > $S/${TAG}_bench_mixed.json 2> gpurun_out/${TAG}_bench_mixed.err
 say geometry;   python3 bench.py --robot-geometry hull --no-cpu-baseline > $S/${TAG}_bench_hull.json 2> gpurun_out/${TAG}_bench_hull.err
 python3 bench.py --robot-geometry hull --shield OFF --no-cpu-baseline > $S/${TAG}_bench_hull_off.json 2>> gpurun_out/${TAG}_bench_hull.err
+python3 bench.py --collision-prevention --no-cpu-baseline > $S/${TAG}_bench_cp.json 2>> gpurun_out/${TAG}_bench_hull.err
 python3 bench.py --env PickPlaceHumanCart --no-cpu-baseline > $S/${TAG}_bench_pickplace.json 2> gpurun_out/${TAG}_bench_pp.err
 python3 bench.py --env PickPlaceHumanCart --ik --no-cpu-baseline > $S/${TAG}_bench_pickplace_ik.json 2>> gpurun_out/${TAG}_bench_pp.err
 fi
