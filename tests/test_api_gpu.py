@@ -308,3 +308,23 @@ def test_launch_order_stays_a_permutation_with_the_busy_envs_in_front():
             seen_busy = max(seen_busy, nb)
     assert seen_busy > 0          # random actions next to a moving human: some env brakes within 45 steps
     G.close()
+
+
+def test_reference_demo_configuration_hip_matches_oracle_backend():
+    """BASELINE configs[0] (demos/demo_reach_human_environment.py: one env, control_freq 5, horizon 1000, SSM, CollisionPreventionWrapper) through HipGymEnv:
+    the HIP stepper and the oracle backend, the demo's loop, step by step."""
+    from human_robot_gym_amd.vec_env import HipGymEnv
+    from helpers import OracleBackend
+    from test_vec_env import DEMO_KW, DEMO_CP, demo_rollout
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=600, max_frames=900)
+    desc = hrg.build_model_desc(DEMO_KW, n_clips=3, collision_prevention=DEMO_CP)
+    e_gpu = HipGymEnv(env_kwargs=DEMO_KW, clips=clips, collision_prevention=DEMO_CP)
+    e_cpu = HipGymEnv(env_kwargs=DEMO_KW, clips=clips, collision_prevention=DEMO_CP, backend=OracleBackend(desc, clips, 1))
+    og, oc = demo_rollout(e_gpu), demo_rollout(e_cpu)
+    assert len(og) == len(oc) == 100
+    for k, ((ob_g, r_g, d_g, i_g), (ob_c, r_c, d_c, i_c)) in enumerate(zip(og, oc)):
+        np.testing.assert_allclose(ob_g, ob_c, rtol=RTOL, atol=1e-6, err_msg=f"step {k}")
+        assert r_g == pytest.approx(r_c, rel=1e-5, abs=1e-6) and d_g == d_c
+        for key in ("failsafe_interventions", "n_collisions", "n_goal_reached", "action_resamples"):
+            assert i_g[key] == i_c[key], (k, key)
+    e_gpu.close(); e_cpu.close()

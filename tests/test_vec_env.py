@@ -259,3 +259,40 @@ def test_robot_geometry_reaches_the_model_through_the_vec_env():
     env.close()
     with pytest.raises(ValueError):
         hrg.build_model_desc(None, robot_geometry="mesh")
+
+
+# BASELINE configs[0]: the keyword set of demos/demo_reach_human_environment.py:41-62 (suite.make) + its CollisionPreventionWrapper (75-77)
+DEMO_KW = dict(robot_base_offset=[0, 0, 0], reward_shaping=True, control_freq=5, hard_reset=False, horizon=1000, shield_type="SSM", base_human_pos_offset=[1.0, 0.0, 0.0],
+               goal_dist=0.0001, human_rand=[1.0, 0.5, 0.2], seed=0)
+DEMO_CP = dict(replace_type=0, n_resamples=20)
+
+
+def demo_rollout(env, steps=100):
+    """the demo's loop (85-100) with an expert in the spirit of ReachHumanExpert: move along the goal difference, some noise"""
+    obs = env.reset()
+    rng = np.random.RandomState(0)
+    out = []
+    for t in range(steps):
+        gd = env.observation_dict(obs)["goal_difference"]
+        a = np.zeros(7)
+        a[:6] = np.clip(5.0 * gd + 0.05 * rng.randn(6), -1, 1)
+        obs, r, done, info = env.step(a)
+        out.append((obs.copy(), r, done, dict(info)))
+        if done:
+            break
+    return out
+
+
+def test_reference_demo_configuration_on_the_oracle_backend():
+    """One env, the demo's keywords, 100 steps of its loop: the 4-tuple API, the dense reward, the shield's counters, the wrapper's resample counter."""
+    clips = hrg.synthetic_clips(3, seed=0, min_frames=600, max_frames=900)
+    desc = hrg.build_model_desc(DEMO_KW, n_clips=3, collision_prevention=DEMO_CP)
+    assert desc.n_cycles == 50 and desc.horizon == 1000 and desc.goal_dist == 0.0001            # control_freq 5: 50 shield cycles per policy step
+    env = HipGymEnv(env_kwargs=DEMO_KW, clips=clips, collision_prevention=DEMO_CP, backend=OracleBackend(desc, clips, 1))
+    out = demo_rollout(env)
+    assert len(out) == 100 and not out[-1][2]
+    rewards = np.array([o[1] for o in out])
+    assert np.isfinite(rewards).all() and (rewards < 0).all() and rewards[-1] > rewards[0]       # dense reward = -distance to the goal: the expert closes in
+    info = out[-1][3]
+    assert info["n_goal_reached"] == 0 and "action_resamples" in info and info["failsafe_interventions"] >= 0
+    env.close()
