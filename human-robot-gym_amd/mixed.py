@@ -11,13 +11,14 @@ from ._cstruct import CONST
 from .animation import synthetic_clips
 from .model import build_model_desc
 
-# training/icra_2024_run_experiments.sh:4-9 (tasks the HIP stepper covers; horizons as there)
+# training/icra_2024_run_experiments.sh:4-9 (horizons as there) with the environment blocks of training/config_icra_2024/environment_evaluation/training/<task>-SAC.yaml: where
+# those differ from the task's general training config (ENV_DEFAULTS) the experiment's value is listed here (tests/test_assets.py compares every common keyword)
 ICRA_TASKS = (
-    ("ReachHuman", dict(horizon=100, shield_type="SSM")),
-    ("PickPlaceHumanCart", dict(horizon=1000, shield_type="SSM")),
+    ("ReachHuman", dict(horizon=100, shield_type="SSM", reward_shaping=True)),
+    ("PickPlaceHumanCart", dict(horizon=1000, shield_type="SSM", done_at_success=True)),
     ("CollaborativeLiftingCart", dict(horizon=5000, shield_type="SSM")),
-    ("RobotHumanHandoverCart", dict(horizon=1000, shield_type="PFL")),
-    ("HumanRobotHandoverCart", dict(horizon=1000, shield_type="PFL")),
+    ("RobotHumanHandoverCart", dict(horizon=1000, shield_type="PFL", collision_reward=0)),
+    ("HumanRobotHandoverCart", dict(horizon=1000, shield_type="PFL", collision_reward=0)),
     ("CollaborativeStackingCart", dict(horizon=3000, shield_type="SSM")),
 )
 

@@ -170,3 +170,22 @@ def test_keywords_outside_the_training_configs_are_the_constructor_defaults(env_
     skip = {"n_nail_placements_sampled_per_100_steps"} if env_id == "CollaborativeHammeringCart" else set()
     bad = {k: (mine[k], ctor[k]) for k in mine if k not in ref and k in ctor and k not in skip and not _same(mine[k], ctor[k])}
     assert not bad, bad
+
+
+def test_mixed_batch_tasks_are_the_icra_2024_experiment_configs():
+    """BASELINE configs[4]: training/icra_2024_run_experiments.sh:4-9 names the six tasks and their horizons; the `environment` block of each
+    config_icra_2024/environment_evaluation/training/<task>-SAC.yaml is what the experiment steps.  ENV_DEFAULTS overlaid with mixed.ICRA_TASKS has to agree with it."""
+    import re
+    import yaml
+    from human_robot_gym_amd import mixed, model as M
+    R = "/root/reference/human_robot_gym/training"
+    short = {"R": "ReachHuman", "PP": "PickPlaceHumanCart", "CL": "CollaborativeLiftingCart", "RHH": "RobotHumanHandoverCart", "HRH": "HumanRobotHandoverCart", "CS": "CollaborativeStackingCart"}
+    runs = re.findall(r"icra_2024_environment_evaluation\.sh (\w+) \w+ \d+ \d+ (\d+) ", open(f"{R}/icra_2024_run_experiments.sh").read())
+    assert [short[s] for s, _ in runs] == [t for t, _ in mixed.ICRA_TASKS]                      # the same six tasks, in the script's order
+    for (s, hz), (env_id, kw) in zip(runs, mixed.ICRA_TASKS):
+        assert int(hz) == kw["horizon"]
+        ref = yaml.safe_load(open(f"{R}/config_icra_2024/environment_evaluation/training/{s}-SAC.yaml"))["environment"]
+        assert ref["env_id"] == env_id
+        mine = dict(M.ENV_DEFAULTS[env_id], **kw)
+        bad = {k: (mine[k], ref[k]) for k in mine if k in ref and k != "seed" and not _same(mine[k], ref[k])}
+        assert not bad, (env_id, bad)
