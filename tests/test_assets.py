@@ -189,3 +189,22 @@ def test_mixed_batch_tasks_are_the_icra_2024_experiment_configs():
         mine = dict(M.ENV_DEFAULTS[env_id], **kw)
         bad = {k: (mine[k], ref[k]) for k in mine if k in ref and k != "seed" and not _same(mine[k], ref[k])}
         assert not bad, (env_id, bad)
+
+
+def test_nail_constants_are_nail_xml():
+    """models/assets/objects/nail.xml: the nail head's collision geom (cylinder r 0.02, half height 0.002 at +0.001), the stem (head 0.06 above the base), the slide
+    joint (axis -z, range 0 .. 0.06, frictionloss 10 000, solreffriction (-100, -100))."""
+    import xml.etree.ElementTree as ET
+    from human_robot_gym_amd import model as M
+    root = ET.parse("/root/reference/human_robot_gym/models/assets/objects/nail.xml").getroot()
+    head = root.find("body")
+    assert root.get("name") == "nail_base" and head.get("name") == "nail_head"
+    assert [float(x) for x in head.get("pos").split()] == [0.0, 0.0, M.NAIL["stem"]]
+    g = [x for x in head.findall("geom") if x.get("name") == "nail_head_g0"][0]
+    r, hh = (float(x) for x in g.get("size").split())
+    assert g.get("type") == "cylinder" and M.NAIL["head_half"] == [r, r, hh] and float(g.get("pos").split()[2]) == M.NAIL["head_dz"]
+    j = head.find("joint")
+    assert j.get("type") == "slide" and [float(x) for x in j.get("axis").split()] == [0.0, 0.0, -1.0]
+    assert [float(x) for x in j.get("range").split()] == [0.0, M.NAIL["range"]] and float(j.get("frictionloss")) == M.NAIL["frictionloss"]
+    assert [float(x) for x in j.get("solreffriction").split()] == [-M.NAIL["fric_damping"], -M.NAIL["fric_damping"]]
+    assert M.HAMMERING_ENV_KWARGS["nail_frictionloss"] == M.NAIL["frictionloss"]
