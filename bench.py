@@ -40,6 +40,7 @@ ENVS_PER_GPU = 4096
 HBM_PEAK_GBS = 8000.0     # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 FP64_VECTOR_PEAK_TF = 78.6  # MI355X FP64 vector peak
 DEFAULT_PMC = os.path.join(ROOT, "profiles", "r03_pmc.json")
+DEFAULT_PMC_PP = os.path.join(ROOT, "profiles", "r03pp_pmc.json")   # the committed capture of `--env PickPlaceHumanCart` (8192 envs, SSM)
 
 
 def algorithmic_bytes_per_env_step(C, state_bytes, n_cycles):
@@ -466,12 +467,14 @@ def main():
         roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                 "traffic_source": None, "kernel": kernel_name, "kernel_ms": kernel_ms, "launches": n_launch, "algorithmic_bytes_per_launch": per_env * n}
         # PMC figures: from the committed capture of the default workload's kernel (never from this run: a counter pass perturbs the timing)
-        default_workload = args.env == "ReachHuman" and n == ENVS_PER_GPU and args.shield == "SSM" and not args.ik and not args.variant_lib and args.robot_geometry == "capsule" and not args.collision_prevention
-        if default_workload:
+        plain = args.shield == "SSM" and not args.ik and not args.variant_lib and args.robot_geometry == "capsule" and not args.collision_prevention
+        default_workload = plain and args.env == "ReachHuman" and n == ENVS_PER_GPU
+        pmc_path = args.pmc_json if default_workload else (DEFAULT_PMC_PP if plain and args.env == "PickPlaceHumanCart" and n == 8192 and args.pmc_json == DEFAULT_PMC else None)
+        if pmc_path:
             try:
-                with open(args.pmc_json) as f:
+                with open(pmc_path) as f:
                     pmc = json.load(f)
-                src = os.path.relpath(args.pmc_json, ROOT)
+                src = os.path.relpath(pmc_path, ROOT)
                 roof["traffic"] = pmc.get("hbm_bytes_per_launch")
                 roof["traffic_source"] = f"{src}: {pmc.get('command', 'rocprofv3 --pmc passes of this command')} (committed capture, per launch; not collected by this run)"
                 for key in ("valu_insts_per_substep", "valu_busy_frac", "valu_lane_utilisation", "fp64_flops_per_launch"):

@@ -38,7 +38,9 @@ if pmc:
         fetch_raw, write = pmc["FETCH_SIZE"] * 1024, pmc["WRITE_SIZE"] * 1024
         traffic = dict(fetch_bytes_raw=fetch_raw, fetch_bytes_x2=2 * fetch_raw, write_bytes=write, hbm_bytes_per_launch=2 * fetch_raw + write,
                        note="FETCH_SIZE x2 per MI355X_MICROARCH.md (gfx950 tallies 128-B requests at 64 B); WRITE_SIZE exact")
-        traffic["command"] = "rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 (separate passes: FETCH_SIZE, WRITE_SIZE, SQ x3; tools/profile_capture.sh)"
+        traffic["command"] = ("rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --env PickPlaceHumanCart --steps 20 --warmup 3 --preroll 300 --no-cpu-baseline (separate passes: FETCH_SIZE, WRITE_SIZE, SQ; tools/profile_capture_pp.sh)"
+                              if tag.endswith("pp") else
+                              "rocprofv3 --pmc <counter set> --kernel-trace -- python3 bench.py --no-cpu-baseline --steps 20 --warmup 3 (separate passes: FETCH_SIZE, WRITE_SIZE, SQ x3; tools/profile_capture.sh)")
         # vector-pipe figures for bench.py's roofline object
         n_env, n_cyc = int(meta.get("Grid_Size", 0)) // 64, 25
         if "SQ_INSTS_VALU" in pmc and n_env:
