@@ -17,8 +17,19 @@ DI int hull_support_wave(const HullRef& H, const double* d, double* out) {
   const double dl0 = H.R[0] * d[0] + H.R[3] * d[1] + H.R[6] * d[2], dl1 = H.R[1] * d[0] + H.R[4] * d[1] + H.R[7] * d[2], dl2 = H.R[2] * d[0] + H.R[5] * d[1] + H.R[8] * d[2];
   double bv = -1e300;
   int bi = 0x7fffffff;
+  // four vertices per lane and trip: their twelve loads are in flight together (the table sits in L2; one wave per SIMD-slot pays the full latency per trip otherwise --
+  // link 4 has 2211 vertices = 35 trips per support call, ~ 8 calls per GJK query)
+  int i = lane;
 #pragma unroll 1
-  for (int i = lane; i < H.n; i += 64) {
+  for (; i + 192 < H.n; i += 256) {
+    double t[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const double* v = H.v + 3 * (i + 64 * u); t[u] = v[0] * dl0 + v[1] * dl1 + v[2] * dl2; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) if (t[u] > bv) { bv = t[u]; bi = i + 64 * u; }
+  }
+#pragma unroll 1
+  for (; i < H.n; i += 64) {
     const double t = H.v[3 * i] * dl0 + H.v[3 * i + 1] * dl1 + H.v[3 * i + 2] * dl2;
     if (t > bv) { bv = t; bi = i; }
   }
@@ -115,8 +126,10 @@ DI bool simplex_closest(int& n, double* v) {
 }
 
 // distance between the hull and the segment [s1, s2] (a capsule's axis, in LDS); witness points wa (on the hull) and wb (on the segment).  0 when they
-// intersect.  Wave-uniform result.
-DI double gjk_hull_segment_wave(const HullRef& H, const double* s1, const double* s2, double* wa, double* wb) {
+// intersect.  Wave-uniform result.  `cutoff`: the caller only asks whether the two come closer than this -- every support point w bounds the distance from below by
+// v.w / |v| (the supporting plane of the Minkowski difference), so the iteration stops at the first plane farther out than the cutoff and returns 1e300: the
+// narrowphase of a pair whose bounding capsules touch but whose hull is clear ends after one or two support calls instead of converging on a distance nobody uses.
+DI double gjk_hull_segment_wave(const HullRef& H, const double* s1, const double* s2, double* wa, double* wb, double cutoff = 1e300) {
   GjkLds& S = g_L.gjk;
   const bool w0 = hrg_lane() == 0;
   double v[3];
@@ -140,7 +153,9 @@ DI double gjk_hull_segment_wave(const HullRef& H, const double* s1, const double
     const int ib = v3dot(v, s2) > v3dot(v, s1) ? 1 : 0;
     v3cpy(b, ib ? s2 : s1);
     v3sub(w, a, b);
-    if (vv - v3dot(v, w) <= 1e-12 * vv) break;
+    const double vw = v3dot(v, w);
+    if (vw > 0 && vw * vw > cutoff * cutoff * vv) { v3set(wa, 0, 0, 0); v3set(wb, 0, 0, 0); return 1e300; }
+    if (vv - vw <= 1e-12 * vv) break;
     bool seen = false;
     for (int q = 0; q < n; q++) if (S.ia[q] == ia && S.ib[q] == ib) seen = true;
     if (seen) break;
@@ -162,14 +177,23 @@ DI void hull_lowest_wave(const HullRef& H, double* out) {
   const int lane = hrg_lane();
   const double r6 = H.R[6], r7 = H.R[7], r8 = H.R[8], pz = H.p[2];
   double zm = 1e300;
+  int i = lane;
 #pragma unroll 1
-  for (int i = lane; i < H.n; i += 64) {
+  for (; i + 192 < H.n; i += 256) {
+    double z[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const double* v = H.v + 3 * (i + 64 * u); z[u] = pz + r6 * v[0] + r7 * v[1] + r8 * v[2]; }
+#pragma unroll
+    for (int u = 0; u < 4; u++) zm = z[u] < zm ? z[u] : zm;
+  }
+#pragma unroll 1
+  for (; i < H.n; i += 64) {
     const double z = pz + r6 * H.v[3 * i] + r7 * H.v[3 * i + 1] + r8 * H.v[3 * i + 2];
     zm = z < zm ? z : zm;
   }
   const double zmin = -wave_max(-zm);
   double sx = 0, sy = 0, cnt = 0;
-#pragma unroll 1
+#pragma unroll 2
   for (int i = lane; i < H.n; i += 64) {
     const double vx = H.v[3 * i], vy = H.v[3 * i + 1], vz = H.v[3 * i + 2];
     const double z = pz + r6 * vx + r7 * vy + r8 * vz;

@@ -1369,7 +1369,7 @@ PH_COLLIDE void collide(const DevModel* __restrict__ dm_, int lane, int* ncon_ou
         if (g2 < GEOM_TABLE) {
           const int hb = g2 - GEOM_HUMAN0;
           double wa[3], wb[3];
-          const double dh = gjk_hull_segment_wave(H, &L.hcap[hb][0], &L.hcap[hb][3], wa, wb);
+          const double dh = gjk_hull_segment_wave(H, &L.hcap[hb][0], &L.hcap[hb][3], wa, wb, (m.hcap_r[hb] + m.contact_margin_human) * (1.0 + 1e-9));   // (a pair it cuts off is dropped below either way)
           if (dh > 1e-9 && lane == src) {
             const double dist = dh - m.hcap_r[hb];
             if (!(dist < m.contact_margin_human)) hit = false;
